@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE - NOT PRODUCT CODE.
+
+Generates tests/golden/*.npz from the UNMODIFIED reference, compiled out of
+/root/reference by oracle/Makefile into oracle/_ref/ref_dump (our driver
+oracle/ref_dump.f90 linked with the reference's objects).
+
+Run in the build container only (needs /root/reference and flang):
+
+    make -C oracle && python oracle/make_golden.py
+
+The fixtures are data only: inputs and the outputs the reference computed.
+Nothing here is needed at test time; tests read the committed .npz files.
+"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF_DIR = os.path.join(HERE, "_ref")
+GOLDEN = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+
+def run_dump(args, log=None):
+    """Run ref_dump in _ref/models (the .input files are opened relative to cwd,
+    README.md:34) with an unlimited stack: DGEXPV_FSP keeps a 5 GB local
+    workspace (KrylovSolver.f90:50-52)."""
+    cmd = "ulimit -s unlimited && exec ../ref_dump " + " ".join(args)
+    env = dict(os.environ, MKL_NUM_THREADS="1")
+    out = subprocess.run(["bash", "-c", cmd], cwd=os.path.join(REF_DIR, "models"),
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                         check=True, text=True).stdout
+    if log is not None:
+        with open(log, "w") as f:
+            f.write(out)
+    return out
+
+
+def read_fsp(path):
+    with open(path, "rb") as f:
+        ns, nr, n = np.fromfile(f, dtype=np.int32, count=3)
+        state = np.fromfile(f, dtype=np.int32, count=ns * n).reshape(n, ns)
+        adj = np.fromfile(f, dtype=np.int32, count=nr * n).reshape(n, nr)
+        offdiag = np.fromfile(f, dtype=np.float64, count=nr * n).reshape(n, nr)
+        diag = np.fromfile(f, dtype=np.float64, count=n)
+        vector = np.fromfile(f, dtype=np.float64, count=n)
+    # arrays are stored [state][slot] = the Fortran (slot, state) column-major
+    # layout of StateSpace.f90:13-17 read row-major
+    return dict(ns=int(ns), nr=int(nr), n=int(n), state=state, adj=adj,
+                offdiag=offdiag, diag=diag, vector=vector)
+
+
+def parse_log(text):
+    """Per-step records printed by PRINT_STATS (KrylovSolver.f90:641-651) and
+    every WSUM evaluation (:452)."""
+    fl = r"([-+0-9.Ee]+)"
+    steps = []
+    for m in re.finditer(r"TIMESTEP\s+(\d+)\s+-+\s*\n\s*FSP SIZE\s+=\s*(\d+)\s*\n\s*STEP_SIZE\s+=\s*" + fl +
+                         r"\s*\n\s*NEXT_STEP\s+=\s*" + fl + r"\s*\n\s*T_NOW\s+=\s*" + fl +
+                         r"\s*\n\s*KRYLOV DIMENSION\s+=\s*(\d+)", text):
+        steps.append((int(m.group(1)), int(m.group(2)), float(m.group(3)), float(m.group(4)),
+                      float(m.group(5)), int(m.group(6))))
+    wsum = [float(x) for x in re.findall(r"WSUM=\s*" + fl, text)]
+    s = np.array(steps, dtype=np.float64).reshape(-1, 6)
+    return dict(step_no=s[:, 0].astype(np.int32), step_n=s[:, 1].astype(np.int32), step_tau=s[:, 2],
+                step_next=s[:, 3], step_tnow=s[:, 4], step_m=s[:, 5].astype(np.int32),
+                wsum=np.array(wsum), n_ssa=np.int32(len(re.findall("CALLING SSA", text))),
+                n_reject=np.int32(len(re.findall("STEPSIZE REJECTED", text))),
+                n_dimchange=np.int32(len(re.findall("DIMENSION CHANGED", text))))
+
+
+SOLVE_CASES = {
+    # fixture name: (ref_dump case, T, FSPTOL, KRYTOL); tolerances must match
+    # oracle/ref_dump.f90 DO_SOLVE, T is passed as the override argument.
+    "toggle_input": ("toggle_input", 1000.0, 1e-4, 1e-10),
+    "toggle_example": ("toggle_example", 100.0, 1e-4, 1e-8),
+    # closed systems, FSP never changes.  The short horizons stay away from the
+    # stationary regime, where the reference's accept/reject decisions hinge on
+    # 1e-10-level rounding of the scaled-and-squared Pade and on the absolute
+    # happy-breakdown threshold (KrylovSolver.f90:249), so that an independent
+    # implementation follows the identical (tau, m) sequence.
+    "ring6": ("ring6", 20.0, 1e-4, 1e-10),
+    "ring6_T40": ("ring6", 40.0, 1e-4, 1e-10),
+    "ring6_long": ("ring6", 60.0, 1e-4, 1e-10),   # trajectory may fork late
+    "ring4": ("ring4", 6.2, 1e-6, 1e-8),
+}
+
+ASSEMBLY_CASES = [("toggle", 5), ("toggle", 10), ("toggle", 20),
+                  ("repressilator", 5), ("repressilator", 10),
+                  ("goutsias", 5), ("goutsias", 10), ("goutsias", 16)]
+
+
+def main():
+    if not os.path.exists(os.path.join(REF_DIR, "ref_dump")):
+        sys.exit("oracle/_ref/ref_dump missing: run `make -C oracle` where /root/reference exists")
+    os.makedirs(GOLDEN, exist_ok=True)
+    tmp = tempfile.mkdtemp(prefix="kfsp_golden_")
+
+    # G1: assembly (integer arrays bit-exact, StateSpace.f90:248-396)
+    for name, k in ASSEMBLY_CASES:
+        p = os.path.join(tmp, f"asm_{name}_{k}.bin")
+        run_dump(["assembly", name, str(k), p])
+        d = read_fsp(p)
+        d.pop("vector")
+        np.savez_compressed(os.path.join(GOLDEN, f"assembly_{name}_k{k}.npz"), k=np.int32(k), **d)
+        print(f"assembly {name} k={k}: N={d['n']}")
+
+    # G3/G6: CME_SOLVE end to end
+    for name, (case, T, fsptol, krytol) in SOLVE_CASES.items():
+        p = os.path.join(tmp, f"solve_{name}.bin")
+        text = run_dump(["solve", case, p, repr(T)])
+        din = read_fsp(p + ".in")
+        dout = read_fsp(p)
+        log = parse_log(text)
+        np.savez_compressed(
+            os.path.join(GOLDEN, f"solve_{name}.npz"),
+            T=T, fsptol=fsptol, krytol=krytol, ns=dout["ns"], nr=dout["nr"],
+            in_n=din["n"], in_state=din["state"], in_vector=din["vector"],
+            n=dout["n"], state=dout["state"], adj=dout["adj"], offdiag=dout["offdiag"],
+            diag=dout["diag"], vector=dout["vector"], **log)
+        print(f"solve {name}: N={dout['n']} steps={len(log['step_no'])} sum={dout['vector'].sum()!r}")
+
+    # G5: DGPADM
+    p = os.path.join(tmp, "padm.bin")
+    run_dump(["padm", p])
+    out = {}
+    with open(p, "rb") as f:
+        ncase = int(np.fromfile(f, dtype=np.int32, count=1)[0])
+        for c in range(ncase):
+            m = int(np.fromfile(f, dtype=np.int32, count=1)[0])
+            t = float(np.fromfile(f, dtype=np.float64, count=1)[0])
+            H = np.fromfile(f, dtype=np.float64, count=m * m).reshape(m, m).T.copy()
+            ns = int(np.fromfile(f, dtype=np.int32, count=1)[0])
+            E = np.fromfile(f, dtype=np.float64, count=m * m).reshape(m, m).T.copy()
+            out[f"m{c}"] = np.int32(m)
+            out[f"t{c}"] = t
+            out[f"H{c}"] = H
+            out[f"ns{c}"] = np.int32(ns)
+            out[f"E{c}"] = E
+    np.savez_compressed(os.path.join(GOLDEN, "padm.npz"), ncase=np.int32(ncase), **out)
+    print(f"padm: {ncase} cases")
+
+    # G4: parser propensity table (TestModelParser.f90:33-43)
+    p = os.path.join(tmp, "prop.bin")
+    run_dump(["proptable", p])
+    P = np.fromfile(p, dtype=np.float64).reshape(50, 50, 4)   # [i-1][j-1][r-1]
+    np.savez_compressed(os.path.join(GOLDEN, "proptable_toggle_test.npz"), P=P,
+                        params=np.array([5000.0, 1600.0, 1.0, 1.0]))
+    print("proptable: ok")
+
+
+if __name__ == "__main__":
+    main()
