@@ -1,0 +1,255 @@
+#!/usr/bin/env python3
+"""Benchmark of the exp(tA)v hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A timed "step" is one generator SpMV launch y = A x (FMATVEC, the dominant
+kernel of the path; with N > 1 ranks each launch is preceded by the RCCL
+all-gather of the source slab, exactly as in the solver).  The workload is
+BASELINE.json configs[2] - the configuration the SpMV-GB/s half of the metric is
+quoted on: repressilator_model.input propensities on a 171^3 box, N = 5 000 211
+states per GPU (weak scaling: the slowest box dimension grows with the number
+of ranks, rows are partitioned contiguously, no data-path collective except the
+all-gather the path itself has).  value = algorithmic GB/s of the whole job,
+B_alg = 12 nnz + 20 N per launch.
+
+The same JSON line carries
+  roofline      the SpMV kernel against the HBM roofline (HIP events on the
+                library's own stream, measured over the timed region)
+  expv          the exp(tA)v half of the metric: BASELINE configs[1] (toggle box
+                10^6 states per GPU, Krylov m = 30, tau = 0.01, 10 steps) wall
+                time per step and its l1 error against the CPU path
+  cpu_baseline  the oracle (plain-C port of the reference loops) on this host,
+                1 core, on a bounded sample of the same workload
+Inputs are synthetic and resident in HBM before the timed region starts.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c3x", "tiny"])
+    ap.add_argument("--variant", type=int, default=0, help="SpMV kernel variant (0 SELL, 1 CSR-stream)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-expv", action="store_true")
+    ap.add_argument("--expv-steps", type=int, default=10)
+    ap.add_argument("--opt", action="append", default=[], help="library option name=value")
+    return ap.parse_args()
+
+
+def spmv_model(workload, nranks):
+    from krylovfspssa_amd import synth
+    if workload == "c3":
+        return synth.repressilator(dims=(171, 171, 171 * nranks)), "repressilator_model.input propensities, box 171x171x(171*ranks)"
+    if workload == "c3x":
+        return synth.repressilator(dims=(216, 216, 216 * nranks)), "repressilator_model.input propensities, box 216x216x(216*ranks) (10^7 states/GPU)"
+    if workload == "c2":
+        return synth.toggle(1000, 1000 * nranks), "toggle_model.input propensities, box 1000x(1000*ranks)"
+    return synth.repressilator(dims=(40, 40, 40 * nranks)), "tiny repressilator box 40x40x(40*ranks)"
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched by torch.distributed.run with N ranks")
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from krylovfspssa_amd import KfspContext, synth
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    ctx = KfspContext(local_rank)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        ctx.set_option(k, int(v))
+    if args.variant == 1:
+        ctx.set_option("build_csr", 1)
+    if world > 1:
+        idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            idt.copy_(torch.from_numpy(KfspContext.unique_id()))
+        dist.broadcast(idt, 0)
+        ctx.comm_init(world, rank, idt.cpu().numpy())
+
+    # ---------------------------------------------------------------- SpMV
+    mdl, desc = spmv_model(args.workload, world)
+    row0, nrows = ctx.row_block(mdl.n)
+    t0 = time.time()
+    rowptr, col, val = mdl.csr_rows(row0, nrows)
+    t_gen = time.time() - t0
+    nnz_global = mdl.nnz()
+    ctx.set_matrix_csr(mdl.n, rowptr, col, val)
+    nnz_local = int(rowptr[-1])
+    x = np.random.default_rng(12345 + rank).random(nrows)
+    ctx.set_vector(x)
+    ctx.begin_step()                      # source column of the SpMV = x
+    info = ctx.matrix_info()
+    b_alg_global = synth.spmv_alg_bytes(nnz_global, mdl.n)
+    b_alg_local = synth.spmv_alg_bytes(nnz_local, nrows)
+
+    ctx.spmv_bench(max(args.warmup, 1), args.variant)
+    barrier()
+    t0 = time.perf_counter()
+    ms_events = ctx.spmv_bench(args.steps, args.variant)
+    barrier()
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+    ms_events = max_over_ranks(ms_events)
+    value = args.steps * b_alg_global / elapsed / 1e9
+    kern_ms = ms_events / args.steps
+    achieved = b_alg_local / (kern_ms * 1e-3) / 1e9
+
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(args.workload, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "cme_generator_spmv_GBps",
+        "value": round(value, 2),
+        "unit": "GB/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{args.workload}: {desc}; generator SpMV y=A x (FMATVEC) per step",
+            "states_per_gpu": int(nrows), "states_total": int(mdl.n),
+            "nnz_total": int(nnz_global), "alg_bytes_per_launch_total": int(b_alg_global),
+            "partition": f"rows x{world}" if world > 1 else "single GPU",
+            "kernel_variant": "sell64" if args.variant == 0 else "csr_stream",
+            "stored_slots_local": info["slots"],
+        },
+        "roofline": {
+            "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "kernel": "k_spmv (SELL-64 row gather)", "avg_launch_ms": round(kern_ms, 5),
+            "alg_bytes_per_launch": int(b_alg_local),
+            "note": "per-GPU algorithmic bytes (12 nnz + 20 N) / HIP-event time of the timed launches"
+                    + ("; includes the all-gather" if world > 1 else ""),
+        },
+        "input_generation_s": round(t_gen, 2),
+    }
+
+    # ---------------------------------------------------------------- expv
+    if not args.no_expv:
+        tg = synth.toggle(1000, 1000 * world) if args.workload != "tiny" else synth.toggle(100, 80 * world)
+        r0, nr = ctx.row_block(tg.n)
+        rp, cc, vv = tg.csr_rows(r0, nr)
+        ctx.set_matrix_csr(tg.n, rp, cc, vv)
+        p0 = synth.poisson_p0(tg, 30.0)
+        m, tau = 30, 0.01
+        ctx.set_vector(p0[r0:r0 + nr])
+        ctx.expv_fixed(m, tau, 1)                 # warm-up
+        ctx.set_vector(p0[r0:r0 + nr])
+        barrier()
+        t0 = time.perf_counter()
+        ws = ctx.expv_fixed(m, tau, args.expv_steps)
+        barrier()
+        t_expv = max_over_ranks(time.perf_counter() - t0)
+        w_gpu = ctx.get_vector()
+        nnz_t = tg.nnz()
+        # reference (unfused) byte count of one fixed-m step
+        b_step = (m + 1) * synth.spmv_alg_bytes(nnz_t, tg.n) + m * 104 * tg.n + 8 * tg.n * (m + 1) + 24 * tg.n
+        out["expv"] = {
+            "workload": f"c2: toggle_model.input propensities, box 1000x(1000*ranks), N={tg.n}, Krylov m={m}, tau={tau}, {args.expv_steps} steps",
+            "ms_per_step": round(t_expv / args.expv_steps * 1e3, 4),
+            "wall_s": round(t_expv, 5),
+            "alg_GBps": round(args.expv_steps * b_step / t_expv / 1e9, 1),
+            "mass_final": float(ws[-1]),
+            "timers_ms": ctx.timers(),
+        }
+    else:
+        tg = None
+
+    # ---------------------------------------------------------- CPU baseline
+    if rank == 0 and world == 1 and not args.no_cpu:
+        from oracle import oracle as O
+        O.lib()
+        adj, off, diag = mdl.ell()
+        A = O.EllMatrix(adj, off, diag)
+        xc = np.random.default_rng(12345).random(mdl.n)
+        O.spmv_ell(A, xc)
+        reps = 0
+        t0 = time.perf_counter()
+        while True:
+            O.spmv_ell(A, xc)
+            reps += 1
+            dt = time.perf_counter() - t0
+            if dt > 12.0 or reps >= 400:
+                break
+        cpu_gbs = reps * b_alg_global / dt / 1e9
+        out["cpu_baseline"] = {
+            "value": round(cpu_gbs, 3), "unit": "GB/s", "cores": 1, "kind": "port",
+            "sample": f"{reps} scatter-form SpMVs (KrylovSolver.f90:593-606 loop order) on the same {args.workload} "
+                      f"matrix, {dt:.1f} s, 1 of {os.cpu_count()} host cores",
+            "ms_per_spmv": round(dt / reps * 1e3, 3),
+        }
+        del A, adj, off, diag
+        if tg is not None:
+            adj, off, diag = tg.ell()
+            A = O.EllMatrix(adj, off, diag)
+            ncpu = 2
+            t0 = time.perf_counter()
+            wc, wsc = O.expv_fixed(A, synth.poisson_p0(tg, 30.0), 30, 0.01, ncpu)
+            dtc = time.perf_counter() - t0
+            out["cpu_baseline"]["expv_ms_per_step"] = round(dtc / ncpu * 1e3, 2)
+            out["cpu_baseline"]["expv_sample"] = f"{ncpu} steps of the c2 recipe"
+            # parity of the GPU result after the same number of steps
+            ctx.set_vector(synth.poisson_p0(tg, 30.0))
+            ctx.expv_fixed(30, 0.01, ncpu)
+            out["expv"]["l1_err_vs_cpu"] = float(np.abs(ctx.get_vector() - wc).sum())
+            out["expv"]["l1_err_steps"] = ncpu
+
+    ctx.close()
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,146 @@
+/*
+ * kfsp.h - C ABI of libkfsp_hip: the exp(tA)v hot path of the Krylov-FSP CME
+ * solver on one MI355X (gfx950) per process.
+ *
+ * The reference (voduchuy/KrylovFspSsa) has no FFI; its seams are Fortran
+ * internal.  Each entry point below names the reference code it stands in for
+ * (paths relative to the reference tree).  The host side that drives these
+ * (the Fortran modules under krylovfspssa_amd/fortran through ISO_C_BINDING, or the ctypes mirror
+ * krylovfspssa_amd/host.py) keeps the reference's own interface.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every array argument is HOST memory unless
+ *     its name ends in _dev.  The library copies on set_* and owns all device
+ *     memory until kfsp_destroy.  No pointer is retained past a call.
+ *   - return value: 0 ok; <0 = index of the bad argument (like IFLAG,
+ *     KrylovSolver.f90:142-149); >0 = 1000+hipError_t or 2000+ncclResult_t.
+ *     Never exits, never throws.  kfsp_last_error() gives the text.
+ *   - indices in reference-layout arrays are 1-based exactly as the reference
+ *     stores them; CSR entry points are 0-based.
+ *   - one host thread per context; calls return when their host-visible
+ *     outputs are valid (device work is synchronised inside).
+ *   - there is NO CPU fallback: without a usable GPU kfsp_create fails.
+ */
+#ifndef KFSP_H
+#define KFSP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct kfsp_ctx kfsp_ctx;
+
+#define KFSP_M_MAX 100            /* KrylovSolver.f90:47 */
+#define KFSP_UNIQUE_ID_BYTES 128  /* sizeof(ncclUniqueId) */
+
+/* ---- context --------------------------------------------------------- */
+/* Replaces the solver's static workspace WSP/IWSP (KrylovSolver.f90:50-52). */
+int kfsp_create(int device, kfsp_ctx **out);
+int kfsp_destroy(kfsp_ctx *ctx);
+const char *kfsp_last_error(const kfsp_ctx *ctx);
+/* library/ABI version, bumped on any signature change */
+int kfsp_abi_version(void);
+
+/* ---- multi-GPU (row partition; no counterpart in the serial reference) -- */
+/* rank 0 creates the id, the host launcher broadcasts the bytes, every rank
+ * calls kfsp_comm_init.  After it, n-arguments below stay GLOBAL sizes and
+ * each context owns the contiguous row block
+ *   [rank*L, min((rank+1)*L, n)),  L = ceil(n / nranks) rounded up to 64. */
+int kfsp_comm_unique_id(void *id_bytes /* [KFSP_UNIQUE_ID_BYTES] */);
+int kfsp_comm_init(kfsp_ctx *ctx, int nranks, int rank, const void *id_bytes);
+int kfsp_row_block(const kfsp_ctx *ctx, int64_t n, int64_t *row0, int64_t *nrows);
+
+/* ---- generator ------------------------------------------------------- */
+/* TYPE FSP_MATRIX verbatim (StateSpace.f90:13-17): ADJ(bw,n) int32 1-based
+ * (0 = successor outside the FSP, -1 = illegal), OFFDIAG(bw,n), DIAG(n)
+ * (positive), leading dimension ld >= bw.  Builds the row-gather form on the
+ * device.  Call again whenever the FSP changed (after MATRIX_STARTER /
+ * ONESTEP_EXTENDER / SSA_EXTENDER / DROP_STATES: KrylovSolver.f90:130-134,
+ * 511, 528-529). */
+int kfsp_set_matrix_ell(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld,
+                        const int32_t *adj, const double *offdiag, const double *diag);
+/* Synthetic / pre-transposed input: gather rows [row0, row0+nrows) of an
+ * n x n generator in CSR, 0-based GLOBAL column indices, the diagonal stored
+ * as an ordinary (negative) entry.  rowptr has nrows+1 entries starting at 0. */
+int kfsp_set_matrix_csr(kfsp_ctx *ctx, int64_t n, int64_t row0, int64_t nrows,
+                        const int64_t *rowptr, const int32_t *col, const double *val);
+/* what the device holds: rows (local), stored off-diagonal slots incl. padding,
+ * true nonzeros incl. diagonal (local rows) */
+int kfsp_matrix_info(const kfsp_ctx *ctx, int64_t *nrows, int64_t *slots, int64_t *nnz);
+
+/* ---- probability vector w (the solver's W == FSP%VECTOR, KrylovSolver.f90:33-34) */
+/* local row block of the context (the whole vector when nranks == 1) */
+int kfsp_set_vector(kfsp_ctx *ctx, int64_t nlocal, const double *w);
+int kfsp_get_vector(kfsp_ctx *ctx, int64_t nlocal, double *w);
+
+/* ---- the hot path ---------------------------------------------------- */
+/* beta = ||w||_2 and v_1 = w / beta.  KrylovSolver.f90:177/540 and :223-226. */
+int kfsp_begin_step(kfsp_ctx *ctx, double *beta);
+
+/* IOP Arnoldi columns jold..m plus the extra product for AVNORM.
+ * KrylovSolver.f90:236-266: FMATVEC, DDOT/DAXPY over the last qiop vectors,
+ * DNRM2, happy-breakdown test, DSCAL; then H(m+2,m+1) = 1.
+ * H is the host Hessenberg image, column-major, leading dimension ldh >= m+2;
+ * columns jold..m (and the corner) are written, others left alone.
+ * *mbrkdwn = m or the breakdown column; *k1 = 2 or 0 (:250); *avnorm as :263.
+ * The basis stays on the device; a later call with jold > 1 extends it
+ * (dimension change, :400-432), including the reference's behaviour when the
+ * dimension shrank below jold (extra product taken from column jold). */
+int kfsp_arnoldi(kfsp_ctx *ctx, int m, int jold, int qiop, double break_tol,
+                 double *H, int ldh, int *mbrkdwn, int *k1, double *avnorm);
+
+/* w = beta * V(:,1:mx) * y ; w = max(w,0) ; *wsum = ||w||_1.
+ * KrylovSolver.f90:444 (DGEMV), :447-449 (clamp), :450 (DASUM) in one pass. */
+int kfsp_combine(kfsp_ctx *ctx, int mx, double beta, const double *y, double *wsum);
+
+/* w = beta * v_1 : the FSP-rejection path, KrylovSolver.f90:467. */
+int kfsp_restore_w(kfsp_ctx *ctx, double beta);
+
+/* y = A x through the device kernel (the FMATVEC seam, KrylovSolver.f90:577;
+ * also what DROP_STATES receives as its matvec, StateSpace.f90:486).
+ * x: full length-n vector on every rank, y: local row block. */
+int kfsp_spmv(kfsp_ctx *ctx, const double *x, double *y);
+/* y = A w for the resident w (DROP_STATES, StateSpace.f90:486), local rows */
+int kfsp_spmv_w(kfsp_ctx *ctx, double *y);
+
+/* single reductions over the resident w (tests; FIND_DROPTOL-style sums) */
+int kfsp_nrm2_w(kfsp_ctx *ctx, double *out);
+int kfsp_asum_w(kfsp_ctx *ctx, double *out);
+/* copy basis column j (1-based, normalised) of the local block to the host */
+int kfsp_get_basis(kfsp_ctx *ctx, int j, int64_t nlocal, double *v);
+
+/* ---- host dense kernel (stays on the host by design) ------------------ */
+/* exp(t*H), (ideg,ideg) Pade + scaling/squaring = DGPADM / DGPADMnorm
+ * (src/expokit/dgpadm.f:2-169, :171-339).  E: m*m column-major (ld m). */
+int kfsp_padm(int ideg, int m, double t, const double *H, int ldh, double *E,
+              int *ns, double *hnorm);
+
+/* ---- benchmark mode --------------------------------------------------- */
+/* nsteps steps of fixed Krylov dimension m and fixed step tau on the resident
+ * w (BASELINE config 2, "m=30"): begin_step, arnoldi(1..m), Pade of order m+2,
+ * combine with mx = m+1.  wsums[nsteps] = mass after each step. */
+int kfsp_expv_fixed(kfsp_ctx *ctx, int m, double tau, int nsteps, double *wsums);
+
+/* reps back-to-back launches of the SpMV kernel y = A v_1 on the context's
+ * stream, bracketed by HIP events: *ms_total = elapsed GPU time.  With
+ * nranks > 1 every launch is preceded by the all-gather of the source slab,
+ * as in the solver.  variant selects the kernel (0 = default). */
+int kfsp_spmv_bench(kfsp_ctx *ctx, int reps, int variant, float *ms_total);
+
+/* accumulated device time (ms) by phase since the last reset; HIP-event based
+ * and only collected when enabled (it adds synchronisation). */
+enum { KFSP_T_SPMV = 0, KFSP_T_ORTHO = 1, KFSP_T_COMBINE = 2, KFSP_T_COMM = 3,
+       KFSP_T_HOST_PADE = 4, KFSP_T_UPLOAD = 5, KFSP_T_COUNT = 6 };
+int kfsp_timers_enable(kfsp_ctx *ctx, int on);
+int kfsp_get_timers(kfsp_ctx *ctx, double *ms /* [KFSP_T_COUNT] */, int reset);
+
+/* tuning knobs (name/value); unknown name -> -2.  "grid_blocks", "nt_loads",
+ * "deterministic" ... see DESIGN.md */
+int kfsp_set_option(kfsp_ctx *ctx, const char *name, int64_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

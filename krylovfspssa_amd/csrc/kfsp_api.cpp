@@ -1,0 +1,1039 @@
+// Host side of libkfsp_hip: the C ABI of include/kfsp.h, the device context
+// (basis, vectors, generator, scalar staging), the ELL -> SELL transpose, the
+// RCCL row-partition plumbing and the host Pade exponential.
+#include "../../include/kfsp.h"
+#include "kfsp_internal.h"
+
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+
+using namespace kfsp;
+
+namespace {
+
+constexpr int kAbiVersion = 1;
+constexpr int kNumPartial = 4;   // rotating block-partial buffers
+constexpr int kNumStage = 8;     // rotating all-reduce staging scalars
+
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t n, bool zero)
+    {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), n * sizeof(T));
+        if (e != hipSuccess) return e;
+        cap = n;
+        if (zero) e = hipMemset(p, 0, n * sizeof(T));
+        return e;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+
+}  // namespace
+
+struct kfsp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+
+    // partition
+    int nranks = 1, rank = 0;
+    ncclComm_t comm = nullptr;
+
+    // sizes
+    int64_t n = 0;        // global states
+    int64_t L = 0;        // rows per rank (padded block length), multiple of 64
+    int64_t row0 = 0;     // first global row of this rank
+    int64_t nloc = 0;     // rows owned
+    int64_t ldv = 0;      // column stride of the basis, multiple of 256
+
+    // generator
+    DevBuf<int64_t> d_off;
+    DevBuf<int32_t> d_col;
+    DevBuf<double> d_val, d_diag;
+    int64_t nchunks = 0, slots = 0, nnz = 0;
+    // optional CSR copy for the CSR-stream kernel variant
+    DevBuf<int64_t> d_rowptr;
+    DevBuf<int32_t> d_ccol, d_tile;
+    DevBuf<double> d_cval;
+    int64_t ntiles = 0;
+    bool want_csr = false, have_csr = false;
+
+    // vectors
+    DevBuf<double> d_V;    // (kMMax+2) columns, stride ldv, unnormalised basis
+    DevBuf<double> d_w;    // probability vector, ldv
+    DevBuf<double> d_xg;   // nranks*L gathered source (nranks > 1) or scratch x (kfsp_spmv)
+    DevBuf<double> d_tmp;  // ldv scratch (kfsp_spmv output)
+
+    // scalars
+    DevBuf<double> d_part;   // kNumPartial * kMaxGrid
+    DevBuf<double> d_stage;  // kNumStage
+    DevBuf<double> d_H;      // kMH * kMH image + 2 (avnorm^2, avnorm)
+    DevBuf<double> d_sq;     // finished squared norms, index = column (1-based)
+    DevBuf<double> d_y;      // kMH coefficients
+    DevBuf<int> d_flag;
+    int part_rr = 0, stage_rr = 0;
+    std::vector<double> h_H;
+    double avnorm_last = 0.0;
+
+    // options
+    int64_t opt_grid = 0;   // 0 = auto
+    int64_t opt_nt = -1;    // -1 auto, 0 off, 1 on
+    bool timers = false;
+    double t_ms[KFSP_T_COUNT] = {0, 0, 0, 0, 0, 0};
+};
+
+namespace {
+
+int fail(kfsp_ctx *c, int code, const char *what)
+{
+    if (c) c->err = what;
+    return code;
+}
+
+int hip_fail(kfsp_ctx *c, hipError_t e, const char *where)
+{
+    if (c) c->err = std::string(where) + ": " + hipGetErrorString(e);
+    return 1000 + (int)e;
+}
+
+int nccl_fail(kfsp_ctx *c, ncclResult_t r, const char *where)
+{
+    if (c) c->err = std::string(where) + ": " + ncclGetErrorString(r);
+    return 2000 + (int)r;
+}
+
+#define HIP_TRY(expr)                                          \
+    do {                                                       \
+        hipError_t e_ = (expr);                                \
+        if (e_ != hipSuccess) return hip_fail(ctx, e_, #expr); \
+    } while (0)
+
+#define NCCL_TRY(expr)                                           \
+    do {                                                         \
+        ncclResult_t r_ = (expr);                                \
+        if (r_ != ncclSuccess) return nccl_fail(ctx, r_, #expr); \
+    } while (0)
+
+int spmv_grid(const kfsp_ctx *c)
+{
+    int64_t g = round_up((c->nchunks + 3) / 4, 8);
+    if (c->opt_grid > 0) g = std::min<int64_t>(g, round_up(c->opt_grid, 8));
+    g = std::min<int64_t>(g, kMaxGrid);
+    return (int)std::max<int64_t>(g, 8);
+}
+
+// Rows the streaming kernels touch: the SELL-padded local block.  Every pass
+// rewrites exactly these rows of every column it uses, so stale data beyond
+// them (left by a larger, earlier FSP) is never read.
+int64_t act_pairs(const kfsp_ctx *c) { return c->nchunks * (kChunk / 2); }
+
+int vec_grid(const kfsp_ctx *c)
+{
+    int64_t g = (act_pairs(c) + kBlock - 1) / kBlock;
+    if (c->opt_grid > 0) g = std::min<int64_t>(g, c->opt_grid);
+    g = std::min<int64_t>(g, kMaxGrid);
+    return (int)std::max<int64_t>(g, 1);
+}
+
+bool use_nt(const kfsp_ctx *c)
+{
+    if (c->opt_nt >= 0) return c->opt_nt != 0;
+    // stream the generator around the caches only when it cannot stay in the
+    // 256 MiB Infinity Cache between two products anyway
+    return (double)c->slots * 12.0 > 192.0 * 1024 * 1024;
+}
+
+double *next_partial(kfsp_ctx *c)
+{
+    double *p = c->d_part.p + (size_t)c->part_rr * kMaxGrid;
+    c->part_rr = (c->part_rr + 1) % kNumPartial;
+    return p;
+}
+
+SellDev sell_of(const kfsp_ctx *c)
+{
+    return SellDev{c->nloc, c->nchunks, c->d_off.p, c->d_col.p, c->d_val.p, c->d_diag.p};
+}
+
+// Make block partials a scalar every rank agrees on.
+int publish(kfsp_ctx *ctx, Pending local, Pending *out)
+{
+    if (ctx->nranks == 1) {
+        *out = local;
+        return 0;
+    }
+    double *st = ctx->d_stage.p + ctx->stage_rr;
+    ctx->stage_rr = (ctx->stage_rr + 1) % kNumStage;
+    launch_finalize(local, st, nullptr, ctx->stream);
+    NCCL_TRY(ncclAllReduce(st, st, 1, ncclDouble, ncclSum, ctx->comm, ctx->stream));
+    *out = Pending{st, 1};
+    return 0;
+}
+
+// The source column must be visible in full on every rank before a product.
+int gather_source(kfsp_ctx *ctx, const double *src_local, const double **xg)
+{
+    if (ctx->nranks == 1) {
+        *xg = src_local;
+        return 0;
+    }
+    NCCL_TRY(ncclAllGather(src_local, ctx->d_xg.p, (size_t)ctx->L, ncclDouble, ctx->comm, ctx->stream));
+    *xg = ctx->d_xg.p;
+    return 0;
+}
+
+// (Re)size everything that depends on the number of states.
+int resize(kfsp_ctx *ctx, int64_t n)
+{
+    ctx->n = n;
+    ctx->L = round_up((n + ctx->nranks - 1) / ctx->nranks, kChunk);
+    if (ctx->L == 0) ctx->L = kChunk;
+    ctx->row0 = (int64_t)ctx->rank * ctx->L;
+    ctx->nloc = std::max<int64_t>(0, std::min<int64_t>(ctx->L, n - ctx->row0));
+    const int64_t ldv = round_up(ctx->L, 256);
+    if (ldv > ctx->ldv || (size_t)ldv * (kMMax + 2) > ctx->d_V.cap) {
+        // grow with head room: the FSP usually keeps growing
+        const int64_t cap = round_up(ldv + ldv / 2, 256);
+        HIP_TRY(ctx->d_V.reserve((size_t)cap * (kMMax + 2), false));
+        HIP_TRY(ctx->d_w.reserve((size_t)cap, false));
+        HIP_TRY(ctx->d_tmp.reserve((size_t)cap, false));
+    }
+    if (ldv != ctx->ldv) {
+        ctx->ldv = ldv;
+        // padding rows must read as zero in every kernel
+        HIP_TRY(hipMemsetAsync(ctx->d_V.p, 0, (size_t)ldv * (kMMax + 2) * sizeof(double), ctx->stream));
+        HIP_TRY(hipMemsetAsync(ctx->d_w.p, 0, (size_t)ldv * sizeof(double), ctx->stream));
+        HIP_TRY(hipMemsetAsync(ctx->d_tmp.p, 0, (size_t)ldv * sizeof(double), ctx->stream));
+    }
+    const size_t xg = (size_t)std::max<int64_t>(ctx->L * ctx->nranks, ldv);
+    if (xg > ctx->d_xg.cap) HIP_TRY(ctx->d_xg.reserve(xg + xg / 2, true));
+    return 0;
+}
+
+// Upload gather rows given as per-row counts + a fill callback.
+struct HostSell {
+    std::vector<int64_t> off;
+    std::vector<int32_t> col;
+    std::vector<double> val, diag;
+    int64_t nchunks = 0, nnz = 0;
+};
+
+void sell_layout(const std::vector<int32_t> &cnt, int64_t nloc, int64_t row0, HostSell &S)
+{
+    S.nchunks = (nloc + kChunk - 1) / kChunk;
+    S.off.assign((size_t)S.nchunks + 1, 0);
+    for (int64_t c = 0; c < S.nchunks; ++c) {
+        int w = 0;
+        const int64_t r1 = std::min<int64_t>(nloc, (c + 1) * kChunk);
+        for (int64_t r = c * kChunk; r < r1; ++r) w = std::max(w, (int)cnt[(size_t)r]);
+        S.off[(size_t)c + 1] = S.off[(size_t)c] + (int64_t)w * kChunk;
+    }
+    const size_t slots = (size_t)S.off[(size_t)S.nchunks];
+    S.col.resize(slots);
+    S.val.assign(slots, 0.0);
+    // padded slots gather the row's own x (always a valid address)
+    for (int64_t c = 0; c < S.nchunks; ++c) {
+        const int64_t o = S.off[(size_t)c], w = (S.off[(size_t)c + 1] - o) / kChunk;
+        for (int64_t k = 0; k < w; ++k)
+            for (int l = 0; l < kChunk; ++l) {
+                const int64_t r = std::min<int64_t>(c * kChunk + l, nloc > 0 ? nloc - 1 : 0);
+                S.col[(size_t)(o + k * kChunk + l)] = (int32_t)(row0 + r);
+            }
+    }
+    S.diag.assign((size_t)S.nchunks * kChunk, 0.0);
+}
+
+int upload_sell(kfsp_ctx *ctx, const HostSell &S)
+{
+    ctx->nchunks = S.nchunks;
+    ctx->slots = S.off[(size_t)S.nchunks];
+    ctx->nnz = S.nnz;
+    HIP_TRY(ctx->d_off.reserve(S.off.size(), false));
+    HIP_TRY(ctx->d_col.reserve(std::max<size_t>(S.col.size(), 64), false));
+    HIP_TRY(ctx->d_val.reserve(std::max<size_t>(S.val.size(), 64), false));
+    HIP_TRY(ctx->d_diag.reserve(std::max<size_t>(S.diag.size(), 64), false));
+    HIP_TRY(hipMemcpyAsync(ctx->d_off.p, S.off.data(), S.off.size() * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    if (!S.col.empty()) {
+        HIP_TRY(hipMemcpyAsync(ctx->d_col.p, S.col.data(), S.col.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(ctx->d_val.p, S.val.data(), S.val.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    }
+    if (!S.diag.empty())
+        HIP_TRY(hipMemcpyAsync(ctx->d_diag.p, S.diag.data(), S.diag.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// CSR copy (off-diagonal entries, row order) + tiles of whole rows for the
+// CSR-stream kernel, derived from the SELL image.
+int upload_csr_from_sell(kfsp_ctx *ctx, const HostSell &S, const std::vector<int32_t> &cnt)
+{
+    const int64_t nloc = ctx->nloc;
+    std::vector<int64_t> rowptr((size_t)nloc + 1, 0);
+    for (int64_t r = 0; r < nloc; ++r) rowptr[(size_t)r + 1] = rowptr[(size_t)r] + cnt[(size_t)r];
+    std::vector<int32_t> col((size_t)rowptr[(size_t)nloc]);
+    std::vector<double> val(col.size());
+    for (int64_t r = 0; r < nloc; ++r) {
+        const int64_t c = r / kChunk, l = r % kChunk, o = S.off[(size_t)c];
+        for (int k = 0; k < cnt[(size_t)r]; ++k) {
+            col[(size_t)(rowptr[(size_t)r] + k)] = S.col[(size_t)(o + (int64_t)k * kChunk + l)];
+            val[(size_t)(rowptr[(size_t)r] + k)] = S.val[(size_t)(o + (int64_t)k * kChunk + l)];
+        }
+    }
+    std::vector<int32_t> tile{0};
+    int64_t r = 0;
+    while (r < nloc) {
+        int64_t e = r;
+        while (e < nloc && e - r < kBlock && rowptr[(size_t)e + 1] - rowptr[(size_t)r] <= 2048) ++e;
+        if (e == r) return fail(ctx, -2, "row longer than a CSR-stream tile");
+        tile.push_back((int32_t)e);
+        r = e;
+    }
+    ctx->ntiles = (int64_t)tile.size() - 1;
+    HIP_TRY(ctx->d_rowptr.reserve(rowptr.size(), false));
+    HIP_TRY(ctx->d_ccol.reserve(std::max<size_t>(col.size(), 64), false));
+    HIP_TRY(ctx->d_cval.reserve(std::max<size_t>(val.size(), 64), false));
+    HIP_TRY(ctx->d_tile.reserve(tile.size(), false));
+    HIP_TRY(hipMemcpy(ctx->d_rowptr.p, rowptr.data(), rowptr.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    if (!col.empty()) {
+        HIP_TRY(hipMemcpy(ctx->d_ccol.p, col.data(), col.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ctx->d_cval.p, val.data(), val.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipMemcpy(ctx->d_tile.p, tile.data(), tile.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    ctx->have_csr = true;
+    return 0;
+}
+
+// ---- host dense exponential (dgpadm.f:2-169 semantics) -------------------
+struct Dense {
+    int m;
+    std::vector<double> a;
+    explicit Dense(int m_) : m(m_), a((size_t)m_ * m_, 0.0) {}
+    double &operator()(int i, int j) { return a[(size_t)j * m + i]; }
+    double operator()(int i, int j) const { return a[(size_t)j * m + i]; }
+};
+
+// C = alpha * A * B
+void matmul(double alpha, const Dense &A, const Dense &B, Dense &C)
+{
+    const int m = A.m;
+    std::fill(C.a.begin(), C.a.end(), 0.0);
+    for (int j = 0; j < m; ++j)
+        for (int k = 0; k < m; ++k) {
+            const double b = alpha * B(k, j);
+            if (b == 0.0) continue;
+            const double *ak = &A.a[(size_t)k * m];
+            double *cj = &C.a[(size_t)j * m];
+            for (int i = 0; i < m; ++i) cj[i] += b * ak[i];
+        }
+}
+
+// X <- Q^{-1} X by Gaussian elimination with row pivoting; false if singular
+bool solve_in_place(Dense &Q, Dense &X)
+{
+    const int m = Q.m;
+    for (int k = 0; k < m; ++k) {
+        int p = k;
+        for (int i = k + 1; i < m; ++i)
+            if (std::fabs(Q(i, k)) > std::fabs(Q(p, k))) p = i;
+        if (Q(p, k) == 0.0) return false;
+        if (p != k)
+            for (int j = 0; j < m; ++j) {
+                std::swap(Q(k, j), Q(p, j));
+                std::swap(X(k, j), X(p, j));
+            }
+        for (int i = k + 1; i < m; ++i) {
+            const double f = Q(i, k) / Q(k, k);
+            if (f == 0.0) continue;
+            Q(i, k) = 0.0;
+            for (int j = k + 1; j < m; ++j) Q(i, j) -= f * Q(k, j);
+            for (int j = 0; j < m; ++j) X(i, j) -= f * X(k, j);
+        }
+    }
+    for (int j = 0; j < m; ++j)
+        for (int i = m - 1; i >= 0; --i) {
+            double s = X(i, j);
+            for (int k = i + 1; k < m; ++k) s -= Q(i, k) * X(k, j);
+            X(i, j) = s / Q(i, i);
+        }
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int kfsp_abi_version(void) { return kAbiVersion; }
+
+int kfsp_padm(int ideg, int m, double t, const double *H, int ldh, double *E, int *ns_out, double *hnorm_out)
+{
+    if (ideg < 1 || ideg > 20) return -1;
+    if (m < 1) return -2;
+    if (!H) return -4;
+    if (ldh < m) return -5;
+    if (!E) return -6;
+    Dense A(m);
+    double hnorm = 0.0;
+    for (int i = 0; i < m; ++i) {
+        double rs = 0.0;
+        for (int j = 0; j < m; ++j) {
+            A(i, j) = H[(size_t)j * ldh + i];
+            rs += std::fabs(A(i, j));
+        }
+        hnorm = std::max(hnorm, rs);
+    }
+    hnorm = std::fabs(t * hnorm);
+    if (hnorm_out) *hnorm_out = hnorm;
+    if (hnorm == 0.0) return -3;   // 'null H', dgpadm.f:84
+    const int ns = std::max(0, (int)(std::log(hnorm) / std::log(2.0)) + 2);
+    if (ns_out) *ns_out = ns;
+    const double scale = t / std::ldexp(1.0, ns);
+
+    std::vector<double> c((size_t)ideg + 1);
+    c[0] = 1.0;
+    for (int k = 1; k <= ideg; ++k)
+        c[(size_t)k] = c[(size_t)k - 1] * (double)(ideg + 1 - k) / (double)(k * (2 * ideg + 1 - k));
+
+    Dense H2(m), P(m), Q(m), T(m);
+    matmul(scale * scale, A, A, H2);
+    for (int i = 0; i < m; ++i) {
+        P(i, i) = c[(size_t)ideg - 1];
+        Q(i, i) = c[(size_t)ideg];
+    }
+    // Horner in H2, alternately on the even (q) and odd (p) coefficient sets
+    bool odd = true;
+    for (int k = ideg - 1; k > 0; --k) {
+        Dense &U = odd ? Q : P;
+        matmul(1.0, U, H2, T);
+        for (int i = 0; i < m; ++i) T(i, i) += c[(size_t)k - 1];
+        std::swap(U.a, T.a);
+        odd = !odd;
+    }
+    {
+        Dense &U = odd ? Q : P;
+        matmul(scale, U, A, T);
+        std::swap(U.a, T.a);
+    }
+    for (size_t i = 0; i < Q.a.size(); ++i) Q.a[i] -= P.a[i];
+    if (!solve_in_place(Q, P)) return -7;
+    for (double &x : P.a) x *= 2.0;
+    for (int i = 0; i < m; ++i) P(i, i) += 1.0;
+    if (ns == 0 && odd) {
+        for (double &x : P.a) x = -x;
+    } else {
+        for (int k = 0; k < ns; ++k) {
+            matmul(1.0, P, P, T);
+            std::swap(P.a, T.a);
+        }
+    }
+    std::memcpy(E, P.a.data(), P.a.size() * sizeof(double));
+    return 0;
+}
+
+int kfsp_create(int device, kfsp_ctx **out)
+{
+    if (!out) return -2;
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) return 1000 + (int)(e == hipSuccess ? hipErrorNoDevice : e);
+    if (device < 0 || device >= count) return -1;
+    std::unique_ptr<kfsp_ctx> c(new kfsp_ctx);
+    kfsp_ctx *ctx = c.get();
+    ctx->device = device;
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&ctx->ev0));
+    HIP_TRY(hipEventCreate(&ctx->ev1));
+    HIP_TRY(ctx->d_part.reserve((size_t)kNumPartial * kMaxGrid, true));
+    HIP_TRY(ctx->d_stage.reserve(kNumStage, true));
+    HIP_TRY(ctx->d_H.reserve((size_t)kMH * kMH + 2, true));
+    HIP_TRY(ctx->d_sq.reserve(kMH + 2, true));
+    HIP_TRY(ctx->d_y.reserve(kMH, true));
+    HIP_TRY(ctx->d_flag.reserve(4, true));
+    ctx->h_H.assign((size_t)kMH * kMH + 2, 0.0);
+    *out = c.release();
+    return 0;
+}
+
+int kfsp_destroy(kfsp_ctx *ctx)
+{
+    if (!ctx) return 0;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->comm) (void)ncclCommDestroy(ctx->comm);
+    ctx->d_off.release(); ctx->d_col.release(); ctx->d_val.release(); ctx->d_diag.release();
+    ctx->d_rowptr.release(); ctx->d_ccol.release(); ctx->d_cval.release(); ctx->d_tile.release();
+    ctx->d_V.release(); ctx->d_w.release(); ctx->d_xg.release(); ctx->d_tmp.release();
+    ctx->d_part.release(); ctx->d_stage.release(); ctx->d_H.release(); ctx->d_sq.release();
+    ctx->d_y.release(); ctx->d_flag.release();
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return 0;
+}
+
+const char *kfsp_last_error(const kfsp_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int kfsp_comm_unique_id(void *id_bytes)
+{
+    if (!id_bytes) return -1;
+    static_assert(sizeof(ncclUniqueId) == KFSP_UNIQUE_ID_BYTES, "ncclUniqueId size");
+    ncclUniqueId id;
+    ncclResult_t r = ncclGetUniqueId(&id);
+    if (r != ncclSuccess) return 2000 + (int)r;
+    std::memcpy(id_bytes, &id, sizeof(id));
+    return 0;
+}
+
+int kfsp_comm_init(kfsp_ctx *ctx, int nranks, int rank, const void *id_bytes)
+{
+    if (!ctx) return -1;
+    if (nranks < 1) return fail(ctx, -2, "nranks < 1");
+    if (rank < 0 || rank >= nranks) return fail(ctx, -3, "rank out of range");
+    if (nranks > 1 && !id_bytes) return fail(ctx, -4, "null unique id");
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (ctx->comm) {
+        (void)ncclCommDestroy(ctx->comm);
+        ctx->comm = nullptr;
+    }
+    ctx->nranks = nranks;
+    ctx->rank = rank;
+    if (nranks > 1) {
+        ncclUniqueId id;
+        std::memcpy(&id, id_bytes, sizeof(id));
+        NCCL_TRY(ncclCommInitRank(&ctx->comm, nranks, id, rank));
+    }
+    ctx->ldv = 0;   // force re-layout on the next matrix
+    return 0;
+}
+
+int kfsp_row_block(const kfsp_ctx *ctx, int64_t n, int64_t *row0, int64_t *nrows)
+{
+    if (!ctx) return -1;
+    if (n < 0) return -2;
+    int64_t L = round_up((n + ctx->nranks - 1) / ctx->nranks, kChunk);
+    if (L == 0) L = kChunk;
+    const int64_t r0 = (int64_t)ctx->rank * L;
+    if (row0) *row0 = std::min(r0, n);
+    if (nrows) *nrows = std::max<int64_t>(0, std::min<int64_t>(L, n - r0));
+    return 0;
+}
+
+int kfsp_set_matrix_ell(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, const int32_t *adj,
+                        const double *offdiag, const double *diag)
+{
+    if (!ctx) return -1;
+    if (n < 1) return fail(ctx, -2, "n < 1");
+    if (bw < 1) return fail(ctx, -3, "bw < 1");
+    if (ld < bw) return fail(ctx, -4, "ld < bw");
+    if (!adj) return fail(ctx, -5, "null adj");
+    if (!offdiag) return fail(ctx, -6, "null offdiag");
+    if (!diag) return fail(ctx, -7, "null diag");
+    HIP_TRY(hipSetDevice(ctx->device));
+    auto t0 = std::chrono::steady_clock::now();
+    if (int rc = resize(ctx, n)) return rc;
+    const int64_t row0 = ctx->row0, nloc = ctx->nloc;
+
+    // in-degree of every local row
+    std::vector<int32_t> cnt((size_t)std::max<int64_t>(nloc, 1), 0);
+    for (int64_t i = 0; i < n; ++i) {
+        const int32_t *a = adj + (size_t)i * ld;
+        for (int j = 0; j < bw; ++j) {
+            const int64_t k = a[j];
+            if (k > n) return fail(ctx, -5, "adj entry exceeds n");
+            if (k >= 1) {
+                const int64_t r = k - 1 - row0;
+                if (r >= 0 && r < nloc) ++cnt[(size_t)r];
+            }
+        }
+    }
+    HostSell S;
+    sell_layout(cnt, nloc, row0, S);
+    std::vector<int32_t> fill((size_t)std::max<int64_t>(nloc, 1), 0);
+    int64_t nnz = nloc;
+    // sources in increasing order: each row's entries end up sorted by column,
+    // the order in which FMATVEC (:598-604) accumulates them
+    for (int64_t i = 0; i < n; ++i) {
+        const int32_t *a = adj + (size_t)i * ld;
+        const double *o = offdiag + (size_t)i * ld;
+        for (int j = 0; j < bw; ++j) {
+            const int64_t k = a[j];
+            if (k < 1) continue;
+            const int64_t r = k - 1 - row0;
+            if (r < 0 || r >= nloc) continue;
+            const int64_t c = r / kChunk, l = r % kChunk;
+            const int64_t pos = S.off[(size_t)c] + (int64_t)fill[(size_t)r]++ * kChunk + l;
+            S.col[(size_t)pos] = (int32_t)i;
+            S.val[(size_t)pos] = o[j];
+            ++nnz;
+        }
+    }
+    for (int64_t r = 0; r < nloc; ++r) S.diag[(size_t)r] = diag[(size_t)(row0 + r)];
+    S.nnz = nnz;
+    if (int rc = upload_sell(ctx, S)) return rc;
+    ctx->have_csr = false;
+    if (ctx->want_csr)
+        if (int rc = upload_csr_from_sell(ctx, S, cnt)) return rc;
+    ctx->t_ms[KFSP_T_UPLOAD] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return 0;
+}
+
+int kfsp_set_matrix_csr(kfsp_ctx *ctx, int64_t n, int64_t row0, int64_t nrows, const int64_t *rowptr,
+                        const int32_t *col, const double *val)
+{
+    if (!ctx) return -1;
+    if (n < 1 || n > 2147483647LL - 512) return fail(ctx, -2, "n out of range");
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (int rc = resize(ctx, n)) return rc;
+    if (row0 != std::min(ctx->row0, n)) return fail(ctx, -3, "row0 is not this rank's block start (kfsp_row_block)");
+    if (nrows != ctx->nloc) return fail(ctx, -4, "nrows is not this rank's block size (kfsp_row_block)");
+    if (!rowptr) return fail(ctx, -5, "null rowptr");
+    if (nrows > 0 && (!col || !val)) return fail(ctx, -6, "null col/val");
+    if (rowptr[0] != 0) return fail(ctx, -5, "rowptr[0] != 0");
+    auto t0 = std::chrono::steady_clock::now();
+    const int64_t nloc = ctx->nloc;
+    std::vector<int32_t> cnt((size_t)std::max<int64_t>(nloc, 1), 0);
+    for (int64_t r = 0; r < nloc; ++r) {
+        if (rowptr[r + 1] < rowptr[r]) return fail(ctx, -5, "rowptr not monotone");
+        int c = 0;
+        for (int64_t p = rowptr[r]; p < rowptr[r + 1]; ++p) {
+            if (col[p] < 0 || col[p] >= n) return fail(ctx, -6, "column index out of range");
+            if (col[p] != row0 + r) ++c;
+        }
+        cnt[(size_t)r] = c;
+    }
+    HostSell S;
+    sell_layout(cnt, nloc, ctx->row0, S);
+    for (int64_t r = 0; r < nloc; ++r) {
+        const int64_t c = r / kChunk, l = r % kChunk;
+        int k = 0;
+        double d = 0.0;
+        for (int64_t p = rowptr[r]; p < rowptr[r + 1]; ++p) {
+            if (col[p] == row0 + r) {
+                d += val[p];
+            } else {
+                const int64_t pos = S.off[(size_t)c] + (int64_t)k++ * kChunk + l;
+                S.col[(size_t)pos] = col[p];
+                S.val[(size_t)pos] = val[p];
+            }
+        }
+        S.diag[(size_t)r] = -d;   // kept positive like DIAG (StateSpace.f90:16)
+    }
+    S.nnz = rowptr[nloc];
+    if (int rc = upload_sell(ctx, S)) return rc;
+    ctx->have_csr = false;
+    if (ctx->want_csr)
+        if (int rc = upload_csr_from_sell(ctx, S, cnt)) return rc;
+    ctx->t_ms[KFSP_T_UPLOAD] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return 0;
+}
+
+int kfsp_matrix_info(const kfsp_ctx *ctx, int64_t *nrows, int64_t *slots, int64_t *nnz)
+{
+    if (!ctx) return -1;
+    if (nrows) *nrows = ctx->nloc;
+    if (slots) *slots = ctx->slots;
+    if (nnz) *nnz = ctx->nnz;
+    return 0;
+}
+
+int kfsp_set_vector(kfsp_ctx *ctx, int64_t nlocal, const double *w)
+{
+    if (!ctx) return -1;
+    if (ctx->ldv == 0) return fail(ctx, -1, "no matrix set");
+    if (nlocal != ctx->nloc) return fail(ctx, -2, "nlocal is not this rank's block size");
+    if (!w && nlocal > 0) return fail(ctx, -3, "null w");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemsetAsync(ctx->d_w.p, 0, (size_t)ctx->ldv * sizeof(double), ctx->stream));
+    if (nlocal > 0)
+        HIP_TRY(hipMemcpyAsync(ctx->d_w.p, w, (size_t)nlocal * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int kfsp_get_vector(kfsp_ctx *ctx, int64_t nlocal, double *w)
+{
+    if (!ctx) return -1;
+    if (nlocal != ctx->nloc) return fail(ctx, -2, "nlocal is not this rank's block size");
+    if (!w && nlocal > 0) return fail(ctx, -3, "null w");
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (nlocal > 0)
+        HIP_TRY(hipMemcpyAsync(w, ctx->d_w.p, (size_t)nlocal * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int kfsp_begin_step(kfsp_ctx *ctx, double *beta)
+{
+    if (!ctx) return -1;
+    if (ctx->ldv == 0) return fail(ctx, -1, "no matrix set");
+    if (!beta) return fail(ctx, -2, "null beta");
+    HIP_TRY(hipSetDevice(ctx->device));
+    double *part = next_partial(ctx);
+    const int g = vec_grid(ctx);
+    launch_copy_nrm2(g, act_pairs(ctx), ctx->d_w.p, ctx->d_V.p, part, ctx->stream);
+    Pending s;
+    if (int rc = publish(ctx, Pending{part, g}, &s)) return rc;
+    double *hb = ctx->d_H.p + (size_t)kMH * kMH;   // scratch pair behind the H image
+    launch_finalize(s, ctx->d_sq.p + 1, hb, ctx->stream);
+    HIP_TRY(hipMemcpyAsync(beta, hb, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int kfsp_arnoldi(kfsp_ctx *ctx, int m, int jold, int qiop, double break_tol, double *H, int ldh,
+                 int *mbrkdwn, int *k1, double *avnorm)
+{
+    if (!ctx) return -1;
+    if (ctx->ldv == 0) return fail(ctx, -1, "no matrix set");
+    if (m < 1 || m > kMMax || (int64_t)m >= std::max<int64_t>(ctx->n, 2)) return fail(ctx, -2, "bad m (need 1 <= m <= 100, m < n)");
+    if (jold < 1 || jold > kMMax) return fail(ctx, -3, "bad jold");
+    if (qiop < 0) return fail(ctx, -4, "bad qiop");
+    if (!H) return fail(ctx, -6, "null H");
+    if (ldh < m + 2) return fail(ctx, -7, "ldh < m+2");
+    if (!mbrkdwn || !k1 || !avnorm) return fail(ctx, -8, "null output");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int64_t ldv = ctx->ldv;
+    const int gs = spmv_grid(ctx), gv = vec_grid(ctx);
+    const bool nt = use_nt(ctx);
+    double *V = ctx->d_V.p, *Hd = ctx->d_H.p, *sq = ctx->d_sq.p;
+    int *flag = ctx->d_flag.p;
+    HIP_TRY(hipMemsetAsync(flag, 0, sizeof(int), st));
+    // entries this pass will not write must not look like a breakdown
+    HIP_TRY(hipMemsetAsync(Hd, 0, (size_t)kMH * kMH * sizeof(double), st));
+
+    Pending pend_sq{sq + jold, 1};
+    for (int j = jold; j <= m; ++j) {
+        const double *src = V + (size_t)(j - 1) * ldv;
+        double *dst = V + (size_t)j * ldv;
+        const double *xg = nullptr;
+        if (int rc = gather_source(ctx, src, &xg)) return rc;
+        const int istart = (qiop > 0) ? std::max(1, j - qiop + 1) : 1;
+        SpmvArgs a;
+        a.A = sell_of(ctx);
+        a.xg = xg;
+        a.row0 = ctx->nranks == 1 ? 0 : ctx->row0;
+        a.y = dst;
+        a.sq = pend_sq;
+        a.sq_final = sq + j;
+        a.h_sub = (j > jold) ? Hd + (size_t)(j - 2) * kMH + (j - 1) : nullptr;   // H(j,j-1)
+        a.udot = V + (size_t)(istart - 1) * ldv;
+        a.partial = next_partial(ctx);
+        a.break_tol = (j > jold) ? break_tol : -1.0;
+        a.brk_flag = flag;
+        launch_spmv(1, gs, a, nt, st);
+        Pending pend;
+        if (int rc = publish(ctx, Pending{a.partial, gs}, &pend)) return rc;
+        for (int i = istart; i <= j; ++i) {
+            OrthoArgs o;
+            o.npairs = act_pairs(ctx);
+            o.w = dst;
+            o.ui = V + (size_t)(i - 1) * ldv;
+            o.dot = pend;
+            o.sq_i = sq + i;
+            o.unext = (i < j) ? V + (size_t)i * ldv : nullptr;
+            o.partial = next_partial(ctx);
+            o.h_out = Hd + (size_t)(j - 1) * kMH + (i - 1);   // H(i,j)
+            o.brk_flag = flag;
+            launch_ortho(gv, o, st);
+            if (int rc = publish(ctx, Pending{o.partial, gv}, &pend)) return rc;
+        }
+        pend_sq = pend;
+    }
+    // the extra product for AVNORM (:261-263); taken from column jold when the
+    // dimension shrank below jold (J1V is only advanced inside the loop)
+    const bool looped = jold <= m;
+    const int jl = looped ? m + 1 : jold;
+    {
+        const double *src = V + (size_t)(jl - 1) * ldv;
+        const double *xg = nullptr;
+        if (int rc = gather_source(ctx, src, &xg)) return rc;
+        SpmvArgs a;
+        a.A = sell_of(ctx);
+        a.xg = xg;
+        a.row0 = ctx->nranks == 1 ? 0 : ctx->row0;
+        a.y = V + (size_t)jl * ldv;
+        a.sq = looped ? pend_sq : Pending{sq + jold, 1};
+        a.sq_final = sq + jl;
+        a.h_sub = looped ? Hd + (size_t)(m - 1) * kMH + m : nullptr;   // H(m+1,m)
+        a.udot = nullptr;
+        a.partial = next_partial(ctx);
+        a.break_tol = looped ? break_tol : -1.0;
+        a.brk_flag = flag;
+        launch_spmv(2, gs, a, nt, st);
+        Pending pend;
+        if (int rc = publish(ctx, Pending{a.partial, gs}, &pend)) return rc;
+        launch_finalize(pend, Hd + (size_t)kMH * kMH, Hd + (size_t)kMH * kMH + 1, st);
+    }
+    HIP_TRY(hipMemcpyAsync(ctx->h_H.data(), Hd, ((size_t)kMH * kMH + 2) * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+
+    const std::vector<double> &hh = ctx->h_H;
+    *mbrkdwn = m;
+    *k1 = 2;
+    for (int j = jold; j <= m; ++j) {
+        const int istart = (qiop > 0) ? std::max(1, j - qiop + 1) : 1;
+        for (int i = istart; i <= j; ++i) H[(size_t)(j - 1) * ldh + (i - 1)] = hh[(size_t)(j - 1) * kMH + (i - 1)];
+        const double hj1j = hh[(size_t)(j - 1) * kMH + j];
+        if (!(hj1j > break_tol)) {   // :249-256
+            *k1 = 0;
+            *mbrkdwn = j;
+            break;
+        }
+        H[(size_t)(j - 1) * ldh + j] = hj1j;
+    }
+    if (*k1 != 0) ctx->avnorm_last = hh[(size_t)kMH * kMH + 1];
+    *avnorm = ctx->avnorm_last;
+    H[(size_t)m * ldh + (m + 1)] = 1.0;   // :266
+    return 0;
+}
+
+int kfsp_combine(kfsp_ctx *ctx, int mx, double beta, const double *y, double *wsum)
+{
+    if (!ctx) return -1;
+    if (ctx->ldv == 0) return fail(ctx, -1, "no matrix set");
+    if (mx < 1 || mx > kMMax + 2) return fail(ctx, -2, "bad mx");
+    if (!y) return fail(ctx, -4, "null y");
+    if (!wsum) return fail(ctx, -5, "null wsum");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    HIP_TRY(hipMemcpyAsync(ctx->d_y.p, y, (size_t)mx * sizeof(double), hipMemcpyHostToDevice, st));
+    CombineArgs a;
+    a.npairs = act_pairs(ctx);
+    a.mx = mx;
+    a.beta = beta;
+    a.V = ctx->d_V.p;
+    a.ldv = ctx->ldv;
+    a.sq = ctx->d_sq.p;
+    a.y = ctx->d_y.p;
+    a.w = ctx->d_w.p;
+    a.partial = next_partial(ctx);
+    const int g = vec_grid(ctx);
+    launch_combine(g, a, st);
+    Pending s;
+    if (int rc = publish(ctx, Pending{a.partial, g}, &s)) return rc;
+    double *hb = ctx->d_H.p + (size_t)kMH * kMH;
+    launch_finalize(s, hb, nullptr, st);
+    HIP_TRY(hipMemcpyAsync(wsum, hb, sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
+int kfsp_restore_w(kfsp_ctx *ctx, double beta)
+{
+    if (!ctx) return -1;
+    if (ctx->ldv == 0) return fail(ctx, -1, "no matrix set");
+    HIP_TRY(hipSetDevice(ctx->device));
+    launch_scale_copy(vec_grid(ctx), act_pairs(ctx), ctx->d_V.p, ctx->d_sq.p + 1, beta, ctx->d_w.p, ctx->stream);
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+static int spmv_plain(kfsp_ctx *ctx, const double *src_local_or_full, bool src_is_full, double *y_dev)
+{
+    const double *xg = src_local_or_full;
+    if (!src_is_full)
+        if (int rc = gather_source(ctx, src_local_or_full, &xg)) return rc;
+    SpmvArgs a;
+    a.A = sell_of(ctx);
+    a.xg = xg;
+    a.row0 = (ctx->nranks == 1) ? 0 : ctx->row0;
+    a.y = y_dev;
+    a.sq = Pending{nullptr, 0};
+    a.sq_final = nullptr;
+    a.h_sub = nullptr;
+    a.udot = nullptr;
+    a.partial = nullptr;
+    a.break_tol = -1.0;
+    a.brk_flag = ctx->d_flag.p;
+    launch_spmv(0, spmv_grid(ctx), a, use_nt(ctx), ctx->stream);
+    return 0;
+}
+
+int kfsp_spmv(kfsp_ctx *ctx, const double *x, double *y)
+{
+    if (!ctx) return -1;
+    if (ctx->ldv == 0) return fail(ctx, -1, "no matrix set");
+    if (!x) return fail(ctx, -2, "null x");
+    if (!y && ctx->nloc > 0) return fail(ctx, -3, "null y");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    HIP_TRY(hipMemsetAsync(ctx->d_xg.p, 0, ctx->d_xg.cap * sizeof(double), st));
+    if (ctx->nranks == 1) {
+        HIP_TRY(hipMemcpyAsync(ctx->d_xg.p, x, (size_t)ctx->n * sizeof(double), hipMemcpyHostToDevice, st));
+    } else {
+        // global index of row k of rank p is p*L + k
+        for (int p = 0; p < ctx->nranks; ++p) {
+            const int64_t b = (int64_t)p * ctx->L, cnt = std::min<int64_t>(ctx->L, ctx->n - b);
+            if (cnt > 0)
+                HIP_TRY(hipMemcpyAsync(ctx->d_xg.p + b, x + b, (size_t)cnt * sizeof(double), hipMemcpyHostToDevice, st));
+        }
+    }
+    if (int rc = spmv_plain(ctx, ctx->d_xg.p, true, ctx->d_tmp.p)) return rc;
+    if (ctx->nloc > 0)
+        HIP_TRY(hipMemcpyAsync(y, ctx->d_tmp.p, (size_t)ctx->nloc * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
+int kfsp_spmv_w(kfsp_ctx *ctx, double *y)
+{
+    if (!ctx) return -1;
+    if (ctx->ldv == 0) return fail(ctx, -1, "no matrix set");
+    if (!y && ctx->nloc > 0) return fail(ctx, -2, "null y");
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (int rc = spmv_plain(ctx, ctx->d_w.p, false, ctx->d_tmp.p)) return rc;
+    if (ctx->nloc > 0)
+        HIP_TRY(hipMemcpyAsync(y, ctx->d_tmp.p, (size_t)ctx->nloc * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+static int reduce_w(kfsp_ctx *ctx, int squared, double *out)
+{
+    if (!ctx) return -1;
+    if (ctx->ldv == 0) return fail(ctx, -1, "no matrix set");
+    if (!out) return fail(ctx, -2, "null out");
+    HIP_TRY(hipSetDevice(ctx->device));
+    double *part = next_partial(ctx);
+    const int g = vec_grid(ctx);
+    launch_reduce(g, act_pairs(ctx), ctx->d_w.p, squared, part, ctx->stream);
+    Pending s;
+    if (int rc = publish(ctx, Pending{part, g}, &s)) return rc;
+    double *hb = ctx->d_H.p + (size_t)kMH * kMH;
+    launch_finalize(s, hb, hb + 1, ctx->stream);
+    HIP_TRY(hipMemcpyAsync(out, squared ? hb + 1 : hb, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int kfsp_nrm2_w(kfsp_ctx *ctx, double *out) { return reduce_w(ctx, 1, out); }
+int kfsp_asum_w(kfsp_ctx *ctx, double *out) { return reduce_w(ctx, 0, out); }
+
+int kfsp_get_basis(kfsp_ctx *ctx, int j, int64_t nlocal, double *v)
+{
+    if (!ctx) return -1;
+    if (ctx->ldv == 0) return fail(ctx, -1, "no matrix set");
+    if (j < 1 || j > kMMax + 2) return fail(ctx, -2, "bad column");
+    if (nlocal != ctx->nloc) return fail(ctx, -3, "nlocal is not this rank's block size");
+    if (!v && nlocal > 0) return fail(ctx, -4, "null v");
+    HIP_TRY(hipSetDevice(ctx->device));
+    double sq = 0.0;
+    HIP_TRY(hipMemcpyAsync(&sq, ctx->d_sq.p + j, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (nlocal > 0)
+        HIP_TRY(hipMemcpyAsync(v, ctx->d_V.p + (size_t)(j - 1) * ctx->ldv, (size_t)nlocal * sizeof(double),
+                               hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const double s = 1.0 / std::sqrt(sq);
+    for (int64_t i = 0; i < nlocal; ++i) v[i] *= s;
+    return 0;
+}
+
+int kfsp_expv_fixed(kfsp_ctx *ctx, int m, double tau, int nsteps, double *wsums)
+{
+    if (!ctx) return -1;
+    if (ctx->ldv == 0) return fail(ctx, -1, "no matrix set");
+    if (m < 1 || m > kMMax || (int64_t)m >= ctx->n) return fail(ctx, -2, "bad m");
+    if (nsteps < 0) return fail(ctx, -4, "bad nsteps");
+    const int mh = m + 2;
+    std::vector<double> H((size_t)mh * mh), E((size_t)mh * mh);
+    for (int s = 0; s < nsteps; ++s) {
+        double beta = 0.0, avn = 0.0, hn = 0.0;
+        int mb = m, k1 = 2, ns = 0;
+        if (int rc = kfsp_begin_step(ctx, &beta)) return rc;
+        std::fill(H.begin(), H.end(), 0.0);
+        if (int rc = kfsp_arnoldi(ctx, m, 1, 2, 1.0e-7, H.data(), mh, &mb, &k1, &avn)) return rc;
+        int mx = mb + k1;
+        auto t0 = std::chrono::steady_clock::now();
+        if (int rc = kfsp_padm(6, mx, tau, H.data(), mh, E.data(), &ns, &hn)) return fail(ctx, rc, "kfsp_padm failed");
+        ctx->t_ms[KFSP_T_HOST_PADE] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        mx = mb + std::max(0, k1 - 1);
+        double ws = 0.0;
+        if (int rc = kfsp_combine(ctx, mx, beta, E.data(), &ws)) return rc;
+        if (wsums) wsums[s] = ws;
+    }
+    return 0;
+}
+
+int kfsp_spmv_bench(kfsp_ctx *ctx, int reps, int variant, float *ms_total)
+{
+    if (!ctx) return -1;
+    if (ctx->ldv == 0) return fail(ctx, -1, "no matrix set");
+    if (reps < 1) return fail(ctx, -2, "reps < 1");
+    if (variant < 0 || variant > 1) return fail(ctx, -3, "unknown variant");
+    if (variant == 1 && !ctx->have_csr) return fail(ctx, -3, "CSR variant needs option build_csr=1 before the matrix is set");
+    if (!ms_total) return fail(ctx, -4, "null ms_total");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const double *src = ctx->d_V.p;
+    double *dst = ctx->d_V.p + ctx->ldv;
+    HIP_TRY(hipEventRecord(ctx->ev0, st));
+    for (int r = 0; r < reps; ++r) {
+        if (variant == 0) {
+            if (int rc = spmv_plain(ctx, src, false, dst)) return rc;
+        } else {
+            const double *xg = nullptr;
+            if (int rc = gather_source(ctx, src, &xg)) return rc;
+            CsrDev A{ctx->nloc, ctx->d_rowptr.p, ctx->d_ccol.p, ctx->d_cval.p, ctx->d_diag.p, ctx->d_tile.p, ctx->ntiles};
+            const int g = (int)std::min<int64_t>(ctx->ntiles, kMaxGrid);
+            launch_spmv_csr_stream(std::max(g, 1), A, xg, ctx->nranks == 1 ? 0 : ctx->row0, dst, st);
+        }
+    }
+    HIP_TRY(hipEventRecord(ctx->ev1, st));
+    HIP_TRY(hipEventSynchronize(ctx->ev1));
+    HIP_TRY(hipEventElapsedTime(ms_total, ctx->ev0, ctx->ev1));
+    return 0;
+}
+
+int kfsp_timers_enable(kfsp_ctx *ctx, int on)
+{
+    if (!ctx) return -1;
+    ctx->timers = on != 0;
+    return 0;
+}
+
+int kfsp_get_timers(kfsp_ctx *ctx, double *ms, int reset)
+{
+    if (!ctx) return -1;
+    if (!ms) return -2;
+    for (int i = 0; i < KFSP_T_COUNT; ++i) ms[i] = ctx->t_ms[i];
+    if (reset)
+        for (double &t : ctx->t_ms) t = 0.0;
+    return 0;
+}
+
+int kfsp_set_option(kfsp_ctx *ctx, const char *name, int64_t value)
+{
+    if (!ctx) return -1;
+    if (!name) return -2;
+    const std::string k(name);
+    if (k == "grid_blocks") ctx->opt_grid = value;
+    else if (k == "nt_loads") ctx->opt_nt = value;
+    else if (k == "build_csr") ctx->want_csr = value != 0;
+    else return fail(ctx, -2, "unknown option");
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,106 @@
+// Internal declarations shared by the host side (kfsp_api.cpp) and the gfx950
+// kernels (kfsp_kernels.hip) of libkfsp_hip.  Not part of the C ABI.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+namespace kfsp {
+
+constexpr int kBlock = 256;        // 4 wavefronts of 64
+constexpr int kWave = 64;
+constexpr int kChunk = 64;         // SELL chunk height = one wavefront
+constexpr int kMaxGrid = 2048;     // 256 CUs x 8 resident 256-thread blocks
+constexpr int kMMax = 100;         // KrylovSolver.f90:47
+constexpr int kMH = kMMax + 2;     // leading dimension of the device H image
+
+// Generator rows of this rank in SELL-64-1: chunk c holds rows [64c, 64c+64),
+// its entries live at off[c] + slot*64 + lane (lane = row within chunk), so a
+// wavefront reads 64 consecutive int32 / f64 per slot.  The diagonal is kept
+// apart (positive, as DIAG in StateSpace.f90:16) and padded slots carry
+// val = 0 with a valid column.
+struct SellDev {
+    int64_t nrows;       // local rows
+    int64_t nchunks;     // ceil(nrows / 64)
+    const int64_t *off;  // [nchunks + 1] entry offsets
+    const int32_t *col;  // global 0-based column
+    const double *val;
+    const double *diag;  // [nchunks * 64]
+};
+
+// Same rows in plain CSR (off-diagonal entries only), for the LDS-staged
+// CSR-stream kernel variant.
+struct CsrDev {
+    int64_t nrows;
+    const int64_t *rowptr;  // [nrows + 1]
+    const int32_t *col;
+    const double *val;
+    const double *diag;
+    const int32_t *tile_row;  // [ntiles + 1] first row of every nnz tile
+    int64_t ntiles;
+};
+
+// A scalar that is the sum of n doubles at p (block partials of the producing
+// kernel, or one finished / all-reduced value).  Consumers sum it themselves in
+// a fixed order: no atomics, no extra launch, bit-reproducible.
+struct Pending {
+    const double *p;
+    int n;
+};
+
+struct SpmvArgs {
+    SellDev A;
+    const double *xg;     // gather source, global indexing
+    int64_t row0;         // global index of local row 0
+    double *y;            // local rows
+    Pending sq;           // squared norm of the source column (modes 1,2)
+    double *sq_final;     // where block 0 stores the finished squared norm
+    double *h_sub;        // where block 0 stores sqrt of it (H(j,j-1)), may be null
+    const double *udot;   // mode 1: vector of the first dot product
+    double *partial;      // [gridDim.x] block partials of the fused reduction
+    double break_tol;     // <0: no breakdown test
+    int *brk_flag;
+};
+
+struct OrthoArgs {
+    int64_t npairs;       // padded local length / 2
+    double *w;            // column being orthogonalised (in/out)
+    const double *ui;     // basis vector subtracted (unnormalised)
+    Pending dot;          // sum = u_i . w
+    const double *sq_i;   // finished squared norm of u_i
+    const double *unext;  // next dot vector, or null -> accumulate w.w
+    double *partial;
+    double *h_out;        // H(i,j)
+    const int *brk_flag;
+};
+
+struct CombineArgs {
+    int64_t npairs;
+    int mx;
+    double beta;
+    const double *V;      // unnormalised basis, column stride ldv
+    int64_t ldv;
+    const double *sq;     // finished squared norms, sq[j] for column j (1-based)
+    const double *y;      // device copy of the coefficient vector
+    double *w;
+    double *partial;
+};
+
+// kernel launchers (kfsp_kernels.hip)
+void launch_spmv(int mode, int grid, const SpmvArgs &a, bool nontemporal, hipStream_t s);
+void launch_spmv_csr_stream(int grid, const CsrDev &A, const double *xg, int64_t row0, double *y, hipStream_t s);
+void launch_ortho(int grid, const OrthoArgs &a, hipStream_t s);
+void launch_combine(int grid, const CombineArgs &a, hipStream_t s);
+// u1 = w, partial = sum w^2
+void launch_copy_nrm2(int grid, int64_t npairs, const double *w, double *u1, double *partial, hipStream_t s);
+// partial = sum |w| or sum w^2
+void launch_reduce(int grid, int64_t npairs, const double *w, int squared, double *partial, hipStream_t s);
+// out[0] = sum(p) ; out_sqrt (may be null) = sqrt of it
+void launch_finalize(Pending p, double *out, double *out_sqrt, hipStream_t s);
+// w = scale * u
+void launch_scale_copy(int grid, int64_t npairs, const double *u, const double *sq_u, double beta, double *w, hipStream_t s);
+
+}  // namespace kfsp

@@ -1,0 +1,347 @@
+// gfx950 (MI355X, CDNA4) kernels of the exp(tA)v hot path.
+//
+// Everything here is bandwidth-bound f64 streaming (<= 0.17 flop/byte), so the
+// design rules are: every HBM byte read once and in full 64-lane-wide
+// contiguous pieces, the per-row scalar work fused into the pass that already
+// holds the row, reductions finished by wavefront shuffles + one LDS hop, and
+// no atomics (block partials in a fixed layout, summed by the consumer in a
+// fixed order -> bit-reproducible runs).  No MFMA: there is no contraction.
+//
+// Reference call sites covered (voduchuy/KrylovFspSsa, src/fsp/KrylovSolver.f90):
+//   k_spmv          FMATVEC :577-607 (as a row gather) fused with the first
+//                   DDOT :243, or with the DNRM2 of :263, and with the DSCAL
+//                   :258 of the source column (lazy normalisation)
+//   k_ortho         DAXPY :244 fused with the next DDOT :243 / DNRM2 :247
+//   k_combine       DGEMV :444 + clamp :447-449 + DASUM :450
+//   k_copy_nrm2     DCOPY :176 / v1 = w/beta :223-226 + DNRM2 :177,:540
+#include "kfsp_internal.h"
+
+namespace kfsp {
+
+// ---------------------------------------------------------------- reductions
+
+__device__ __forceinline__ double wave_allreduce_sum(double v)
+{
+    // xor butterfly over the 64 lanes: every lane ends with the same bits
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Sum over the block, result in every thread.  red: 4 doubles of LDS.
+__device__ __forceinline__ double block_allreduce_sum(double v, double *red)
+{
+    v = wave_allreduce_sum(v);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) red[wave] = v;
+    __syncthreads();
+    const double t = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+    return t;
+}
+
+// Finish a Pending scalar: every thread of every block performs the same
+// additions in the same order.
+__device__ __forceinline__ double finish_sum(Pending s, double *red)
+{
+    double a = 0.0;
+    for (int i = threadIdx.x; i < s.n; i += kBlock) a += s.p[i];
+    return block_allreduce_sum(a, red);
+}
+
+template <bool NT>
+__device__ __forceinline__ double ld_stream(const double *p)
+{
+    if (NT) return __builtin_nontemporal_load(p);
+    return *p;
+}
+template <bool NT>
+__device__ __forceinline__ int32_t ld_stream(const int32_t *p)
+{
+    if (NT) return __builtin_nontemporal_load(p);
+    return *p;
+}
+
+// ---------------------------------------------------------------------- SpMV
+//
+// One lane = one row, one wavefront = one SELL chunk, so slot k of a chunk is
+// one 256-B (col) + one 512-B (val) fully used, contiguous read per wave.
+// Work distribution is XCD-aware: workgroups b, b+8, b+16.. share an XCD (and
+// its 4 MiB L2), so XCD x sweeps the contiguous chunk range [x*CPX,(x+1)*CPX)
+// with its workgroups advancing as one front; the gathered x window of a front
+// (rows +- the generator's strides) then stays in that XCD's L2 instead of
+// being fetched by all eight.
+//
+// MODE 0: y = A x                      (FMATVEC seam, DROP_STATES, bench)
+// MODE 1: y = s A u ; partial = udot.y (Arnoldi column, s = 1/||u||)
+// MODE 2: y = s A u ; partial = y.y    (the AVNORM product)
+template <int MODE, bool NT>
+__global__ __launch_bounds__(kBlock) void k_spmv(SpmvArgs a)
+{
+    __shared__ double red[4];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    double s = 1.0;
+    if (MODE != 0) {
+        if (*a.brk_flag) return;
+        const double S = finish_sum(a.sq, red);
+        const double nrm = sqrt(S);
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            if (a.sq_final) *a.sq_final = S;
+            if (a.h_sub) *a.h_sub = nrm;
+        }
+        if (a.break_tol >= 0.0 && !(nrm > a.break_tol)) {   // happy breakdown :249
+            if (blockIdx.x == 0 && threadIdx.x == 0) *a.brk_flag = 1;
+            return;
+        }
+        s = 1.0 / nrm;
+    }
+
+    const int xcd = blockIdx.x & 7;
+    const int slot = blockIdx.x >> 3;
+    const int bx = gridDim.x >> 3;                        // workgroups per XCD
+    const int64_t cpx = (a.A.nchunks + 7) >> 3;
+    const int64_t cbeg = (int64_t)xcd * cpx;
+    const int64_t cend = (cbeg + cpx < a.A.nchunks) ? cbeg + cpx : a.A.nchunks;
+
+    double acc = 0.0;
+    for (int64_t c = cbeg + (int64_t)slot * 4 + wave; c < cend; c += (int64_t)bx * 4) {
+        const int64_t off = a.A.off[c];
+        const int w = (int)((a.A.off[c + 1] - off) >> 6);
+        const int64_t r = (c << 6) + lane;
+        const int32_t *cp = a.A.col + off + lane;
+        const double *vp = a.A.val + off + lane;
+        const double xr = a.xg[a.row0 + r];
+        double sum = -ld_stream<NT>(a.A.diag + r) * xr;
+        int k = 0;
+        for (; k + 4 <= w; k += 4) {
+            const int32_t c0 = ld_stream<NT>(cp + (k + 0) * 64), c1 = ld_stream<NT>(cp + (k + 1) * 64);
+            const int32_t c2 = ld_stream<NT>(cp + (k + 2) * 64), c3 = ld_stream<NT>(cp + (k + 3) * 64);
+            const double v0 = ld_stream<NT>(vp + (k + 0) * 64), v1 = ld_stream<NT>(vp + (k + 1) * 64);
+            const double v2 = ld_stream<NT>(vp + (k + 2) * 64), v3 = ld_stream<NT>(vp + (k + 3) * 64);
+            sum += v0 * a.xg[c0];
+            sum += v1 * a.xg[c1];
+            sum += v2 * a.xg[c2];
+            sum += v3 * a.xg[c3];
+        }
+        for (; k < w; ++k) sum += ld_stream<NT>(vp + k * 64) * a.xg[ld_stream<NT>(cp + k * 64)];
+        if (MODE != 0) sum *= s;
+        a.y[r] = sum;
+        if (MODE == 1) acc += a.udot[r] * sum;
+        if (MODE == 2) acc += sum * sum;
+    }
+    if (MODE != 0) {
+        const double t = block_allreduce_sum(acc, red);
+        if (threadIdx.x == 0) a.partial[blockIdx.x] = t;
+    }
+}
+
+void launch_spmv(int mode, int grid, const SpmvArgs &a, bool nt, hipStream_t st)
+{
+    dim3 g(grid), b(kBlock);
+    if (nt) {
+        if (mode == 0) hipLaunchKernelGGL((k_spmv<0, true>), g, b, 0, st, a);
+        else if (mode == 1) hipLaunchKernelGGL((k_spmv<1, true>), g, b, 0, st, a);
+        else hipLaunchKernelGGL((k_spmv<2, true>), g, b, 0, st, a);
+    } else {
+        if (mode == 0) hipLaunchKernelGGL((k_spmv<0, false>), g, b, 0, st, a);
+        else if (mode == 1) hipLaunchKernelGGL((k_spmv<1, false>), g, b, 0, st, a);
+        else hipLaunchKernelGGL((k_spmv<2, false>), g, b, 0, st, a);
+    }
+}
+
+// CSR-stream variant: a workgroup owns a run of whole rows holding <= kTile
+// off-diagonal entries, streams their (col,val) tile with full-width
+// contiguous reads, parks val*x[col] in LDS and lets one lane per row add its
+// few products.  No padding bytes at all; costs an 8-B row pointer per row.
+constexpr int kTile = 2048;
+__global__ __launch_bounds__(kBlock) void k_spmv_csr_stream(CsrDev A, const double *__restrict__ xg,
+                                                            int64_t row0, double *__restrict__ y)
+{
+    __shared__ double prod[kTile];
+    for (int64_t t = blockIdx.x; t < A.ntiles; t += gridDim.x) {
+        const int rbeg = A.tile_row[t], rend = A.tile_row[t + 1];
+        const int64_t pbeg = A.rowptr[rbeg], pend = A.rowptr[rend];
+        const int cnt = (int)(pend - pbeg);
+        for (int i = threadIdx.x; i < cnt; i += kBlock)
+            prod[i] = A.val[pbeg + i] * xg[A.col[pbeg + i]];
+        __syncthreads();
+        const int r = rbeg + threadIdx.x;
+        if (r < rend) {
+            const int lo = (int)(A.rowptr[r] - pbeg), hi = (int)(A.rowptr[r + 1] - pbeg);
+            double sum = -A.diag[r] * xg[row0 + r];
+            for (int i = lo; i < hi; ++i) sum += prod[i];
+            y[r] = sum;
+        }
+        __syncthreads();
+    }
+}
+
+void launch_spmv_csr_stream(int grid, const CsrDev &A, const double *xg, int64_t row0, double *y, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_spmv_csr_stream, dim3(grid), dim3(kBlock), 0, st, A, xg, row0, y);
+}
+
+// --------------------------------------------------- orthogonalisation step
+// h = (u_i . w) s_i ;  w -= h s_i u_i ;  partial = unext . w  (or w . w)
+__global__ __launch_bounds__(kBlock) void k_ortho(OrthoArgs a)
+{
+    __shared__ double red[4];
+    if (*a.brk_flag) return;
+    const double si = 1.0 / sqrt(*a.sq_i);
+    const double h = finish_sum(a.dot, red) * si;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *a.h_out = h;
+    const double coef = h * si;
+    double2 *w2 = reinterpret_cast<double2 *>(a.w);
+    const double2 *u2 = reinterpret_cast<const double2 *>(a.ui);
+    const double2 *n2 = reinterpret_cast<const double2 *>(a.unext);
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.npairs; i += (int64_t)gridDim.x * kBlock) {
+        double2 w = w2[i];
+        const double2 u = u2[i];
+        w.x -= coef * u.x;
+        w.y -= coef * u.y;
+        w2[i] = w;
+        if (n2) {
+            const double2 v = n2[i];
+            acc += v.x * w.x;
+            acc += v.y * w.y;
+        } else {
+            acc += w.x * w.x;
+            acc += w.y * w.y;
+        }
+    }
+    const double t = block_allreduce_sum(acc, red);
+    if (threadIdx.x == 0) a.partial[blockIdx.x] = t;
+}
+
+void launch_ortho(int grid, const OrthoArgs &a, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_ortho, dim3(grid), dim3(kBlock), 0, st, a);
+}
+
+// ------------------------------------------------------------------ combine
+// w = beta * sum_j y_j s_j u_j ; clamp ; partial = sum |w|
+__global__ __launch_bounds__(kBlock) void k_combine(CombineArgs a)
+{
+    __shared__ double red[4];
+    __shared__ double coef[kMH];
+    for (int j = threadIdx.x; j < a.mx; j += kBlock)
+        coef[j] = a.beta * a.y[j] / sqrt(a.sq[j + 1]);
+    __syncthreads();
+    double2 *w2 = reinterpret_cast<double2 *>(a.w);
+    const int64_t ld2 = a.ldv >> 1;
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.npairs; i += (int64_t)gridDim.x * kBlock) {
+        const double2 *v = reinterpret_cast<const double2 *>(a.V) + i;
+        double sx = 0.0, sy = 0.0;
+        int j = 0;
+        for (; j + 4 <= a.mx; j += 4) {
+            const double2 v0 = v[(int64_t)(j + 0) * ld2], v1 = v[(int64_t)(j + 1) * ld2];
+            const double2 v2 = v[(int64_t)(j + 2) * ld2], v3 = v[(int64_t)(j + 3) * ld2];
+            sx += coef[j] * v0.x; sy += coef[j] * v0.y;
+            sx += coef[j + 1] * v1.x; sy += coef[j + 1] * v1.y;
+            sx += coef[j + 2] * v2.x; sy += coef[j + 2] * v2.y;
+            sx += coef[j + 3] * v3.x; sy += coef[j + 3] * v3.y;
+        }
+        for (; j < a.mx; ++j) {
+            const double2 vj = v[(int64_t)j * ld2];
+            sx += coef[j] * vj.x; sy += coef[j] * vj.y;
+        }
+        sx = sx < 0.0 ? 0.0 : sx;       // FSP non-negativity :447-449 (NaN stays NaN)
+        sy = sy < 0.0 ? 0.0 : sy;
+        w2[i] = make_double2(sx, sy);
+        acc += fabs(sx);
+        acc += fabs(sy);
+    }
+    const double t = block_allreduce_sum(acc, red);
+    if (threadIdx.x == 0) a.partial[blockIdx.x] = t;
+}
+
+void launch_combine(int grid, const CombineArgs &a, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_combine, dim3(grid), dim3(kBlock), 0, st, a);
+}
+
+// --------------------------------------------------------- small streaming ops
+__global__ __launch_bounds__(kBlock) void k_copy_nrm2(int64_t npairs, const double2 *__restrict__ w,
+                                                      double2 *__restrict__ u, double *__restrict__ partial)
+{
+    __shared__ double red[4];
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < npairs; i += (int64_t)gridDim.x * kBlock) {
+        const double2 v = w[i];
+        u[i] = v;
+        acc += v.x * v.x;
+        acc += v.y * v.y;
+    }
+    const double t = block_allreduce_sum(acc, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+void launch_copy_nrm2(int grid, int64_t npairs, const double *w, double *u1, double *partial, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_copy_nrm2, dim3(grid), dim3(kBlock), 0, st, npairs,
+                       reinterpret_cast<const double2 *>(w), reinterpret_cast<double2 *>(u1), partial);
+}
+
+__global__ __launch_bounds__(kBlock) void k_reduce(int64_t npairs, const double2 *__restrict__ w, int squared,
+                                                   double *__restrict__ partial)
+{
+    __shared__ double red[4];
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < npairs; i += (int64_t)gridDim.x * kBlock) {
+        const double2 v = w[i];
+        if (squared) {
+            acc += v.x * v.x;
+            acc += v.y * v.y;
+        } else {
+            acc += fabs(v.x);
+            acc += fabs(v.y);
+        }
+    }
+    const double t = block_allreduce_sum(acc, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+void launch_reduce(int grid, int64_t npairs, const double *w, int squared, double *partial, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_reduce, dim3(grid), dim3(kBlock), 0, st, npairs, reinterpret_cast<const double2 *>(w),
+                       squared, partial);
+}
+
+__global__ __launch_bounds__(kBlock) void k_finalize(Pending p, double *out, double *out_sqrt)
+{
+    __shared__ double red[4];
+    const double t = finish_sum(p, red);
+    if (threadIdx.x == 0) {
+        if (out) *out = t;
+        if (out_sqrt) *out_sqrt = sqrt(t);
+    }
+}
+
+void launch_finalize(Pending p, double *out, double *out_sqrt, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kBlock), 0, st, p, out, out_sqrt);
+}
+
+__global__ __launch_bounds__(kBlock) void k_scale_copy(int64_t npairs, const double2 *__restrict__ u,
+                                                       const double *__restrict__ sq_u, double beta,
+                                                       double2 *__restrict__ w)
+{
+    const double c = beta / sqrt(*sq_u);
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < npairs; i += (int64_t)gridDim.x * kBlock) {
+        const double2 v = u[i];
+        w[i] = make_double2(c * v.x, c * v.y);
+    }
+}
+
+void launch_scale_copy(int grid, int64_t npairs, const double *u, const double *sq_u, double beta, double *w,
+                       hipStream_t st)
+{
+    hipLaunchKernelGGL(k_scale_copy, dim3(grid), dim3(kBlock), 0, st, npairs,
+                       reinterpret_cast<const double2 *>(u), sq_u, beta, reinterpret_cast<double2 *>(w));
+}
+
+}  // namespace kfsp

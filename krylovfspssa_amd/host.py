@@ -1,0 +1,264 @@
+"""ctypes mirror of the C ABI in include/kfsp.h (libkfsp_hip.so).
+
+This is plumbing for tests, bench.py and Python drivers: numpy arrays in the
+reference's own layouts go in, numpy arrays come out; all arithmetic of the hot
+path happens in the HIP library.  There is no CPU fallback: importing works
+anywhere (so the symbol table can be checked without a GPU), but creating a
+context without a usable MI355X raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+M_MAX = 100
+T_NAMES = ("spmv", "ortho", "combine", "comm", "host_pade", "upload")
+
+_lib = None
+
+
+class KfspError(RuntimeError):
+    pass
+
+
+def library_path():
+    return _build.LIB
+
+
+def load_library():
+    """Load libkfsp_hip.so; fails loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise KfspError(f"{path} is missing: run `python -m krylovfspssa_amd.build` "
+                        "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = C.CDLL(path)
+    vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+    sig = {
+        "kfsp_create": [C.c_int, C.POINTER(vp)],
+        "kfsp_destroy": [vp],
+        "kfsp_abi_version": [],
+        "kfsp_comm_unique_id": [vp],
+        "kfsp_comm_init": [vp, C.c_int, C.c_int, vp],
+        "kfsp_row_block": [vp, i64, C.POINTER(i64), C.POINTER(i64)],
+        "kfsp_set_matrix_ell": [vp, i32, i32, i32, vp, vp, vp],
+        "kfsp_set_matrix_csr": [vp, i64, i64, i64, vp, vp, vp],
+        "kfsp_matrix_info": [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)],
+        "kfsp_set_vector": [vp, i64, vp],
+        "kfsp_get_vector": [vp, i64, vp],
+        "kfsp_begin_step": [vp, C.POINTER(dbl)],
+        "kfsp_arnoldi": [vp, C.c_int, C.c_int, C.c_int, dbl, vp, C.c_int, C.POINTER(C.c_int),
+                         C.POINTER(C.c_int), C.POINTER(dbl)],
+        "kfsp_combine": [vp, C.c_int, dbl, vp, C.POINTER(dbl)],
+        "kfsp_restore_w": [vp, dbl],
+        "kfsp_spmv": [vp, vp, vp],
+        "kfsp_spmv_w": [vp, vp],
+        "kfsp_nrm2_w": [vp, C.POINTER(dbl)],
+        "kfsp_asum_w": [vp, C.POINTER(dbl)],
+        "kfsp_get_basis": [vp, C.c_int, i64, vp],
+        "kfsp_padm": [C.c_int, C.c_int, dbl, vp, C.c_int, vp, C.POINTER(C.c_int), C.POINTER(dbl)],
+        "kfsp_expv_fixed": [vp, C.c_int, dbl, C.c_int, vp],
+        "kfsp_spmv_bench": [vp, C.c_int, C.c_int, C.POINTER(C.c_float)],
+        "kfsp_timers_enable": [vp, C.c_int],
+        "kfsp_get_timers": [vp, vp, C.c_int],
+        "kfsp_set_option": [vp, C.c_char_p, i64],
+    }
+    for name, args in sig.items():
+        f = getattr(lib, name)
+        f.argtypes = args
+        f.restype = C.c_int
+    lib.kfsp_last_error.argtypes = [vp]
+    lib.kfsp_last_error.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def padm(H, t, ideg=6):
+    """Host Pade exponential of the library (dgpadm.f:2-169 semantics)."""
+    lib = load_library()
+    Hf = np.asfortranarray(H, dtype=np.float64)
+    m = Hf.shape[0]
+    E = np.empty((m, m), dtype=np.float64, order="F")
+    ns, hn = C.c_int(0), C.c_double(0.0)
+    rc = lib.kfsp_padm(ideg, m, float(t), _p(Hf), m, _p(E), C.byref(ns), C.byref(hn))
+    if rc:
+        raise KfspError(f"kfsp_padm -> {rc}")
+    return E, ns.value, hn.value
+
+
+class KfspContext:
+    """One device context = one rank's share of the solver workspace."""
+
+    def __init__(self, device=0):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        rc = self._lib.kfsp_create(int(device), C.byref(self._h))
+        if rc:
+            self._h = C.c_void_p()
+            raise KfspError(f"kfsp_create(device={device}) -> {rc}: no usable HIP device; "
+                            "the exp(tA)v hot path has no CPU fallback")
+        self.n = 0
+        self.nranks, self.rank = 1, 0
+
+    # -- lifetime
+    def close(self):
+        if self._h:
+            self._lib.kfsp_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc:
+            msg = self._lib.kfsp_last_error(self._h)
+            raise KfspError(f"{what} -> {rc}: {msg.decode() if msg else ''}")
+
+    # -- partition
+    @staticmethod
+    def unique_id():
+        buf = np.zeros(128, dtype=np.uint8)
+        rc = load_library().kfsp_comm_unique_id(_p(buf))
+        if rc:
+            raise KfspError(f"kfsp_comm_unique_id -> {rc}")
+        return buf
+
+    def comm_init(self, nranks, rank, id_bytes=None):
+        buf = None if id_bytes is None else np.ascontiguousarray(id_bytes, dtype=np.uint8)
+        self._chk(self._lib.kfsp_comm_init(self._h, nranks, rank, None if buf is None else _p(buf)), "kfsp_comm_init")
+        self.nranks, self.rank = nranks, rank
+
+    def row_block(self, n):
+        r0, nr = C.c_int64(0), C.c_int64(0)
+        self._chk(self._lib.kfsp_row_block(self._h, int(n), C.byref(r0), C.byref(nr)), "kfsp_row_block")
+        return r0.value, nr.value
+
+    # -- generator
+    def set_matrix_ell(self, adj, offdiag, diag):
+        """FSP_MATRIX arrays as [state][slot] numpy arrays (= Fortran (slot,state))."""
+        adj = np.ascontiguousarray(adj, dtype=np.int32)
+        offdiag = np.ascontiguousarray(offdiag, dtype=np.float64)
+        diag = np.ascontiguousarray(diag, dtype=np.float64)
+        n, bw = adj.shape
+        assert offdiag.shape == (n, bw) and diag.shape == (n,)
+        self._chk(self._lib.kfsp_set_matrix_ell(self._h, n, bw, bw, _p(adj), _p(offdiag), _p(diag)),
+                  "kfsp_set_matrix_ell")
+        self.n = n
+        self.row0, self.nloc = self.row_block(n)
+
+    def set_matrix_csr(self, n, rowptr, col, val, row0=None):
+        rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
+        col = np.ascontiguousarray(col, dtype=np.int32)
+        val = np.ascontiguousarray(val, dtype=np.float64)
+        r0, nr = self.row_block(n)
+        if row0 is None:
+            row0 = r0
+        assert len(rowptr) == nr + 1, (len(rowptr), nr)
+        self._chk(self._lib.kfsp_set_matrix_csr(self._h, int(n), int(row0), int(nr), _p(rowptr), _p(col), _p(val)),
+                  "kfsp_set_matrix_csr")
+        self.n = int(n)
+        self.row0, self.nloc = r0, nr
+
+    def matrix_info(self):
+        a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        self._chk(self._lib.kfsp_matrix_info(self._h, C.byref(a), C.byref(b), C.byref(c)), "kfsp_matrix_info")
+        return dict(rows=a.value, slots=b.value, nnz=c.value)
+
+    # -- vectors
+    def set_vector(self, w):
+        w = np.ascontiguousarray(w, dtype=np.float64)
+        self._chk(self._lib.kfsp_set_vector(self._h, len(w), _p(w)), "kfsp_set_vector")
+
+    def get_vector(self):
+        w = np.empty(self.nloc, dtype=np.float64)
+        self._chk(self._lib.kfsp_get_vector(self._h, self.nloc, _p(w)), "kfsp_get_vector")
+        return w
+
+    def get_basis(self, j):
+        v = np.empty(self.nloc, dtype=np.float64)
+        self._chk(self._lib.kfsp_get_basis(self._h, int(j), self.nloc, _p(v)), "kfsp_get_basis")
+        return v
+
+    # -- hot path
+    def begin_step(self):
+        b = C.c_double(0.0)
+        self._chk(self._lib.kfsp_begin_step(self._h, C.byref(b)), "kfsp_begin_step")
+        return b.value
+
+    def arnoldi(self, m, jold=1, qiop=2, break_tol=1e-7, H=None):
+        """-> (H[(m+2),(m+2)] F-order, mbrkdwn, k1, avnorm)."""
+        mh = m + 2
+        if H is None:
+            H = np.zeros((mh, mh), dtype=np.float64, order="F")
+        assert H.flags.f_contiguous and H.shape[0] >= mh
+        mb, k1, av = C.c_int(0), C.c_int(0), C.c_double(0.0)
+        self._chk(self._lib.kfsp_arnoldi(self._h, m, jold, qiop, float(break_tol), _p(H), H.shape[0],
+                                         C.byref(mb), C.byref(k1), C.byref(av)), "kfsp_arnoldi")
+        return H, mb.value, k1.value, av.value
+
+    def combine(self, mx, beta, y):
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        assert len(y) >= mx
+        ws = C.c_double(0.0)
+        self._chk(self._lib.kfsp_combine(self._h, int(mx), float(beta), _p(y), C.byref(ws)), "kfsp_combine")
+        return ws.value
+
+    def restore_w(self, beta):
+        self._chk(self._lib.kfsp_restore_w(self._h, float(beta)), "kfsp_restore_w")
+
+    def spmv(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        assert len(x) == self.n
+        y = np.empty(self.nloc, dtype=np.float64)
+        self._chk(self._lib.kfsp_spmv(self._h, _p(x), _p(y)), "kfsp_spmv")
+        return y
+
+    def spmv_w(self):
+        y = np.empty(self.nloc, dtype=np.float64)
+        self._chk(self._lib.kfsp_spmv_w(self._h, _p(y)), "kfsp_spmv_w")
+        return y
+
+    def nrm2_w(self):
+        o = C.c_double(0.0)
+        self._chk(self._lib.kfsp_nrm2_w(self._h, C.byref(o)), "kfsp_nrm2_w")
+        return o.value
+
+    def asum_w(self):
+        o = C.c_double(0.0)
+        self._chk(self._lib.kfsp_asum_w(self._h, C.byref(o)), "kfsp_asum_w")
+        return o.value
+
+    def expv_fixed(self, m, tau, nsteps):
+        ws = np.zeros(max(nsteps, 1), dtype=np.float64)
+        self._chk(self._lib.kfsp_expv_fixed(self._h, int(m), float(tau), int(nsteps), _p(ws)), "kfsp_expv_fixed")
+        return ws[:nsteps]
+
+    def spmv_bench(self, reps, variant=0):
+        ms = C.c_float(0.0)
+        self._chk(self._lib.kfsp_spmv_bench(self._h, int(reps), int(variant), C.byref(ms)), "kfsp_spmv_bench")
+        return ms.value
+
+    def timers(self, reset=False):
+        t = np.zeros(len(T_NAMES))
+        self._chk(self._lib.kfsp_get_timers(self._h, _p(t), int(reset)), "kfsp_get_timers")
+        return dict(zip(T_NAMES, t.tolist()))
+
+    def set_option(self, name, value):
+        self._chk(self._lib.kfsp_set_option(self._h, name.encode(), int(value)), "kfsp_set_option")

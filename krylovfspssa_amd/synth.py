@@ -1,0 +1,208 @@
+"""Synthetic CME generators on hyper-rectangular state sets.
+
+Input construction for benchmarks and parity tests (numpy, host side, not part
+of the timed path).  States are the lattice points of a box
+[0,n_1) x ... x [0,n_d) in lexicographic order with species 1 fastest, i.e.
+state index i = sum_k x_k * stride_k, stride_1 = 1.
+
+Two output forms:
+  * `ell(...)`      the reference's own FSP_MATRIX layout (StateSpace.f90:13-17):
+                    ADJ/OFFDIAG [state][slot] (1-based, 0 = successor outside
+                    the box, -1 = negative population), DIAG = sum of ALL
+                    propensities (StateSpace.f90:207-212) -> kfsp_set_matrix_ell
+  * `csr_rows(...)` gather rows of a row block with global columns and the
+                    diagonal stored in place -> kfsp_set_matrix_csr (what each
+                    rank of a row partition builds for itself)
+
+The propensity formulas restate the reference's model files (data):
+models/toggle_model.input:29-32, models/repressilator_model.input:32-37,
+models/goutsias_model.input:43-52; parameter values are the ones its drivers
+use (test/TestSolverFromFile.f90:31, examples/transcr6d.f90:23-32).
+"""
+import numpy as np
+
+
+class BoxModel:
+    """stoich: (d, R) integer array; prop(r, X) -> propensity of reaction r at the
+    coordinate arrays X[0..d-1] (float64 arrays of equal shape)."""
+
+    def __init__(self, name, dims, stoich, prop):
+        self.name = name
+        self.dims = tuple(int(x) for x in dims)
+        self.stoich = np.asarray(stoich, dtype=np.int64)
+        self.prop = prop
+        self.d, self.R = self.stoich.shape
+        assert self.d == len(self.dims)
+        self.strides = np.concatenate(([1], np.cumprod(self.dims[:-1]))).astype(np.int64)
+        self.n = int(np.prod(self.dims))
+        self.offsets = (self.stoich * self.strides[:, None]).sum(axis=0)   # index shift of each reaction
+
+    def coords(self, idx):
+        return [(idx // self.strides[k]) % self.dims[k] for k in range(self.d)]
+
+    # ---- reference layout -------------------------------------------------
+    def ell(self):
+        idx = np.arange(self.n, dtype=np.int64)
+        X = self.coords(idx)
+        Xf = [x.astype(np.float64) for x in X]
+        adj = np.empty((self.n, self.R), dtype=np.int32)
+        off = np.empty((self.n, self.R), dtype=np.float64)
+        diag = np.zeros(self.n, dtype=np.float64)
+        for r in range(self.R):
+            neg = np.zeros(self.n, dtype=bool)
+            out = np.zeros(self.n, dtype=bool)
+            for k in range(self.d):
+                s = self.stoich[k, r]
+                if s:
+                    y = X[k] + s
+                    neg |= y < 0
+                    out |= y >= self.dims[k]
+            a = np.where(out, 0, idx + self.offsets[r] + 1)
+            adj[:, r] = np.where(neg, -1, a)
+            off[:, r] = self.prop(r, Xf)
+            diag += off[:, r]            # sequential over reactions, as StateSpace.f90:207-212
+        return adj, off, diag
+
+    # ---- gather rows of a block --------------------------------------------
+    def csr_rows(self, row0=0, nrows=None):
+        if nrows is None:
+            nrows = self.n - row0
+        rows = np.arange(row0, row0 + nrows, dtype=np.int64)
+        X = self.coords(rows)
+        Xf = [x.astype(np.float64) for x in X]
+        big = np.iinfo(np.int64).max
+        cols = np.full((nrows, self.R + 1), big, dtype=np.int64)
+        vals = np.zeros((nrows, self.R + 1), dtype=np.float64)
+        dsum = np.zeros(nrows, dtype=np.float64)
+        for r in range(self.R):
+            ok = np.ones(nrows, dtype=bool)
+            P = []
+            for k in range(self.d):
+                s = self.stoich[k, r]
+                y = X[k] - s if s else X[k]
+                if s:
+                    ok &= (y >= 0) & (y < self.dims[k])
+                P.append(y.astype(np.float64))
+            a = self.prop(r, P)                       # propensity at the predecessor
+            cols[:, r] = np.where(ok, rows - self.offsets[r], big)
+            vals[:, r] = np.where(ok, a, 0.0)
+            dsum += self.prop(r, Xf)                  # every reaction leaves the state
+        cols[:, self.R] = rows
+        vals[:, self.R] = -dsum
+        order = np.argsort(cols, axis=1, kind="stable")
+        cols = np.take_along_axis(cols, order, axis=1)
+        vals = np.take_along_axis(vals, order, axis=1)
+        valid = cols != big
+        rowptr = np.concatenate(([0], np.cumsum(valid.sum(axis=1)))).astype(np.int64)
+        return rowptr, cols[valid].astype(np.int32), vals[valid]
+
+    def nnz(self):
+        """true nonzeros incl. the diagonal"""
+        nnz = self.n
+        for r in range(self.R):
+            c = 1
+            for k in range(self.d):
+                c *= max(self.dims[k] - abs(int(self.stoich[k, r])), 0)
+            nnz += c
+        return nnz
+
+
+def _outer_fastest_first(vectors):
+    p = vectors[0]
+    for v in vectors[1:]:
+        p = (v[:, None] * p[None, :]).reshape(-1)
+    return p
+
+
+def poisson_p0(model, lam=30.0):
+    vs = []
+    for k in range(model.d):
+        x = np.arange(model.dims[k], dtype=np.float64)
+        lg = np.concatenate(([0.0], np.cumsum(np.log(np.arange(1, model.dims[k], dtype=np.float64)))))
+        vs.append(np.exp(x * np.log(lam) - lam - lg))
+    p = _outer_fastest_first(vs)
+    return p / p.sum()
+
+
+def toggle(n1=1000, n2=1000, params=(1.0, 100.0, 1.0, 1.0, 100.0, 1.0)):
+    bx, kx, dx, by, ky, dy = params
+    st = [[1, -1, 0, 0], [0, 0, 1, -1]]
+
+    def prop(r, X):
+        x, y = X
+        if r == 0:
+            return bx + kx / (2.0 + 0.2 * y ** 2)
+        if r == 1:
+            return dx * x
+        if r == 2:
+            return by + ky / (1.0 + 0.5 * x ** 1.5)
+        return dy * y
+    return BoxModel("toggle", (n1, n2), st, prop)
+
+
+def repressilator(n=171, params=(100.0, 100.0, 100.0, 1.0, 1.0, 1.0), dims=None):
+    a1, a2, a3, b1, b2, b3 = params
+    st = [[1, 0, 0, -1, 0, 0], [0, 1, 0, 0, -1, 0], [0, 0, 1, 0, 0, -1]]
+
+    def prop(r, X):
+        s1, s2, s3 = X
+        if r == 0:
+            return a1 / (1.0 + s3 ** 2.5)
+        if r == 1:
+            return a2 / (1.0 + s1 ** 1.5)
+        if r == 2:
+            return a3 / (1.0 + s2 ** 1.5)
+        return (b1 * s1, b2 * s2, b3 * s3)[r - 3]
+    return BoxModel("repressilator", dims if dims is not None else (n, n, n), st, prop)
+
+
+def birth_death(dims, k=None, g=None):
+    """d-species network of 2d reactions +-e_i with propensities k_i and g_i*x_i
+    (SURVEY.md 8(d), config C5)."""
+    d = len(dims)
+    k = np.linspace(5.0, 9.0, d) if k is None else np.asarray(k, dtype=np.float64)
+    g = np.linspace(0.6, 1.4, d) if g is None else np.asarray(g, dtype=np.float64)
+    st = np.zeros((d, 2 * d), dtype=np.int64)
+    for i in range(d):
+        st[i, 2 * i] = 1
+        st[i, 2 * i + 1] = -1
+
+    def prop(r, X):
+        i = r // 2
+        return np.full_like(X[i], k[i]) if r % 2 == 0 else g[i] * X[i]
+    return BoxModel("birth_death", dims, st, prop)
+
+
+GOUTSIAS_PARAMS = (0.043, 0.0007, 0.0715, 0.0039, 0.0199264663575241, 0.4791,
+                   0.000199264663575241, 0.8765e-11, 0.0830269431563506104, 0.5)
+
+
+def goutsias_box(dims, params=GOUTSIAS_PARAMS):
+    """Goutsias transcription model (species M, D, RNA, DNA, DNA.D, DNA.2D) on a
+    plain box; used at small sizes for parity tests."""
+    c = params
+    st = np.zeros((6, 10), dtype=np.int64)
+    M, D, RNA, DNA, DNAD, DNA2D = range(6)
+    st[M, 0] = 1
+    st[M, 1] = -1
+    st[RNA, 2] = 1
+    st[RNA, 3] = -1
+    st[DNA, 4] = -1; st[D, 4] = -1; st[DNAD, 4] = 1
+    st[DNA, 5] = 1; st[D, 5] = 1; st[DNAD, 5] = -1
+    st[DNAD, 6] = -1; st[D, 6] = -1; st[DNA2D, 6] = 1
+    st[DNAD, 7] = 1; st[D, 7] = 1; st[DNA2D, 7] = -1
+    st[M, 8] = -2; st[D, 8] = 1
+    st[M, 9] = 2; st[D, 9] = -1
+
+    def prop(r, X):
+        m, d_, rna, dna, dnad, dna2d = X
+        return (c[0] * rna, c[1] * m, c[2] * dnad, c[3] * rna, c[4] * dna * d_, c[5] * dnad,
+                c[6] * dnad * d_, c[7] * dna2d, c[8] * m * (m - 1) / 2.0, c[9] * d_)[r]
+    return BoxModel("goutsias", dims, st, prop)
+
+
+def spmv_alg_bytes(nnz, n):
+    """Algorithmic bytes of one generator SpMV: CSR with f64
+    values + int32 columns (12 B per nonzero incl. the diagonal) and per row a
+    4-B row pointer, x read once, y written once (20 B)."""
+    return 12 * int(nnz) + 20 * int(n)

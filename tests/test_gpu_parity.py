@@ -1,0 +1,242 @@
+"""Parity of the HIP hot path (through the C ABI, krylovfspssa_amd/host.py) with
+the CPU oracle and the reference's golden fixtures.  Needs a real MI355X."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from krylovfspssa_amd import KfspContext
+    c = KfspContext(0)
+    yield c
+    c.close()
+
+
+def _golden(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def _abs_gen(oracle, adj, off, diag, x):
+    """|A| |x| row-wise: the scale rounding errors of one product live on"""
+    A = oracle.EllMatrix(adj, np.abs(off), -np.abs(diag))
+    return oracle.spmv_ell(A, np.abs(x))
+
+
+SPMV_FIXTURES = ["assembly_toggle_k5.npz", "assembly_toggle_k20.npz", "assembly_repressilator_k10.npz",
+                 "assembly_goutsias_k10.npz", "assembly_goutsias_k16.npz", "solve_toggle_input.npz",
+                 "solve_toggle_example.npz", "solve_ring6.npz"]
+
+
+@pytest.mark.parametrize("fixture", SPMV_FIXTURES)
+def test_spmv_on_reference_matrices(ctx, oracle, golden_dir, fixture):
+    """kfsp_spmv (FMATVEC seam, KrylovSolver.f90:577-607) on matrices assembled by
+    the reference itself.  Tolerance: 1e-13 of |A||x| per entry (different
+    summation order than the scatter loop, fused multiply-add on the GPU)."""
+    g = _golden(golden_dir, fixture)
+    adj, off, diag = g["adj"], g["offdiag"], g["diag"]
+    A = oracle.EllMatrix(adj, off, diag)
+    ctx.set_matrix_ell(adj, off, diag)
+    info = ctx.matrix_info()
+    assert info["rows"] == A.n and info["nnz"] == A.nnz()
+    rng = np.random.default_rng(12345)
+    for x in (np.eye(1, A.n, 0).ravel(), np.ones(A.n), rng.random(A.n)):
+        y = ctx.spmv(x)
+        ref = oracle.spmv_ell(A, x)
+        scale = _abs_gen(oracle, adj, off, diag, x)
+        assert np.all(np.abs(y - ref) <= 1e-13 * scale + 1e-300)
+
+
+def test_spmv_synthetic_boxes_ell_and_csr_agree(ctx, oracle):
+    from krylovfspssa_amd import synth
+    rng = np.random.default_rng(7)
+    for mdl in (synth.toggle(130, 77), synth.repressilator(dims=(23, 19, 17)),
+                synth.goutsias_box((7, 6, 5, 3, 3, 3)), synth.birth_death((9, 8, 7, 6))):
+        adj, off, diag = mdl.ell()
+        A = oracle.EllMatrix(adj, off, diag)
+        x = rng.random(mdl.n)
+        ref = oracle.spmv_ell(A, x)
+        scale = _abs_gen(oracle, adj, off, diag, x)
+        ctx.set_matrix_ell(adj, off, diag)
+        y1 = ctx.spmv(x)
+        ctx.set_matrix_csr(mdl.n, *mdl.csr_rows())
+        y2 = ctx.spmv(x)
+        assert np.all(np.abs(y1 - ref) <= 1e-13 * scale)
+        assert np.array_equal(y1, y2)       # same device layout either way
+        assert ctx.matrix_info()["nnz"] == mdl.nnz()
+
+
+def test_spmv_is_deterministic_and_handles_ragged_sizes(ctx, oracle):
+    from krylovfspssa_amd import synth
+    rng = np.random.default_rng(3)
+    for dims in ((1, 2), (5, 1), (63, 1), (64, 1), (65, 3), (257, 5)):
+        mdl = synth.toggle(*dims)
+        adj, off, diag = mdl.ell()
+        ctx.set_matrix_ell(adj, off, diag)
+        x = rng.random(mdl.n)
+        y = ctx.spmv(x)
+        assert np.array_equal(y, ctx.spmv(x))
+        ref = oracle.spmv_ell(oracle.EllMatrix(adj, off, diag), x)
+        assert np.abs(y - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+
+
+def _setup(ctx, oracle, adj, off, diag, w):
+    ctx.set_matrix_ell(adj, off, diag)
+    ctx.set_vector(w)
+    return oracle.EllMatrix(adj, off, diag)
+
+
+def test_begin_step_norms_and_restore(ctx, oracle, golden_dir):
+    g = _golden(golden_dir, "solve_toggle_input.npz")
+    w = g["vector"]
+    _setup(ctx, oracle, g["adj"], g["offdiag"], g["diag"], w)
+    beta = ctx.begin_step()
+    assert beta == pytest.approx(np.sqrt((w * w).sum()), rel=1e-14)
+    assert ctx.nrm2_w() == pytest.approx(beta, rel=1e-14)
+    assert ctx.asum_w() == pytest.approx(np.abs(w).sum(), rel=1e-14)
+    v1 = ctx.get_basis(1)
+    assert np.abs(v1 - w / beta).max() < 1e-15
+    ctx.restore_w(beta)                                  # KrylovSolver.f90:467
+    assert np.abs(ctx.get_vector() - w).max() <= 1e-16
+    assert np.abs(ctx.spmv_w() - oracle.spmv_ell(oracle.EllMatrix(g["adj"], g["offdiag"], g["diag"]), w)).max() < 1e-13
+
+
+@pytest.mark.parametrize("fixture,m", [("solve_toggle_input.npz", 30), ("solve_ring6.npz", 29),
+                                       ("assembly_goutsias_k16.npz", 60), ("assembly_toggle_k5.npz", 10)])
+def test_arnoldi_matches_oracle(ctx, oracle, golden_dir, fixture, m):
+    """IOP Arnoldi (KrylovSolver.f90:236-266): Hessenberg entries, basis, AVNORM."""
+    g = _golden(golden_dir, fixture)
+    n = int(g["n"])
+    rng = np.random.default_rng(11)
+    w = g["vector"] if "vector" in g.files and g["vector"].sum() > 0.5 else rng.random(n)
+    A = _setup(ctx, oracle, g["adj"], g["offdiag"], g["diag"], w)
+    beta = ctx.begin_step()
+    H, mb, k1, av = ctx.arnoldi(m)
+    V, Href, mbr, k1r, avr = oracle.arnoldi(A, w / np.sqrt((w * w).sum()), m)
+    assert (mb, k1) == (mbr, k1r) == (m, 2)
+    hs = np.abs(Href).max()
+    assert np.abs(H - Href).max() <= 1e-11 * hs
+    assert av == pytest.approx(avr, rel=1e-10)
+    assert H[m + 1, m] == 1.0
+    for j in (1, 2, m // 2, m + 1):
+        assert np.abs(ctx.get_basis(j) - V[:, j - 1]).max() <= 1e-10
+    assert beta == pytest.approx(np.sqrt((w * w).sum()), rel=1e-14)
+
+
+def test_arnoldi_restart_extends_basis_like_reference(ctx, oracle, golden_dir):
+    """Dimension change (KrylovSolver.f90:400-432): a second call with jold = m_old
+    recomputes column m_old and continues; shrinking takes the AVNORM product
+    from column jold."""
+    g = _golden(golden_dir, "solve_ring6.npz")
+    w = g["in_vector"]
+    A = _setup(ctx, oracle, g["adj"], g["offdiag"], g["diag"], w)
+    ctx.begin_step()
+    m0, m1 = 12, 20
+    H0, *_ = ctx.arnoldi(m0)
+    H1 = np.zeros((m1 + 2, m1 + 2), order="F")
+    H1[:m0 + 1, :m0] = H0[:m0 + 1, :m0]
+    H1, mb, k1, av = ctx.arnoldi(m1, jold=m0, H=H1)
+    _, Href, _, _, avr = oracle.arnoldi(A, w / np.sqrt((w * w).sum()), m1)
+    assert np.abs(H1 - Href).max() <= 1e-11 * np.abs(Href).max()
+    assert av == pytest.approx(avr, rel=1e-10)
+    # shrink below jold: loop body skipped, product A v_jold
+    H2 = np.zeros((10 + 2, 10 + 2), order="F")
+    _, mb, k1, av2 = ctx.arnoldi(10, jold=m1, H=H2)
+    vj = ctx.get_basis(m1)
+    assert av2 == pytest.approx(np.sqrt((oracle.spmv_ell(A, vj) ** 2).sum()), rel=1e-12)
+    assert (mb, k1) == (10, 2) and H2[11, 10] == 1.0
+
+
+def test_happy_breakdown_is_detected(ctx, oracle):
+    """A stationary start vector: A v1 = 0, so column 1 breaks down (:249-256)."""
+    adj = np.array([[2, -1], [1, -1], [0, 0]], dtype=np.int32)[:2]
+    off = np.array([[1.0, 0.0], [1.0, 0.0]])
+    diag = np.array([1.0, 1.0])
+    # pad to a 70-state reducible chain so that m < n
+    n = 70
+    ADJ = np.full((n, 2), -1, dtype=np.int32)
+    OFF = np.zeros((n, 2))
+    DIAG = np.zeros(n)
+    ADJ[:2], OFF[:2], DIAG[:2] = adj, off, diag
+    for i in range(2, n):
+        ADJ[i, 0] = i if i + 1 > n - 1 else i + 2
+        OFF[i, 0] = 0.5
+        DIAG[i] = 0.5
+    w = np.zeros(n)
+    w[:2] = 0.5
+    A = _setup(ctx, oracle, ADJ, OFF, DIAG, w)
+    ctx.begin_step()
+    H, mb, k1, av = ctx.arnoldi(10)
+    _, Href, mbr, k1r, _ = oracle.arnoldi(A, w / np.sqrt(0.5), 10)
+    assert (mb, k1) == (mbr, k1r) == (1, 0)
+    assert abs(H[0, 0] - Href[0, 0]) < 1e-15 and H[1, 0] == 0.0 and H[11, 10] == 1.0
+
+
+@pytest.mark.parametrize("mdl_name,m,tau,steps", [("toggle", 30, 0.01, 4), ("repressilator", 30, 0.002, 3),
+                                                  ("ring6", 20, 0.05, 5)])
+def test_expv_fixed_matches_oracle(ctx, oracle, golden_dir, mdl_name, m, tau, steps):
+    """Benchmark-mode exp(tau A)^steps p0 (BASELINE config 2 recipe at a size the
+    oracle finishes in seconds): l1 error < 1e-10, mass after every step."""
+    from krylovfspssa_amd import synth
+    if mdl_name == "ring6":
+        g = _golden(golden_dir, "solve_ring6.npz")
+        adj, off, diag, p0 = g["adj"], g["offdiag"], g["diag"], g["in_vector"]
+    else:
+        mdl = synth.toggle(160, 140) if mdl_name == "toggle" else synth.repressilator(dims=(40, 36, 30))
+        adj, off, diag = mdl.ell()
+        p0 = synth.poisson_p0(mdl, 30.0 if mdl_name == "toggle" else 12.0)
+    A = _setup(ctx, oracle, adj, off, diag, p0)
+    ws = ctx.expv_fixed(m, tau, steps)
+    w = ctx.get_vector()
+    wref, wsref = oracle.expv_fixed(A, p0, m, tau, steps)
+    assert np.abs(w - wref).sum() < 1e-10
+    assert np.abs(ws - wsref).max() < 1e-12
+    assert np.all(w >= 0.0)
+
+
+def test_combine_clamps_and_sums(ctx, oracle, golden_dir):
+    g = _golden(golden_dir, "solve_ring4.npz")
+    w = g["in_vector"]
+    A = _setup(ctx, oracle, g["adj"], g["offdiag"], g["diag"], w)
+    beta = ctx.begin_step()
+    m = 12
+    ctx.arnoldi(m)
+    V, *_ = oracle.arnoldi(A, w / beta, m)
+    rng = np.random.default_rng(5)
+    y = rng.standard_normal(m + 1)          # forces negative entries
+    wsum = ctx.combine(m + 1, beta, y)
+    ref = np.maximum(beta * V[:, :m + 1] @ y, 0.0)
+    got = ctx.get_vector()
+    assert np.abs(got - ref).max() < 1e-12
+    assert (ref == 0).sum() > 0 and np.all(got >= 0)
+    assert wsum == pytest.approx(ref.sum(), rel=1e-13)
+
+
+def test_size_independent_properties_at_benchmark_size(ctx):
+    """BASELINE config 2 matrix (toggle box 1000 x 1000, N = 10^6): linearity,
+    the mass-balance identity 1^T A x = -leak . x, determinism."""
+    from krylovfspssa_amd import synth
+    mdl = synth.toggle(1000, 1000)
+    rowptr, col, val = mdl.csr_rows()
+    assert rowptr[-1] == 4_996_000 == mdl.nnz()
+    ctx.set_matrix_csr(mdl.n, rowptr, col, val)
+    rng = np.random.default_rng(12345)
+    x, z = rng.random(mdl.n), rng.random(mdl.n)
+    ax, az = ctx.spmv(x), ctx.spmv(z)
+    lin = ctx.spmv(2.0 * x - 3.0 * z)
+    assert np.abs(lin - (2.0 * ax - 3.0 * az)).max() <= 1e-9 * np.abs(ax).max()
+    # column sums of the generator = -(propensity leaving the box)
+    colsum = np.zeros(mdl.n)
+    np.add.at(colsum, col, val)
+    assert (ax.sum() - colsum @ x) == pytest.approx(0.0, abs=1e-7 * np.abs(ax).sum())
+    assert np.array_equal(ax, ctx.spmv(x))
+    # expv on it conserves mass up to the leak and stays non-negative
+    p0 = synth.poisson_p0(mdl, 30.0)
+    ctx.set_vector(p0)
+    ws = ctx.expv_fixed(30, 0.01, 2)
+    w = ctx.get_vector()
+    assert np.all(w >= 0) and 0.999 < ws[-1] <= 1.0 + 1e-12
+    assert ws[-1] == pytest.approx(w.sum(), rel=1e-13)
