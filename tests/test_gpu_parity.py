@@ -111,7 +111,9 @@ def test_arnoldi_matches_oracle(ctx, oracle, golden_dir, fixture, m):
     g = _golden(golden_dir, fixture)
     n = int(g["n"])
     rng = np.random.default_rng(11)
-    w = g["vector"] if "vector" in g.files and g["vector"].sum() > 0.5 else rng.random(n)
+    # a generic start vector: the fixtures' final vectors are (near) stationary,
+    # where A v1 ~ 0 and every later column is rounding noise in both codes
+    w = g["in_vector"] if fixture == "solve_ring6.npz" else rng.random(n)
     A = _setup(ctx, oracle, g["adj"], g["offdiag"], g["diag"], w)
     beta = ctx.begin_step()
     H, mb, k1, av = ctx.arnoldi(m)
