@@ -129,6 +129,11 @@ int kfsp_expv_fixed(kfsp_ctx *ctx, int m, double tau, int nsteps, double *wsums)
  * as in the solver.  variant selects the kernel (0 = default). */
 int kfsp_spmv_bench(kfsp_ctx *ctx, int reps, int variant, float *ms_total);
 
+/* diagnostics: reps launches that read exactly nbytes from a scratch buffer
+ * with elem_bytes (4, 8, 16) per lane in the SpMV's access shape; used to
+ * calibrate the rocprofv3 FETCH_SIZE counter on a known byte count. */
+int kfsp_selftest_stream(kfsp_ctx *ctx, int64_t nbytes, int elem_bytes, int reps, float *ms_total);
+
 /* accumulated device time (ms) by phase since the last reset; HIP-event based
  * and only collected when enabled (it adds synchronisation). */
 enum { KFSP_T_SPMV = 0, KFSP_T_ORTHO = 1, KFSP_T_COMBINE = 2, KFSP_T_COMM = 3,

@@ -1007,6 +1007,26 @@ int kfsp_spmv_bench(kfsp_ctx *ctx, int reps, int variant, float *ms_total)
     return 0;
 }
 
+int kfsp_selftest_stream(kfsp_ctx *ctx, int64_t nbytes, int elem_bytes, int reps, float *ms_total)
+{
+    if (!ctx) return -1;
+    if (nbytes < 4096 || nbytes % 4096) return fail(ctx, -2, "nbytes must be a positive multiple of 4096");
+    if (elem_bytes != 4 && elem_bytes != 8 && elem_bytes != 16) return fail(ctx, -3, "elem_bytes must be 4, 8 or 16");
+    if (reps < 1) return fail(ctx, -4, "reps < 1");
+    HIP_TRY(hipSetDevice(ctx->device));
+    DevBuf<char> buf;
+    HIP_TRY(buf.reserve((size_t)nbytes, true));
+    HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+    for (int r = 0; r < reps; ++r) launch_stream_read(kMaxGrid, elem_bytes, nbytes, buf.p, ctx->d_part.p, ctx->stream);
+    HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+    HIP_TRY(hipEventSynchronize(ctx->ev1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    if (ms_total) *ms_total = ms;
+    buf.release();
+    return 0;
+}
+
 int kfsp_timers_enable(kfsp_ctx *ctx, int on)
 {
     if (!ctx) return -1;

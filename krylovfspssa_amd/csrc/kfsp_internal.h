@@ -103,4 +103,7 @@ void launch_finalize(Pending p, double *out, double *out_sqrt, hipStream_t s);
 // w = scale * u
 void launch_scale_copy(int grid, int64_t npairs, const double *u, const double *sq_u, double beta, double *w, hipStream_t s);
 
+// counter calibration: read nbytes with elem_bytes per lane
+void launch_stream_read(int grid, int elem_bytes, int64_t nbytes, const void *p, double *sink, hipStream_t s);
+
 }  // namespace kfsp

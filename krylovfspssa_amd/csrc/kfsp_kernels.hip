@@ -344,4 +344,31 @@ void launch_scale_copy(int grid, int64_t npairs, const double *u, const double *
                        reinterpret_cast<const double2 *>(u), sq_u, beta, reinterpret_cast<double2 *>(w));
 }
 
+// ------------------------------------------------------- counter calibration
+// Reads n elements of width W bytes per lane (4, 8 or 16) in the SpMV's own
+// access shape (one contiguous 64-lane piece per wave instruction) and folds
+// them into one value per block, so the traffic is exactly n*W bytes read.
+typedef double d2v __attribute__((ext_vector_type(2)));
+template <class T>
+__global__ __launch_bounds__(kBlock) void k_stream_read(int64_t n, const T *__restrict__ p, double *__restrict__ sink)
+{
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const T v = __builtin_nontemporal_load(p + i);
+        if constexpr (sizeof(T) == 16) acc += v.x + v.y;
+        else acc += (double)v;
+    }
+    if (acc == 0.12345) sink[blockIdx.x] = acc;   // never true for the zero-filled buffer: keeps the loads alive
+}
+
+void launch_stream_read(int grid, int elem_bytes, int64_t nbytes, const void *p, double *sink, hipStream_t st)
+{
+    if (elem_bytes == 4)
+        hipLaunchKernelGGL((k_stream_read<int32_t>), dim3(grid), dim3(kBlock), 0, st, nbytes / 4, (const int32_t *)p, sink);
+    else if (elem_bytes == 8)
+        hipLaunchKernelGGL((k_stream_read<double>), dim3(grid), dim3(kBlock), 0, st, nbytes / 8, (const double *)p, sink);
+    else
+        hipLaunchKernelGGL((k_stream_read<d2v>), dim3(grid), dim3(kBlock), 0, st, nbytes / 16, (const d2v *)p, sink);
+}
+
 }  // namespace kfsp

@@ -63,6 +63,7 @@ def load_library():
         "kfsp_padm": [C.c_int, C.c_int, dbl, vp, C.c_int, vp, C.POINTER(C.c_int), C.POINTER(dbl)],
         "kfsp_expv_fixed": [vp, C.c_int, dbl, C.c_int, vp],
         "kfsp_spmv_bench": [vp, C.c_int, C.c_int, C.POINTER(C.c_float)],
+        "kfsp_selftest_stream": [vp, i64, C.c_int, C.c_int, C.POINTER(C.c_float)],
         "kfsp_timers_enable": [vp, C.c_int],
         "kfsp_get_timers": [vp, vp, C.c_int],
         "kfsp_set_option": [vp, C.c_char_p, i64],
@@ -253,6 +254,12 @@ class KfspContext:
     def spmv_bench(self, reps, variant=0):
         ms = C.c_float(0.0)
         self._chk(self._lib.kfsp_spmv_bench(self._h, int(reps), int(variant), C.byref(ms)), "kfsp_spmv_bench")
+        return ms.value
+
+    def selftest_stream(self, nbytes, elem_bytes, reps=1):
+        ms = C.c_float(0.0)
+        self._chk(self._lib.kfsp_selftest_stream(self._h, int(nbytes), int(elem_bytes), int(reps), C.byref(ms)),
+                  "kfsp_selftest_stream")
         return ms.value
 
     def timers(self, reset=False):
