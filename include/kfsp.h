@@ -69,6 +69,8 @@ int kfsp_set_matrix_csr(kfsp_ctx *ctx, int64_t n, int64_t row0, int64_t nrows,
 /* what the device holds: rows (local), stored off-diagonal slots incl. padding,
  * true nonzeros incl. diagonal (local rows) */
 int kfsp_matrix_info(const kfsp_ctx *ctx, int64_t *nrows, int64_t *slots, int64_t *nnz);
+/* global number of states of the generator last set (FSP%SIZE) */
+int kfsp_num_states(const kfsp_ctx *ctx, int64_t *n);
 
 /* ---- probability vector w (the solver's W == FSP%VECTOR, KrylovSolver.f90:33-34) */
 /* local row block of the context (the whole vector when nranks == 1) */
@@ -116,6 +118,50 @@ int kfsp_get_basis(kfsp_ctx *ctx, int j, int64_t nlocal, double *v);
  * (src/expokit/dgpadm.f:2-169, :171-339).  E: m*m column-major (ld m). */
 int kfsp_padm(int ideg, int m, double t, const double *H, int ldh, double *E,
               int *ns, double *hnorm);
+
+/* ---- the adaptive solver ---------------------------------------------- */
+/* Seams of DGEXPV_FSP through which the host's state-space code is reached.
+ * A callback may call back into this library (kfsp_get_vector, kfsp_spmv_w,
+ * kfsp_set_matrix_ell, kfsp_set_vector ...) and must leave the context holding
+ * the generator and the probability vector of the (possibly changed) FSP.
+ *   drop   : DROP_STATES(W, FSP, MODEL, DSUM, FMATVEC), KrylovSolver.f90:509-512
+ *   expand : SSA_EXTENDER(T_SSA, ..) + ONESTEP_EXTENDER, :518-534
+ *   log    : the reference's VERBOSITY prints and the unconditional WSUM print
+ *            (:233,384-389,427-431,452,502,523); vals layout per event below.
+ * Any of them may be NULL: no drop = nothing is ever dropped, no expand =
+ * kfsp_dgexpv returns 10 when the FSP criterion calls for an expansion. */
+enum {
+    KFSP_EV_BEGIN_IOP = 1,   /* (none) */
+    KFSP_EV_WSUM = 2,        /* wsum */
+    KFSP_EV_STEP = 3,        /* nstep, n, t_step, t_new, t_now, m */
+    KFSP_EV_REJECT_STEP = 4, /* t_old, err_loc, err_required, t_step_new */
+    KFSP_EV_DIM_CHANGE = 5,  /* err_loc, err_required, m_new */
+    KFSP_EV_CALL_SSA = 6     /* t_ssa */
+};
+typedef struct {
+    void *user;
+    int (*drop)(void *user, double dsum, int64_t *n_new);
+    int (*expand)(void *user, double t_ssa, int64_t *n_new);
+    void (*log)(void *user, int event, const double *vals, int nvals);
+} kfsp_fsp_ops;
+
+/* What the reference gathers in IWSP(1:7)/WSP(1:10) and then discards
+ * (KrylovSolver.f90:554-573), plus counts of the FSP events. */
+typedef struct {
+    int32_t nmult, nexph, nscale, nstep, nreject, ibrkflag, mbrkdwn;
+    int32_t n_wsum, n_expand, n_drop_calls;
+    double step_min, step_max, x_error, s_error, tbrkdwn, t_now, hump, beta;
+} kfsp_stats;
+
+/* DGEXPV_FSP (KrylovSolver.f90:40-653) from :151 on: the adaptive time loop on
+ * the context's resident generator and vector w (= V on entry, = W on exit).
+ * MATRIX_STARTER and the five initial ONESTEP_EXTENDER calls (:130-134) are
+ * the caller's (they build what is uploaded first).  n_reactions is
+ * MODEL%NREACTIONS (enters the cost model through NNZ, :196,:537).
+ * returns 0; 10 = expansion needed but ops->expand == NULL; <0 bad argument;
+ * >0 device/host failure as everywhere. */
+int kfsp_dgexpv(kfsp_ctx *ctx, double t, double fsptol, double krytol, int n_reactions,
+                const kfsp_fsp_ops *ops, kfsp_stats *stats);
 
 /* ---- benchmark mode --------------------------------------------------- */
 /* nsteps steps of fixed Krylov dimension m and fixed step tau on the resident

@@ -658,6 +658,14 @@ int kfsp_matrix_info(const kfsp_ctx *ctx, int64_t *nrows, int64_t *slots, int64_
     return 0;
 }
 
+int kfsp_num_states(const kfsp_ctx *ctx, int64_t *n)
+{
+    if (!ctx) return -1;
+    if (!n) return -2;
+    *n = ctx->n;
+    return 0;
+}
+
 int kfsp_set_vector(kfsp_ctx *ctx, int64_t nlocal, const double *w)
 {
     if (!ctx) return -1;
@@ -707,7 +715,9 @@ int kfsp_arnoldi(kfsp_ctx *ctx, int m, int jold, int qiop, double break_tol, dou
 {
     if (!ctx) return -1;
     if (ctx->ldv == 0) return fail(ctx, -1, "no matrix set");
-    if (m < 1 || m > kMMax || (int64_t)m >= std::max<int64_t>(ctx->n, 2)) return fail(ctx, -2, "bad m (need 1 <= m <= 100, m < n)");
+    // m >= n is legal: the reference only caps M at N-1 when a step starts (:211),
+    // a dimension change (:404) may exceed it and runs into a breakdown instead
+    if (m < 1 || m > kMMax) return fail(ctx, -2, "bad m (need 1 <= m <= 100)");
     if (jold < 1 || jold > kMMax) return fail(ctx, -3, "bad jold");
     if (qiop < 0) return fail(ctx, -4, "bad qiop");
     if (!H) return fail(ctx, -6, "null H");

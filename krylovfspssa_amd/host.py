@@ -48,6 +48,8 @@ def load_library():
         "kfsp_set_matrix_ell": [vp, i32, i32, i32, vp, vp, vp],
         "kfsp_set_matrix_csr": [vp, i64, i64, i64, vp, vp, vp],
         "kfsp_matrix_info": [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)],
+        "kfsp_num_states": [vp, C.POINTER(i64)],
+        "kfsp_dgexpv": [vp, dbl, dbl, dbl, C.c_int, vp, vp],
         "kfsp_set_vector": [vp, i64, vp],
         "kfsp_get_vector": [vp, i64, vp],
         "kfsp_begin_step": [vp, C.POINTER(dbl)],
@@ -80,6 +82,24 @@ def load_library():
 
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+_DROP_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_double, C.POINTER(C.c_int64))
+_EXPAND_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_double, C.POINTER(C.c_int64))
+_LOG_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_int)
+
+EV_BEGIN_IOP, EV_WSUM, EV_STEP, EV_REJECT_STEP, EV_DIM_CHANGE, EV_CALL_SSA = 1, 2, 3, 4, 5, 6
+
+
+class FspOps(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("drop", _DROP_FN), ("expand", _EXPAND_FN), ("log", _LOG_FN)]
+
+
+class SolveStats(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("nmult", "nexph", "nscale", "nstep", "nreject", "ibrkflag", "mbrkdwn",
+                                         "n_wsum", "n_expand", "n_drop_calls")] + \
+               [(k, C.c_double) for k in ("step_min", "step_max", "x_error", "s_error", "tbrkdwn", "t_now",
+                                          "hump", "beta")]
 
 
 def padm(H, t, ideg=6):
@@ -245,6 +265,40 @@ class KfspContext:
         o = C.c_double(0.0)
         self._chk(self._lib.kfsp_asum_w(self._h, C.byref(o)), "kfsp_asum_w")
         return o.value
+
+    def dgexpv(self, t, fsptol, krytol, n_reactions, drop=None, expand=None):
+        """The adaptive solver (DGEXPV_FSP, KrylovSolver.f90:151-573) on the resident
+        generator and vector.  drop(dsum) / expand(t_ssa) are Python callables that
+        return the new number of states (they re-upload through this context).
+        -> (return code, SolveStats, log) with log = list of (event, values)."""
+        log = []
+
+        def _log(_u, ev, vals, n):
+            log.append((ev, [vals[i] for i in range(n)]))
+
+        def _wrap(fn):
+            def cb(_u, x, n_new):
+                try:
+                    r = fn(x)
+                    if r is not None:
+                        n_new[0] = int(r)
+                    return 0
+                except Exception as e:      # never let an exception cross the C boundary
+                    log.append((-1, repr(e)))
+                    return 4000
+            return cb
+        ops = FspOps(None, _DROP_FN(_wrap(drop)) if drop else _DROP_FN(), _EXPAND_FN(_wrap(expand)) if expand else _EXPAND_FN(),
+                     _LOG_FN(_log))
+        st = SolveStats()
+        rc = self._lib.kfsp_dgexpv(self._h, float(t), float(fsptol), float(krytol), int(n_reactions),
+                                   C.byref(ops), C.byref(st))
+        if rc not in (0, 10):
+            self._chk(rc, "kfsp_dgexpv")
+        n = C.c_int64(0)
+        self._lib.kfsp_num_states(self._h, C.byref(n))
+        self.n = n.value
+        self.row0, self.nloc = self.row_block(self.n)
+        return rc, st, log
 
     def expv_fixed(self, m, tau, nsteps):
         ws = np.zeros(max(nsteps, 1), dtype=np.float64)

@@ -242,3 +242,64 @@ def test_size_independent_properties_at_benchmark_size(ctx):
     w = ctx.get_vector()
     assert np.all(w >= 0) and 0.999 < ws[-1] <= 1.0 + 1e-12
     assert ws[-1] == pytest.approx(w.sum(), rel=1e-13)
+
+
+# ---------------------------------------------------------------- adaptive solver
+
+def _would_drop(ctx, dsum):
+    """DROP_STATES (StateSpace.f90:431-548) up to its compaction decision, in numpy
+    on vectors fetched through the C ABI: FIND_DROPTOL :398-427, marking :475-495,
+    the 10 % rule :497.  Returns True when the reference would compact the FSP."""
+    w = ctx.get_vector()
+    droptol = 1e-8
+    while True:
+        s = w[(w < droptol) & (w > 0)].sum()
+        if s < dsum:
+            break
+        droptol /= 10.0
+    cnt = int((w < droptol).sum()) - int((ctx.spmv_w() > 1e-8).sum())
+    return cnt / len(w) > 0.1
+
+
+@pytest.mark.parametrize("name", ["ring6", "ring6_T40", "ring4"])
+def test_adaptive_solver_follows_reference_trajectory(ctx, golden_dir, name):
+    """kfsp_dgexpv against CME_SOLVE of the unmodified reference on closed systems:
+    identical step sizes and Krylov dimensions, WSUM sequence and final vector
+    within l1 < 1e-10 (BASELINE north_star tolerance)."""
+    from krylovfspssa_amd import host
+    g = _golden(golden_dir, f"solve_{name}.npz")
+    ctx.set_matrix_ell(g["adj"], g["offdiag"], g["diag"])
+    ctx.set_vector(g["in_vector"])
+    dropped = []
+
+    def drop(dsum):
+        dropped.append(_would_drop(ctx, dsum))
+        return None
+
+    rc, st, log = ctx.dgexpv(float(g["T"]), float(g["fsptol"]), float(g["krytol"]), int(g["nr"]), drop=drop)
+    assert rc == 0 and not any(dropped)
+    steps = [v for ev, v in log if ev == host.EV_STEP]
+    wsums = np.array([v[0] for ev, v in log if ev == host.EV_WSUM])
+    assert np.array_equal([s[2] for s in steps], g["step_tau"])
+    assert np.array_equal([int(s[5]) for s in steps], g["step_m"])
+    assert np.array_equal([s[4] for s in steps], g["step_tnow"])
+    assert len(wsums) == len(g["wsum"]) and np.abs(wsums - g["wsum"]).max() < 1e-10
+    assert sum(ev == host.EV_REJECT_STEP for ev, _ in log) == int(g["n_reject"])
+    assert sum(ev == host.EV_DIM_CHANGE for ev, _ in log) == int(g["n_dimchange"])
+    w = ctx.get_vector()
+    assert np.abs(w - g["vector"]).sum() < 1e-10
+    assert st.nstep == len(g["step_tau"]) and st.t_now == float(g["T"])
+
+
+def test_adaptive_solver_reports_needed_expansion(ctx, golden_dir):
+    """An open system from a point mass leaks probability at once: without an
+    expand callback the solver stops with code 10 after the FSP test fails
+    (KrylovSolver.f90:458-470, 518-534) and leaves w = beta*v1 restored."""
+    g = _golden(golden_dir, "assembly_toggle_k5.npz")
+    ctx.set_matrix_ell(g["adj"], g["offdiag"], g["diag"])
+    p0 = np.zeros(int(g["n"]))
+    p0[0] = 1.0
+    ctx.set_vector(p0)
+    rc, st, log = ctx.dgexpv(1000.0, 1e-4, 1e-10, int(g["nr"]))
+    assert rc == 10
+    assert any(ev == 6 for ev, _ in log)
