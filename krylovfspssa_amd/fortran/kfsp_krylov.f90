@@ -1,0 +1,222 @@
+! MODULE KRYLOVSOLVER - the solver entry points of the reference
+! (src/fsp/KrylovSolver.f90:7-36 CME_SOLVE, :40-653 DGEXPV_FSP) on top of the
+! MI355X hot path.
+!
+! The Fortran side owns what the reference's host code owns - the model, the
+! state list, the generator columns and the decisions about growing and
+! shrinking the FSP - and hands the time loop to libkfsp_hip through the C ABI
+! (module KFSP_C, include/kfsp.h):
+!     generator columns  -> kfsp_set_matrix_ell   (FSP%MATRIX verbatim)
+!     probability vector -> kfsp_set_vector / kfsp_get_vector
+!     time loop          -> kfsp_dgexpv, which calls back here when the FSP has
+!                           to change: CB_DROP (DROP_STATES, :509-512) and
+!                           CB_EXPAND (SSA_EXTENDER + ONESTEP_EXTENDER, :518-534)
+!     log lines          -> CB_LOG prints what the reference prints
+! There is no CPU fallback: without the library / a GPU the solve stops.
+MODULE KRYLOVSOLVER
+  USE, INTRINSIC :: ISO_C_BINDING
+  USE STATESPACE
+  USE KFSP_C
+  IMPLICIT NONE
+
+  ! statistics of the last solve (the reference computes them into local
+  ! arrays and loses them, :554-573)
+  TYPE(KFSP_STATS), SAVE :: LAST_SOLVE_STATS
+
+  TYPE(C_PTR), SAVE, PRIVATE :: CTX = C_NULL_PTR
+  TYPE(FINITE_STATE_PROJECTION), POINTER, SAVE, PRIVATE :: CUR_FSP => NULL()
+  TYPE(CME_MODEL), POINTER, SAVE, PRIVATE :: CUR_MODEL => NULL()
+  INTEGER, SAVE, PRIVATE :: CUR_TRACE = 0
+
+  PRIVATE :: ENSURE_CONTEXT, UPLOAD_FSP, CHECK, CB_DROP, CB_EXPAND, CB_LOG
+
+CONTAINS
+
+  SUBROUTINE CME_SOLVE(MODEL, T, FSP_IN, FSP_OUT, FSPTOL, EXP_TOL, VERBOSITY)
+    TYPE(CME_MODEL), INTENT(IN) :: MODEL
+    DOUBLE PRECISION, INTENT(IN) :: T
+    TYPE(FINITE_STATE_PROJECTION) :: FSP_IN
+    DOUBLE PRECISION, INTENT(IN) :: FSPTOL
+    DOUBLE PRECISION, INTENT(IN) :: EXP_TOL
+    TYPE(FINITE_STATE_PROJECTION) :: FSP_OUT
+    INTEGER, INTENT(IN), OPTIONAL :: VERBOSITY
+    INTEGER :: ITRACE, IFLAG
+    DOUBLE PRECISION :: KRYTOL
+    ITRACE = 0
+    IF (PRESENT(VERBOSITY)) ITRACE = VERBOSITY
+    KRYTOL = EXP_TOL
+    PRINT *, 'CALLING DGEXPV_FSP'
+    CALL DGEXPV_FSP(MODEL, T, FSP_IN%VECTOR, FSP_OUT, FSP_OUT%VECTOR, FSPTOL, KRYTOL, ITRACE, IFLAG)
+  END SUBROUTINE CME_SOLVE
+
+  ! p(T) = exp(T A) p(0) on an adaptively grown / pruned FSP.
+  ! V: start vector on the seed states FSP%STATE(:,1:FSP%SIZE); on return
+  ! FSP holds the final state list and FSP%VECTOR(1:FSP%SIZE) (= W) the result.
+  SUBROUTINE DGEXPV_FSP(MODEL, T, V, FSP, W, FSPTOL, KRYTOL, ITRACE, IFLAG)
+    TYPE(CME_MODEL), TARGET :: MODEL
+    DOUBLE PRECISION, INTENT(IN) :: T
+    DOUBLE PRECISION, INTENT(IN) :: V(:)
+    DOUBLE PRECISION, TARGET :: W(:)
+    DOUBLE PRECISION, INTENT(IN) :: FSPTOL
+    DOUBLE PRECISION :: KRYTOL
+    TYPE(FINITE_STATE_PROJECTION), TARGET :: FSP
+    INTEGER :: ITRACE
+    INTEGER :: IFLAG
+    TYPE(KFSP_FSP_OPS) :: OPS
+    DOUBLE PRECISION, ALLOCATABLE :: P0(:)
+    INTEGER :: I, N0, RC
+
+    IFLAG = 0
+    N0 = FSP%SIZE
+    ALLOCATE(P0(N0))
+    P0 = V(1:N0)                       ! DCOPY(FSP%SIZE, V, 1, W, 1)  :176
+
+    ! the FSP the first step runs on (:130-134)
+    CALL MATRIX_STARTER(FSP, MODEL)
+    DO I = 1, 5
+       CALL ONESTEP_EXTENDER(FSP, MODEL)
+    ENDDO
+    FSP%VECTOR(1:N0) = P0
+    IF (FSP%SIZE > N0) FSP%VECTOR(N0 + 1:FSP%SIZE) = 0.0D0
+
+    CALL ENSURE_CONTEXT()
+    CUR_FSP => FSP
+    CUR_MODEL => MODEL
+    CUR_TRACE = ITRACE
+    CALL UPLOAD_FSP(FSP, MODEL)
+
+    OPS%USER = C_NULL_PTR
+    OPS%DROP = C_FUNLOC(CB_DROP)
+    OPS%EXPAND = C_FUNLOC(CB_EXPAND)
+    OPS%LOG = C_FUNLOC(CB_LOG)
+    RC = KFSP_DGEXPV(CTX, T, FSPTOL, KRYTOL, INT(MODEL%NREACTIONS, C_INT), OPS, LAST_SOLVE_STATS)
+    CALL CHECK(RC, 'kfsp_dgexpv')
+
+    RC = KFSP_GET_VECTOR(CTX, INT(FSP%SIZE, C_INT64_T), FSP%VECTOR)
+    CALL CHECK(RC, 'kfsp_get_vector')
+    ! W is FSP%VECTOR itself when called through CME_SOLVE; a distinct W gets a copy
+    IF (.NOT. C_ASSOCIATED(C_LOC(W(1)), C_LOC(FSP%VECTOR(1)))) THEN
+       IF (SIZE(W) >= FSP%SIZE) W(1:FSP%SIZE) = FSP%VECTOR(1:FSP%SIZE)
+    ENDIF
+    NULLIFY(CUR_FSP, CUR_MODEL)
+  END SUBROUTINE DGEXPV_FSP
+
+  ! ------------------------------------------------------------- plumbing
+
+  SUBROUTINE ENSURE_CONTEXT()
+    CHARACTER(LEN=16) :: ENV
+    INTEGER :: DEV, L, STAT, RC
+    IF (C_ASSOCIATED(CTX)) RETURN
+    DEV = 0
+    CALL GET_ENVIRONMENT_VARIABLE('KFSP_DEVICE', ENV, L, STAT)
+    IF (STAT == 0 .AND. L > 0) READ(ENV(1:L), *, IOSTAT=STAT) DEV
+    RC = KFSP_CREATE(INT(DEV, C_INT), CTX)
+    IF (RC /= 0) THEN
+       PRINT *, 'KFSP: NO USABLE HIP DEVICE (kfsp_create returned', RC, '); THE SOLVER HAS NO CPU PATH.'
+       STOP 2
+    ENDIF
+  END SUBROUTINE ENSURE_CONTEXT
+
+  SUBROUTINE CHECK(RC, WHAT)
+    INTEGER(C_INT), INTENT(IN) :: RC
+    CHARACTER(LEN=*), INTENT(IN) :: WHAT
+    IF (RC == 0) RETURN
+    PRINT *, 'KFSP: ', WHAT, ' FAILED WITH CODE ', RC, ': ', KFSP_ERROR_TEXT(CTX)
+    STOP 3
+  END SUBROUTINE CHECK
+
+  ! generator columns + probability vector of the current FSP -> device
+  SUBROUTINE UPLOAD_FSP(FSP, MODEL)
+    TYPE(FINITE_STATE_PROJECTION), INTENT(IN) :: FSP
+    TYPE(CME_MODEL), INTENT(IN) :: MODEL
+    INTEGER(C_INT) :: RC
+    RC = KFSP_SET_MATRIX_ELL(CTX, INT(FSP%SIZE, C_INT32_T), INT(MODEL%NREACTIONS, C_INT32_T), &
+         INT(SIZE(FSP%MATRIX%ADJ, 1), C_INT32_T), FSP%MATRIX%ADJ, FSP%MATRIX%OFFDIAG, FSP%MATRIX%DIAG)
+    CALL CHECK(RC, 'kfsp_set_matrix_ell')
+    RC = KFSP_SET_VECTOR(CTX, INT(FSP%SIZE, C_INT64_T), FSP%VECTOR)
+    CALL CHECK(RC, 'kfsp_set_vector')
+  END SUBROUTINE UPLOAD_FSP
+
+  ! DROP_STATES seam: the derivative guard's product A*w comes from the device
+  FUNCTION CB_DROP(USER, DSUM, N_NEW) BIND(C) RESULT(RC)
+    TYPE(C_PTR), VALUE :: USER
+    REAL(C_DOUBLE), VALUE :: DSUM
+    INTEGER(C_INT64_T) :: N_NEW
+    INTEGER(C_INT) :: RC
+    DOUBLE PRECISION, ALLOCATABLE :: WLOC(:), AW(:)
+    DOUBLE PRECISION :: D
+    LOGICAL :: CHANGED
+    INTEGER :: N
+    N = CUR_FSP%SIZE
+    ALLOCATE(WLOC(N), AW(N))
+    RC = KFSP_GET_VECTOR(CTX, INT(N, C_INT64_T), WLOC)
+    IF (RC /= 0) RETURN
+    RC = KFSP_SPMV_W(CTX, AW)
+    IF (RC /= 0) RETURN
+    D = DSUM
+    CALL DROP_STATES_CORE(WLOC, CUR_FSP, CUR_MODEL, D, AW, CHANGED)
+    IF (CHANGED) THEN
+       CUR_FSP%VECTOR(1:N) = WLOC
+       CALL UPLOAD_FSP(CUR_FSP, CUR_MODEL)
+    ENDIF
+    N_NEW = CUR_FSP%SIZE
+    RC = 0
+  END FUNCTION CB_DROP
+
+  ! expansion seam: SSA paths of length T_SSA from every state, then one sweep
+  ! of one-step reachability; new states start with probability 0
+  FUNCTION CB_EXPAND(USER, T_SSA, N_NEW) BIND(C) RESULT(RC)
+    TYPE(C_PTR), VALUE :: USER
+    REAL(C_DOUBLE), VALUE :: T_SSA
+    INTEGER(C_INT64_T) :: N_NEW
+    INTEGER(C_INT) :: RC
+    DOUBLE PRECISION :: TS
+    RC = KFSP_GET_VECTOR(CTX, INT(CUR_FSP%SIZE, C_INT64_T), CUR_FSP%VECTOR)
+    IF (RC /= 0) RETURN
+    TS = T_SSA
+    CALL SSA_EXTENDER(TS, CUR_FSP, CUR_MODEL)
+    CALL ONESTEP_EXTENDER(CUR_FSP, CUR_MODEL)
+    CALL UPLOAD_FSP(CUR_FSP, CUR_MODEL)
+    N_NEW = CUR_FSP%SIZE
+    RC = 0
+  END FUNCTION CB_EXPAND
+
+  ! the reference's prints (KrylovSolver.f90:233-235, 384-389, 427-431, 452,
+  ! 523-525, 641-651), same wording so that its logs and ours diff cleanly
+  SUBROUTINE CB_LOG(USER, EVENT, VALS, NVALS) BIND(C)
+    TYPE(C_PTR), VALUE :: USER
+    INTEGER(C_INT), VALUE :: EVENT, NVALS
+    REAL(C_DOUBLE), INTENT(IN) :: VALS(*)
+    SELECT CASE (EVENT)
+    CASE (KFSP_EV_WSUM)
+       PRINT *, 'WSUM= ', VALS(1)
+    CASE (KFSP_EV_BEGIN_IOP)
+       IF (CUR_TRACE /= 0) PRINT *, 'BEGINNING IOP...'
+    CASE (KFSP_EV_STEP)
+       IF (CUR_TRACE /= 0) THEN
+          PRINT *, 'TIMESTEP', INT(VALS(1)), '-------------------------------'
+          PRINT *, 'FSP SIZE         =', INT(VALS(2))
+          PRINT *, 'STEP_SIZE        =', VALS(3)
+          PRINT *, 'NEXT_STEP        =', VALS(4)
+          PRINT *, 'T_NOW            =', VALS(5)
+          PRINT *, 'KRYLOV DIMENSION =', INT(VALS(6))
+       ENDIF
+    CASE (KFSP_EV_REJECT_STEP)
+       IF (CUR_TRACE /= 0) THEN
+          PRINT *, 'T_STEP =', VALS(1)
+          PRINT *, 'ERR_LOC =', VALS(2)
+          PRINT *, 'ERR_REQUIRED =', VALS(3)
+          PRINT *, 'STEPSIZE REJECTED, DOWN TO:', VALS(4)
+       ENDIF
+    CASE (KFSP_EV_DIM_CHANGE)
+       IF (CUR_TRACE /= 0) THEN
+          PRINT *, 'ERR_LOC =', VALS(1)
+          PRINT *, 'ERR_REQUIRED =', VALS(2)
+          PRINT *, 'DIMENSION CHANGED INTO M =', INT(VALS(3))
+       ENDIF
+    CASE (KFSP_EV_CALL_SSA)
+       IF (CUR_TRACE /= 0) PRINT *, 'CALLING SSA'
+    END SELECT
+  END SUBROUTINE CB_LOG
+
+END MODULE KRYLOVSOLVER
