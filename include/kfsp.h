@@ -51,6 +51,9 @@ int kfsp_abi_version(void);
 int kfsp_comm_unique_id(void *id_bytes /* [KFSP_UNIQUE_ID_BYTES] */);
 int kfsp_comm_init(kfsp_ctx *ctx, int nranks, int rank, const void *id_bytes);
 int kfsp_row_block(const kfsp_ctx *ctx, int64_t n, int64_t *row0, int64_t *nrows);
+/* the same arithmetic without a context (host only; usable without a GPU):
+ * block of `rank` out of `nranks` for n states, and the padded block length L */
+int kfsp_partition(int64_t n, int nranks, int rank, int64_t *row0, int64_t *nrows, int64_t *block_len);
 
 /* ---- generator ------------------------------------------------------- */
 /* TYPE FSP_MATRIX verbatim (StateSpace.f90:13-17): ADJ(bw,n) int32 1-based

@@ -528,16 +528,25 @@ int kfsp_comm_init(kfsp_ctx *ctx, int nranks, int rank, const void *id_bytes)
     return 0;
 }
 
+int kfsp_partition(int64_t n, int nranks, int rank, int64_t *row0, int64_t *nrows, int64_t *block_len)
+{
+    if (n < 0) return -1;
+    if (nranks < 1) return -2;
+    if (rank < 0 || rank >= nranks) return -3;
+    int64_t L = round_up((n + nranks - 1) / nranks, kChunk);
+    if (L == 0) L = kChunk;
+    const int64_t r0 = (int64_t)rank * L;
+    if (row0) *row0 = std::min(r0, n);
+    if (nrows) *nrows = std::max<int64_t>(0, std::min<int64_t>(L, n - r0));
+    if (block_len) *block_len = L;
+    return 0;
+}
+
 int kfsp_row_block(const kfsp_ctx *ctx, int64_t n, int64_t *row0, int64_t *nrows)
 {
     if (!ctx) return -1;
     if (n < 0) return -2;
-    int64_t L = round_up((n + ctx->nranks - 1) / ctx->nranks, kChunk);
-    if (L == 0) L = kChunk;
-    const int64_t r0 = (int64_t)ctx->rank * L;
-    if (row0) *row0 = std::min(r0, n);
-    if (nrows) *nrows = std::max<int64_t>(0, std::min<int64_t>(L, n - r0));
-    return 0;
+    return kfsp_partition(n, ctx->nranks, ctx->rank, row0, nrows, nullptr) ? -2 : 0;
 }
 
 int kfsp_set_matrix_ell(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, const int32_t *adj,

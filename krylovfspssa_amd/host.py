@@ -45,6 +45,7 @@ def load_library():
         "kfsp_comm_unique_id": [vp],
         "kfsp_comm_init": [vp, C.c_int, C.c_int, vp],
         "kfsp_row_block": [vp, i64, C.POINTER(i64), C.POINTER(i64)],
+        "kfsp_partition": [i64, C.c_int, C.c_int, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)],
         "kfsp_set_matrix_ell": [vp, i32, i32, i32, vp, vp, vp],
         "kfsp_set_matrix_csr": [vp, i64, i64, i64, vp, vp, vp],
         "kfsp_matrix_info": [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)],
@@ -113,6 +114,17 @@ def padm(H, t, ideg=6):
     if rc:
         raise KfspError(f"kfsp_padm -> {rc}")
     return E, ns.value, hn.value
+
+
+def partition(n, nranks, rank):
+    """(row0, nrows, L): the contiguous row block of `rank` and the padded block
+    length; global index of local row k of rank p is p*L + k (host arithmetic
+    of the library, no GPU needed)."""
+    r0, nr, L = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+    rc = load_library().kfsp_partition(int(n), int(nranks), int(rank), C.byref(r0), C.byref(nr), C.byref(L))
+    if rc:
+        raise KfspError(f"kfsp_partition -> {rc}")
+    return r0.value, nr.value, L.value
 
 
 class KfspContext:
