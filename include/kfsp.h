@@ -175,7 +175,9 @@ int kfsp_expv_fixed(kfsp_ctx *ctx, int m, double tau, int nsteps, double *wsums)
 /* reps back-to-back launches of the SpMV kernel y = A v_1 on the context's
  * stream, bracketed by HIP events: *ms_total = elapsed GPU time.  With
  * nranks > 1 every launch is preceded by the all-gather of the source slab,
- * as in the solver.  variant selects the kernel (0 = default). */
+ * as in the solver.  variant: 0 = the format the library chose (banded DIA when
+ * the rows allow it, else SELL-64), 1 = CSR-stream (needs option build_csr=1
+ * before the matrix is set), 2 = SELL-64 even when DIA is active. */
 int kfsp_spmv_bench(kfsp_ctx *ctx, int reps, int variant, float *ms_total);
 
 /* diagnostics: reps launches that read exactly nbytes from a scratch buffer

@@ -71,6 +71,12 @@ struct kfsp_ctx {
     DevBuf<int32_t> d_col;
     DevBuf<double> d_val, d_diag;
     int64_t nchunks = 0, slots = 0, nnz = 0;
+    // banded (DIA) form, used instead of SELL when the rows allow it
+    DevBuf<double> d_dia;
+    bool use_dia = false;
+    int nd = 0;
+    int32_t delta[kMaxDiag] = {0};
+    int64_t dia_ld = 0;
     // optional CSR copy for the CSR-stream kernel variant
     DevBuf<int64_t> d_rowptr;
     DevBuf<int32_t> d_ccol, d_tile;
@@ -89,6 +95,7 @@ struct kfsp_ctx {
     DevBuf<double> d_stage;  // kNumStage
     DevBuf<double> d_H;      // kMH * kMH image + 2 (avnorm^2, avnorm)
     DevBuf<double> d_sq;     // finished squared norms, index = column (1-based)
+    DevBuf<double> d_g;      // finished u_j . u_{j-1}, index = j
     DevBuf<double> d_y;      // kMH coefficients
     DevBuf<int> d_flag;
     int part_rr = 0, stage_rr = 0;
@@ -96,8 +103,11 @@ struct kfsp_ctx {
     double avnorm_last = 0.0;
 
     // options
-    int64_t opt_grid = 0;   // 0 = auto
+    int64_t opt_grid = 0;   // cap on the product kernels' grid, 0 = auto (2048)
+    int64_t opt_vgrid = 0;  // cap on the streaming kernels' grid, 0 = auto (1024)
     int64_t opt_nt = -1;    // -1 auto, 0 off, 1 on
+    int64_t opt_format = 0; // 0 auto (DIA when banded), 1 always SELL
+    int64_t opt_fused = 1;  // 1: one-pass IOP(2) orthogonalisation (k_ortho2)
     bool timers = false;
     double t_ms[KFSP_T_COUNT] = {0, 0, 0, 0, 0, 0};
 };
@@ -137,8 +147,11 @@ int nccl_fail(kfsp_ctx *c, ncclResult_t r, const char *where)
 int spmv_grid(const kfsp_ctx *c)
 {
     int64_t g = round_up((c->nchunks + 3) / 4, 8);
-    if (c->opt_grid > 0) g = std::min<int64_t>(g, round_up(c->opt_grid, 8));
-    g = std::min<int64_t>(g, kMaxGrid);
+    // 1024 workgroups (4 per CU, 16 waves per CU) already saturate HBM with the
+    // 5-9 independent loads a lane keeps in flight, and halve the partial sums
+    // every consumer has to re-add (measured: profiles/r01_sweep.log)
+    const int64_t cap = c->opt_grid > 0 ? round_up(c->opt_grid, 8) : 1024;
+    g = std::min<int64_t>(g, std::min<int64_t>(cap, kMaxGrid));
     return (int)std::max<int64_t>(g, 8);
 }
 
@@ -147,11 +160,14 @@ int spmv_grid(const kfsp_ctx *c)
 // them (left by a larger, earlier FSP) is never read.
 int64_t act_pairs(const kfsp_ctx *c) { return c->nchunks * (kChunk / 2); }
 
+// Streaming kernels: every consumer re-sums the producer's partials, so the
+// grid is kept at <= 1024 workgroups (4 per CU) with >= 4 pairs per lane; the
+// loops are unrolled so that this still keeps > 16 MB of loads in flight.
 int vec_grid(const kfsp_ctx *c)
 {
-    int64_t g = (act_pairs(c) + kBlock - 1) / kBlock;
-    if (c->opt_grid > 0) g = std::min<int64_t>(g, c->opt_grid);
-    g = std::min<int64_t>(g, kMaxGrid);
+    int64_t g = (act_pairs(c) + 4 * kBlock - 1) / (4 * kBlock);
+    const int64_t cap = c->opt_vgrid > 0 ? c->opt_vgrid : 1024;
+    g = std::min<int64_t>(g, std::min<int64_t>(cap, kMaxGrid));
     return (int)std::max<int64_t>(g, 1);
 }
 
@@ -160,7 +176,8 @@ bool use_nt(const kfsp_ctx *c)
     if (c->opt_nt >= 0) return c->opt_nt != 0;
     // stream the generator around the caches only when it cannot stay in the
     // 256 MiB Infinity Cache between two products anyway
-    return (double)c->slots * 12.0 > 192.0 * 1024 * 1024;
+    const double bytes = c->use_dia ? (double)c->nd * c->dia_ld * 8.0 : (double)c->slots * 12.0;
+    return bytes > 192.0 * 1024 * 1024;
 }
 
 double *next_partial(kfsp_ctx *c)
@@ -175,6 +192,21 @@ SellDev sell_of(const kfsp_ctx *c)
     return SellDev{c->nloc, c->nchunks, c->d_off.p, c->d_col.p, c->d_val.p, c->d_diag.p};
 }
 
+// generator part of the product kernel's arguments
+void set_matrix_args(const kfsp_ctx *c, SpmvArgs &a)
+{
+    a.A = sell_of(c);
+    a.D.nd = c->nd;
+    for (int d = 0; d < kMaxDiag; ++d) a.D.delta[d] = c->delta[d];
+    a.D.val = c->d_dia.p;
+    a.D.ld = c->dia_ld;
+    a.D.diag = c->d_diag.p;
+    a.D.nchunks = c->nchunks;
+    a.D.n = c->n;
+    a.udot2 = nullptr;
+    a.partial2 = nullptr;
+}
+
 // Make block partials a scalar every rank agrees on.
 int publish(kfsp_ctx *ctx, Pending local, Pending *out)
 {
@@ -187,6 +219,22 @@ int publish(kfsp_ctx *ctx, Pending local, Pending *out)
     launch_finalize(local, st, nullptr, ctx->stream);
     NCCL_TRY(ncclAllReduce(st, st, 1, ncclDouble, ncclSum, ctx->comm, ctx->stream));
     *out = Pending{st, 1};
+    return 0;
+}
+
+// Several scalars at once: one all-reduce for all of them.
+int publish_n(kfsp_ctx *ctx, const Pending *local, int k, Pending *out)
+{
+    if (ctx->nranks == 1) {
+        for (int i = 0; i < k; ++i) out[i] = local[i];
+        return 0;
+    }
+    if (ctx->stage_rr + k > kNumStage) ctx->stage_rr = 0;
+    double *st = ctx->d_stage.p + ctx->stage_rr;
+    ctx->stage_rr = (ctx->stage_rr + k) % kNumStage;
+    for (int i = 0; i < k; ++i) launch_finalize(local[i], st + i, nullptr, ctx->stream);
+    NCCL_TRY(ncclAllReduce(st, st, (size_t)k, ncclDouble, ncclSum, ctx->comm, ctx->stream));
+    for (int i = 0; i < k; ++i) out[i] = Pending{st + i, 1};
     return 0;
 }
 
@@ -280,6 +328,52 @@ int upload_sell(kfsp_ctx *ctx, const HostSell &S)
     if (!S.diag.empty())
         HIP_TRY(hipMemcpyAsync(ctx->d_diag.p, S.diag.data(), S.diag.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// Banded form: accepted when the local rows use at most kMaxDiag distinct
+// column offsets and the diagonals are reasonably full.
+int maybe_upload_dia(kfsp_ctx *ctx, const HostSell &S, const std::vector<int32_t> &cnt)
+{
+    ctx->use_dia = false;
+    ctx->nd = 0;
+    if (ctx->opt_format == 1 || ctx->nloc == 0) return 0;
+    const int64_t nloc = ctx->nloc, row0 = ctx->row0;
+    int nd = 0;
+    int64_t delta[kMaxDiag];
+    int64_t nnz_off = 0;
+    for (int64_t r = 0; r < nloc; ++r) {
+        const int64_t c = r / kChunk, l = r % kChunk, o = S.off[(size_t)c];
+        for (int k = 0; k < cnt[(size_t)r]; ++k) {
+            const int64_t dl = (int64_t)S.col[(size_t)(o + (int64_t)k * kChunk + l)] - (row0 + r);
+            int d = 0;
+            while (d < nd && delta[d] != dl) ++d;
+            if (d == nd) {
+                if (nd == kMaxDiag) return 0;
+                delta[nd++] = dl;
+            }
+            ++nnz_off;
+        }
+    }
+    if (nd == 0 || (double)nd * (double)nloc > 1.25 * (double)nnz_off + 1024.0) return 0;
+    std::sort(delta, delta + nd);
+    const int64_t ld = ctx->nchunks * kChunk;
+    std::vector<double> val((size_t)nd * (size_t)ld, 0.0);
+    for (int64_t r = 0; r < nloc; ++r) {
+        const int64_t c = r / kChunk, l = r % kChunk, o = S.off[(size_t)c];
+        for (int k = 0; k < cnt[(size_t)r]; ++k) {
+            const size_t pos = (size_t)(o + (int64_t)k * kChunk + l);
+            const int64_t dl = (int64_t)S.col[pos] - (row0 + r);
+            const int d = (int)(std::lower_bound(delta, delta + nd, dl) - delta);
+            val[(size_t)d * (size_t)ld + (size_t)r] += S.val[pos];
+        }
+    }
+    HIP_TRY(ctx->d_dia.reserve(val.size(), false));
+    HIP_TRY(hipMemcpy(ctx->d_dia.p, val.data(), val.size() * sizeof(double), hipMemcpyHostToDevice));
+    ctx->nd = nd;
+    ctx->dia_ld = ld;
+    for (int d = 0; d < nd; ++d) ctx->delta[d] = (int32_t)delta[d];
+    ctx->use_dia = true;
     return 0;
 }
 
@@ -468,6 +562,7 @@ int kfsp_create(int device, kfsp_ctx **out)
     HIP_TRY(ctx->d_stage.reserve(kNumStage, true));
     HIP_TRY(ctx->d_H.reserve((size_t)kMH * kMH + 2, true));
     HIP_TRY(ctx->d_sq.reserve(kMH + 2, true));
+    HIP_TRY(ctx->d_g.reserve(kMH + 2, true));
     HIP_TRY(ctx->d_y.reserve(kMH, true));
     HIP_TRY(ctx->d_flag.reserve(4, true));
     ctx->h_H.assign((size_t)kMH * kMH + 2, 0.0);
@@ -485,7 +580,7 @@ int kfsp_destroy(kfsp_ctx *ctx)
     ctx->d_rowptr.release(); ctx->d_ccol.release(); ctx->d_cval.release(); ctx->d_tile.release();
     ctx->d_V.release(); ctx->d_w.release(); ctx->d_xg.release(); ctx->d_tmp.release();
     ctx->d_part.release(); ctx->d_stage.release(); ctx->d_H.release(); ctx->d_sq.release();
-    ctx->d_y.release(); ctx->d_flag.release();
+    ctx->d_y.release(); ctx->d_flag.release(); ctx->d_g.release(); ctx->d_dia.release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -601,6 +696,7 @@ int kfsp_set_matrix_ell(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, const 
     for (int64_t r = 0; r < nloc; ++r) S.diag[(size_t)r] = diag[(size_t)(row0 + r)];
     S.nnz = nnz;
     if (int rc = upload_sell(ctx, S)) return rc;
+    if (int rc = maybe_upload_dia(ctx, S, cnt)) return rc;
     ctx->have_csr = false;
     if (ctx->want_csr)
         if (int rc = upload_csr_from_sell(ctx, S, cnt)) return rc;
@@ -651,6 +747,7 @@ int kfsp_set_matrix_csr(kfsp_ctx *ctx, int64_t n, int64_t row0, int64_t nrows, c
     }
     S.nnz = rowptr[nloc];
     if (int rc = upload_sell(ctx, S)) return rc;
+    if (int rc = maybe_upload_dia(ctx, S, cnt)) return rc;
     ctx->have_csr = false;
     if (ctx->want_csr)
         if (int rc = upload_csr_from_sell(ctx, S, cnt)) return rc;
@@ -662,7 +759,7 @@ int kfsp_matrix_info(const kfsp_ctx *ctx, int64_t *nrows, int64_t *slots, int64_
 {
     if (!ctx) return -1;
     if (nrows) *nrows = ctx->nloc;
-    if (slots) *slots = ctx->slots;
+    if (slots) *slots = ctx->use_dia ? (int64_t)ctx->nd * ctx->dia_ld : ctx->slots;
     if (nnz) *nnz = ctx->nnz;
     return 0;
 }
@@ -743,7 +840,11 @@ int kfsp_arnoldi(kfsp_ctx *ctx, int m, int jold, int qiop, double break_tol, dou
     // entries this pass will not write must not look like a breakdown
     HIP_TRY(hipMemsetAsync(Hd, 0, (size_t)kMH * kMH * sizeof(double), st));
 
+    const bool dia = ctx->use_dia;
+    const bool fused = (qiop == 2) && ctx->opt_fused != 0;
+    double *gfin = ctx->d_g.p;
     Pending pend_sq{sq + jold, 1};
+    Pending pend_g{gfin + jold, 1};      // u_jold . u_{jold-1}, finished by the pass that built column jold
     for (int j = jold; j <= m; ++j) {
         const double *src = V + (size_t)(j - 1) * ldv;
         double *dst = V + (size_t)j * ldv;
@@ -751,18 +852,58 @@ int kfsp_arnoldi(kfsp_ctx *ctx, int m, int jold, int qiop, double break_tol, dou
         if (int rc = gather_source(ctx, src, &xg)) return rc;
         const int istart = (qiop > 0) ? std::max(1, j - qiop + 1) : 1;
         SpmvArgs a;
-        a.A = sell_of(ctx);
+        set_matrix_args(ctx, a);
         a.xg = xg;
         a.row0 = ctx->nranks == 1 ? 0 : ctx->row0;
         a.y = dst;
         a.sq = pend_sq;
         a.sq_final = sq + j;
         a.h_sub = (j > jold) ? Hd + (size_t)(j - 2) * kMH + (j - 1) : nullptr;   // H(j,j-1)
-        a.udot = V + (size_t)(istart - 1) * ldv;
-        a.partial = next_partial(ctx);
         a.break_tol = (j > jold) ? break_tol : -1.0;
         a.brk_flag = flag;
-        launch_spmv(1, gs, a, nt, st);
+        if (fused) {
+            // one product kernel with both dot products, one update kernel
+            const bool two = j >= 2;
+            a.udot = two ? V + (size_t)(j - 2) * ldv : src;      // u_{j-1} (or u_1 for the first column)
+            a.partial = next_partial(ctx);
+            a.udot2 = two ? src : nullptr;                        // u_j
+            a.partial2 = two ? next_partial(ctx) : nullptr;
+            launch_spmv(two ? 3 : 1, gs, a, nt, dia, st);
+            Pending loc[3], pub[3];
+            int k = 0;
+            loc[k++] = Pending{a.partial, gs};
+            if (two) {
+                loc[k++] = Pending{a.partial2, gs};
+                loc[k++] = pend_g;
+            }
+            // pend_g is already global (finished or all-reduced); publish the new ones only
+            if (int rc = publish_n(ctx, loc, two ? 2 : 1, pub)) return rc;
+            Ortho2Args o;
+            o.npairs = act_pairs(ctx);
+            o.w = dst;
+            o.u1 = two ? V + (size_t)(j - 2) * ldv : nullptr;
+            o.u2 = src;
+            o.a = two ? pub[0] : Pending{nullptr, 0};
+            o.b = two ? pub[1] : pub[0];
+            o.g = two ? pend_g : Pending{nullptr, 0};
+            o.sq1 = two ? sq + (j - 1) : nullptr;
+            o.sq2 = sq + j;
+            o.partial_sq = next_partial(ctx);
+            o.partial_g = next_partial(ctx);
+            o.h1_out = two ? Hd + (size_t)(j - 1) * kMH + (j - 2) : nullptr;   // H(j-1,j)
+            o.h2_out = Hd + (size_t)(j - 1) * kMH + (j - 1);                   // H(j,j)
+            o.g_final = two ? gfin + j : nullptr;
+            o.brk_flag = flag;
+            launch_ortho2(gv, o, st);
+            Pending loc2[2] = {Pending{o.partial_sq, gv}, Pending{o.partial_g, gv}}, pub2[2];
+            if (int rc = publish_n(ctx, loc2, 2, pub2)) return rc;
+            pend_sq = pub2[0];
+            pend_g = pub2[1];
+            continue;
+        }
+        a.udot = V + (size_t)(istart - 1) * ldv;
+        a.partial = next_partial(ctx);
+        launch_spmv(1, gs, a, nt, dia, st);
         Pending pend;
         if (int rc = publish(ctx, Pending{a.partial, gs}, &pend)) return rc;
         for (int i = istart; i <= j; ++i) {
@@ -790,7 +931,7 @@ int kfsp_arnoldi(kfsp_ctx *ctx, int m, int jold, int qiop, double break_tol, dou
         const double *xg = nullptr;
         if (int rc = gather_source(ctx, src, &xg)) return rc;
         SpmvArgs a;
-        a.A = sell_of(ctx);
+        set_matrix_args(ctx, a);
         a.xg = xg;
         a.row0 = ctx->nranks == 1 ? 0 : ctx->row0;
         a.y = V + (size_t)jl * ldv;
@@ -801,10 +942,13 @@ int kfsp_arnoldi(kfsp_ctx *ctx, int m, int jold, int qiop, double break_tol, dou
         a.partial = next_partial(ctx);
         a.break_tol = looped ? break_tol : -1.0;
         a.brk_flag = flag;
-        launch_spmv(2, gs, a, nt, st);
+        launch_spmv(2, gs, a, nt, dia, st);
         Pending pend;
         if (int rc = publish(ctx, Pending{a.partial, gs}, &pend)) return rc;
         launch_finalize(pend, Hd + (size_t)kMH * kMH, Hd + (size_t)kMH * kMH + 1, st);
+        // u_{m+1} . u_m for a later restart at column m+1 is never needed (a
+        // restart resumes at jold <= m), but finish it so that gfin stays final
+        if (fused && looped) launch_finalize(pend_g, gfin + (m + 1), nullptr, st);
     }
     HIP_TRY(hipMemcpyAsync(ctx->h_H.data(), Hd, ((size_t)kMH * kMH + 2) * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -849,7 +993,8 @@ int kfsp_combine(kfsp_ctx *ctx, int mx, double beta, const double *y, double *ws
     a.y = ctx->d_y.p;
     a.w = ctx->d_w.p;
     a.partial = next_partial(ctx);
-    const int g = vec_grid(ctx);
+    // one pair per lane: each lane already streams mx columns
+    const int g = (int)std::max<int64_t>(1, std::min<int64_t>(kMaxGrid, (act_pairs(ctx) + kBlock - 1) / kBlock));
     launch_combine(g, a, st);
     Pending s;
     if (int rc = publish(ctx, Pending{a.partial, g}, &s)) return rc;
@@ -870,13 +1015,14 @@ int kfsp_restore_w(kfsp_ctx *ctx, double beta)
     return 0;
 }
 
-static int spmv_plain(kfsp_ctx *ctx, const double *src_local_or_full, bool src_is_full, double *y_dev)
+static int spmv_plain(kfsp_ctx *ctx, const double *src_local_or_full, bool src_is_full, double *y_dev,
+                      bool force_sell = false)
 {
     const double *xg = src_local_or_full;
     if (!src_is_full)
         if (int rc = gather_source(ctx, src_local_or_full, &xg)) return rc;
     SpmvArgs a;
-    a.A = sell_of(ctx);
+    set_matrix_args(ctx, a);
     a.xg = xg;
     a.row0 = (ctx->nranks == 1) ? 0 : ctx->row0;
     a.y = y_dev;
@@ -887,7 +1033,7 @@ static int spmv_plain(kfsp_ctx *ctx, const double *src_local_or_full, bool src_i
     a.partial = nullptr;
     a.break_tol = -1.0;
     a.brk_flag = ctx->d_flag.p;
-    launch_spmv(0, spmv_grid(ctx), a, use_nt(ctx), ctx->stream);
+    launch_spmv(0, spmv_grid(ctx), a, use_nt(ctx), ctx->use_dia && !force_sell, ctx->stream);
     return 0;
 }
 
@@ -1001,7 +1147,7 @@ int kfsp_spmv_bench(kfsp_ctx *ctx, int reps, int variant, float *ms_total)
     if (!ctx) return -1;
     if (ctx->ldv == 0) return fail(ctx, -1, "no matrix set");
     if (reps < 1) return fail(ctx, -2, "reps < 1");
-    if (variant < 0 || variant > 1) return fail(ctx, -3, "unknown variant");
+    if (variant < 0 || variant > 2) return fail(ctx, -3, "unknown variant (0 auto, 1 CSR-stream, 2 SELL)");
     if (variant == 1 && !ctx->have_csr) return fail(ctx, -3, "CSR variant needs option build_csr=1 before the matrix is set");
     if (!ms_total) return fail(ctx, -4, "null ms_total");
     HIP_TRY(hipSetDevice(ctx->device));
@@ -1010,8 +1156,8 @@ int kfsp_spmv_bench(kfsp_ctx *ctx, int reps, int variant, float *ms_total)
     double *dst = ctx->d_V.p + ctx->ldv;
     HIP_TRY(hipEventRecord(ctx->ev0, st));
     for (int r = 0; r < reps; ++r) {
-        if (variant == 0) {
-            if (int rc = spmv_plain(ctx, src, false, dst)) return rc;
+        if (variant != 1) {
+            if (int rc = spmv_plain(ctx, src, false, dst, variant == 2)) return rc;
         } else {
             const double *xg = nullptr;
             if (int rc = gather_source(ctx, src, &xg)) return rc;
@@ -1069,8 +1215,11 @@ int kfsp_set_option(kfsp_ctx *ctx, const char *name, int64_t value)
     if (!name) return -2;
     const std::string k(name);
     if (k == "grid_blocks") ctx->opt_grid = value;
+    else if (k == "vec_grid_blocks") ctx->opt_vgrid = value;
     else if (k == "nt_loads") ctx->opt_nt = value;
     else if (k == "build_csr") ctx->want_csr = value != 0;
+    else if (k == "format") ctx->opt_format = value;
+    else if (k == "fused_ortho") ctx->opt_fused = value;
     else return fail(ctx, -2, "unknown option");
     return 0;
 }

@@ -31,6 +31,21 @@ struct SellDev {
     const double *diag;  // [nchunks * 64]
 };
 
+// Banded form for state sets whose ordering makes every reaction a constant
+// index shift (lattice boxes in lexicographic order): diagonal d holds
+// val[d*ld + r] = A(r, r + delta[d]); no column indices at all.  Entries that
+// would leave [0, n) are stored as 0 and their x index is clamped.
+constexpr int kMaxDiag = 16;
+struct DiaDev {
+    int nd;
+    int32_t delta[kMaxDiag];
+    const double *val;   // nd x ld
+    int64_t ld;          // >= nchunks * 64
+    const double *diag;
+    int64_t nchunks;
+    int64_t n;           // global number of states (clamp bound)
+};
+
 // Same rows in plain CSR (off-diagonal entries only), for the LDS-staged
 // CSR-stream kernel variant.
 struct CsrDev {
@@ -53,16 +68,37 @@ struct Pending {
 
 struct SpmvArgs {
     SellDev A;
+    DiaDev D;             // used instead of A by the banded kernels
     const double *xg;     // gather source, global indexing
     int64_t row0;         // global index of local row 0
     double *y;            // local rows
     Pending sq;           // squared norm of the source column (modes 1,2)
     double *sq_final;     // where block 0 stores the finished squared norm
     double *h_sub;        // where block 0 stores sqrt of it (H(j,j-1)), may be null
-    const double *udot;   // mode 1: vector of the first dot product
+    const double *udot;   // modes 1,3: vector of the first dot product
     double *partial;      // [gridDim.x] block partials of the fused reduction
+    const double *udot2;  // mode 3: second dot vector
+    double *partial2;
     double break_tol;     // <0: no breakdown test
     int *brk_flag;
+};
+
+// Both Gram-Schmidt updates of an IOP(2) column in one pass.  With
+//   a = u1.w, b = u2.w (from the product kernel), g = u2.u1 (from the previous
+// column's update) the modified Gram-Schmidt coefficients are
+//   h1 = a s1,  h2 = (b - h1 s1 g) s2       [ = v2.(w - h1 v1) ]
+// and w -= h1 s1 u1 + h2 s2 u2; partials: w.w (next norm) and w.u2 (next g).
+struct Ortho2Args {
+    int64_t npairs;
+    double *w;
+    const double *u1;     // u_{j-1}, null for the first column
+    const double *u2;     // u_j
+    Pending a, b, g;
+    const double *sq1, *sq2;
+    double *partial_sq, *partial_g;
+    double *h1_out, *h2_out;
+    double *g_final;      // block 0 stores the finished g (restart needs it)
+    const int *brk_flag;
 };
 
 struct OrthoArgs {
@@ -90,7 +126,8 @@ struct CombineArgs {
 };
 
 // kernel launchers (kfsp_kernels.hip)
-void launch_spmv(int mode, int grid, const SpmvArgs &a, bool nontemporal, hipStream_t s);
+void launch_spmv(int mode, int grid, const SpmvArgs &a, bool nontemporal, bool dia, hipStream_t s);
+void launch_ortho2(int grid, const Ortho2Args &a, hipStream_t s);
 void launch_spmv_csr_stream(int grid, const CsrDev &A, const double *xg, int64_t row0, double *y, hipStream_t s);
 void launch_ortho(int grid, const OrthoArgs &a, hipStream_t s);
 void launch_combine(int grid, const CombineArgs &a, hipStream_t s);

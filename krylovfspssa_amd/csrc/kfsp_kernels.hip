@@ -12,6 +12,7 @@
 //                   DDOT :243, or with the DNRM2 of :263, and with the DSCAL
 //                   :258 of the source column (lazy normalisation)
 //   k_ortho         DAXPY :244 fused with the next DDOT :243 / DNRM2 :247
+//   k_ortho2        both DDOT/DAXPY pairs of an IOP(2) column + DNRM2 in one pass
 //   k_combine       DGEMV :444 + clamp :447-449 + DASUM :450
 //   k_copy_nrm2     DCOPY :176 / v1 = w/beta :223-226 + DNRM2 :177,:540
 #include "kfsp_internal.h"
@@ -40,6 +41,25 @@ __device__ __forceinline__ double block_allreduce_sum(double v, double *red)
     return t;
 }
 
+// Three sums with one barrier pair.  red: 12 doubles of LDS.
+__device__ __forceinline__ void block_allreduce_sum3(double &a, double &b, double &c, double *red)
+{
+    a = wave_allreduce_sum(a);
+    b = wave_allreduce_sum(b);
+    c = wave_allreduce_sum(c);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        red[wave] = a;
+        red[4 + wave] = b;
+        red[8 + wave] = c;
+    }
+    __syncthreads();
+    a = (red[0] + red[1]) + (red[2] + red[3]);
+    b = (red[4] + red[5]) + (red[6] + red[7]);
+    c = (red[8] + red[9]) + (red[10] + red[11]);
+    __syncthreads();
+}
+
 // Finish a Pending scalar: every thread of every block performs the same
 // additions in the same order.
 __device__ __forceinline__ double finish_sum(Pending s, double *red)
@@ -47,6 +67,22 @@ __device__ __forceinline__ double finish_sum(Pending s, double *red)
     double a = 0.0;
     for (int i = threadIdx.x; i < s.n; i += kBlock) a += s.p[i];
     return block_allreduce_sum(a, red);
+}
+
+// Three Pending scalars at once (loads of all three in flight together).
+__device__ __forceinline__ void finish_sum3(Pending p, Pending q, Pending r, double &a, double &b, double &c,
+                                            double *red)
+{
+    a = 0.0;
+    b = 0.0;
+    c = 0.0;
+    const int n = max(p.n, max(q.n, r.n));
+    for (int i = threadIdx.x; i < n; i += kBlock) {
+        if (i < p.n) a += p.p[i];
+        if (i < q.n) b += q.p[i];
+        if (i < r.n) c += r.p[i];
+    }
+    block_allreduce_sum3(a, b, c, red);
 }
 
 template <bool NT>
@@ -64,27 +100,103 @@ __device__ __forceinline__ int32_t ld_stream(const int32_t *p)
 
 // ---------------------------------------------------------------------- SpMV
 //
-// One lane = one row, one wavefront = one SELL chunk, so slot k of a chunk is
-// one 256-B (col) + one 512-B (val) fully used, contiguous read per wave.
+// One lane = one row, one wavefront = one 64-row chunk.
+//   SELL: slot k of a chunk is one contiguous 256-B (col) + 512-B (val) read.
+//   DIA : diagonal d of a chunk is one contiguous 512-B val read; x is read as
+//         the same 64 rows shifted by delta[d] (no index traffic at all).
 // Work distribution is XCD-aware: workgroups b, b+8, b+16.. share an XCD (and
 // its 4 MiB L2), so XCD x sweeps the contiguous chunk range [x*CPX,(x+1)*CPX)
 // with its workgroups advancing as one front; the gathered x window of a front
 // (rows +- the generator's strides) then stays in that XCD's L2 instead of
 // being fetched by all eight.
 //
-// MODE 0: y = A x                      (FMATVEC seam, DROP_STATES, bench)
-// MODE 1: y = s A u ; partial = udot.y (Arnoldi column, s = 1/||u||)
-// MODE 2: y = s A u ; partial = y.y    (the AVNORM product)
-template <int MODE, bool NT>
+// MODE 0: y = A x                           (FMATVEC seam, DROP_STATES, bench)
+// MODE 1: y = s A u ; partial = udot.y      (Arnoldi column, s = 1/||u||)
+// MODE 2: y = s A u ; partial = y.y         (the AVNORM product)
+// MODE 3: y = s A u ; partial = udot.y, partial2 = udot2.y   (IOP(2) column)
+template <bool NT>
+__device__ __forceinline__ double row_sell(const SellDev &A, const double *__restrict__ xg, int64_t row0,
+                                           int64_t c, int lane)
+{
+    const int64_t off = A.off[c];
+    const int w = (int)((A.off[c + 1] - off) >> 6);
+    const int64_t r = (c << 6) + lane;
+    const int32_t *cp = A.col + off + lane;
+    const double *vp = A.val + off + lane;
+    double sum = -ld_stream<NT>(A.diag + r) * xg[row0 + r];
+    int k = 0;
+    for (; k + 4 <= w; k += 4) {
+        const int32_t c0 = ld_stream<NT>(cp + (k + 0) * 64), c1 = ld_stream<NT>(cp + (k + 1) * 64);
+        const int32_t c2 = ld_stream<NT>(cp + (k + 2) * 64), c3 = ld_stream<NT>(cp + (k + 3) * 64);
+        const double v0 = ld_stream<NT>(vp + (k + 0) * 64), v1 = ld_stream<NT>(vp + (k + 1) * 64);
+        const double v2 = ld_stream<NT>(vp + (k + 2) * 64), v3 = ld_stream<NT>(vp + (k + 3) * 64);
+        sum += v0 * xg[c0];
+        sum += v1 * xg[c1];
+        sum += v2 * xg[c2];
+        sum += v3 * xg[c3];
+    }
+    for (; k < w; ++k) sum += ld_stream<NT>(vp + k * 64) * xg[ld_stream<NT>(cp + k * 64)];
+    return sum;
+}
+
+template <bool NT>
+__device__ __forceinline__ double row_dia(const DiaDev &D, const double *__restrict__ xg, int64_t row0,
+                                          int64_t c, int lane)
+{
+    const int64_t r = (c << 6) + lane;
+    const int64_t g = row0 + r;
+    const int64_t last = D.n - 1;
+    const double *vp = D.val + r;
+    double sum = -ld_stream<NT>(D.diag + r) * xg[g < last ? g : last];
+    int d = 0;
+    for (; d + 4 <= D.nd; d += 4) {
+        const double v0 = ld_stream<NT>(vp + (int64_t)(d + 0) * D.ld), v1 = ld_stream<NT>(vp + (int64_t)(d + 1) * D.ld);
+        const double v2 = ld_stream<NT>(vp + (int64_t)(d + 2) * D.ld), v3 = ld_stream<NT>(vp + (int64_t)(d + 3) * D.ld);
+        int64_t i0 = g + D.delta[d + 0], i1 = g + D.delta[d + 1], i2 = g + D.delta[d + 2], i3 = g + D.delta[d + 3];
+        i0 = i0 < 0 ? 0 : (i0 > last ? last : i0);
+        i1 = i1 < 0 ? 0 : (i1 > last ? last : i1);
+        i2 = i2 < 0 ? 0 : (i2 > last ? last : i2);
+        i3 = i3 < 0 ? 0 : (i3 > last ? last : i3);
+        sum += v0 * xg[i0];
+        sum += v1 * xg[i1];
+        sum += v2 * xg[i2];
+        sum += v3 * xg[i3];
+    }
+    for (; d < D.nd; ++d) {
+        int64_t i0 = g + D.delta[d];
+        i0 = i0 < 0 ? 0 : (i0 > last ? last : i0);
+        sum += ld_stream<NT>(vp + (int64_t)d * D.ld) * xg[i0];
+    }
+    return sum;
+}
+
+template <int MODE, bool NT, bool DIA>
 __global__ __launch_bounds__(kBlock) void k_spmv(SpmvArgs a)
 {
-    __shared__ double red[4];
+    __shared__ double red[12];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (MODE != 0) {
+        if (*a.brk_flag) return;
+    }
+
+    const int64_t nchunks = DIA ? a.D.nchunks : a.A.nchunks;
+    const int xcd = blockIdx.x & 7;
+    const int slot = blockIdx.x >> 3;
+    const int bx = gridDim.x >> 3;                        // workgroups per XCD
+    const int64_t cpx = (nchunks + 7) >> 3;
+    const int64_t cbeg = (int64_t)xcd * cpx;
+    const int64_t cend = (cbeg + cpx < nchunks) ? cbeg + cpx : nchunks;
+    const int64_t cstep = (int64_t)bx * 4;
+    int64_t c = cbeg + (int64_t)slot * 4 + wave;
+
+    // The first chunk's row sums are started before the pending norm is
+    // finished: the partial-sum round trip overlaps the first generator loads.
+    double sum = 0.0;
+    if (c < cend) sum = DIA ? row_dia<NT>(a.D, a.xg, a.row0, c, lane) : row_sell<NT>(a.A, a.xg, a.row0, c, lane);
 
     double s = 1.0;
     if (MODE != 0) {
-        if (*a.brk_flag) return;
         const double S = finish_sum(a.sq, red);
         const double nrm = sqrt(S);
         if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -98,56 +210,48 @@ __global__ __launch_bounds__(kBlock) void k_spmv(SpmvArgs a)
         s = 1.0 / nrm;
     }
 
-    const int xcd = blockIdx.x & 7;
-    const int slot = blockIdx.x >> 3;
-    const int bx = gridDim.x >> 3;                        // workgroups per XCD
-    const int64_t cpx = (a.A.nchunks + 7) >> 3;
-    const int64_t cbeg = (int64_t)xcd * cpx;
-    const int64_t cend = (cbeg + cpx < a.A.nchunks) ? cbeg + cpx : a.A.nchunks;
-
-    double acc = 0.0;
-    for (int64_t c = cbeg + (int64_t)slot * 4 + wave; c < cend; c += (int64_t)bx * 4) {
-        const int64_t off = a.A.off[c];
-        const int w = (int)((a.A.off[c + 1] - off) >> 6);
+    double acc = 0.0, acc2 = 0.0;
+    while (c < cend) {
         const int64_t r = (c << 6) + lane;
-        const int32_t *cp = a.A.col + off + lane;
-        const double *vp = a.A.val + off + lane;
-        const double xr = a.xg[a.row0 + r];
-        double sum = -ld_stream<NT>(a.A.diag + r) * xr;
-        int k = 0;
-        for (; k + 4 <= w; k += 4) {
-            const int32_t c0 = ld_stream<NT>(cp + (k + 0) * 64), c1 = ld_stream<NT>(cp + (k + 1) * 64);
-            const int32_t c2 = ld_stream<NT>(cp + (k + 2) * 64), c3 = ld_stream<NT>(cp + (k + 3) * 64);
-            const double v0 = ld_stream<NT>(vp + (k + 0) * 64), v1 = ld_stream<NT>(vp + (k + 1) * 64);
-            const double v2 = ld_stream<NT>(vp + (k + 2) * 64), v3 = ld_stream<NT>(vp + (k + 3) * 64);
-            sum += v0 * a.xg[c0];
-            sum += v1 * a.xg[c1];
-            sum += v2 * a.xg[c2];
-            sum += v3 * a.xg[c3];
-        }
-        for (; k < w; ++k) sum += ld_stream<NT>(vp + k * 64) * a.xg[ld_stream<NT>(cp + k * 64)];
         if (MODE != 0) sum *= s;
         a.y[r] = sum;
-        if (MODE == 1) acc += a.udot[r] * sum;
+        if (MODE == 1 || MODE == 3) acc += a.udot[r] * sum;
         if (MODE == 2) acc += sum * sum;
+        if (MODE == 3) acc2 += a.udot2[r] * sum;
+        c += cstep;
+        if (c < cend) sum = DIA ? row_dia<NT>(a.D, a.xg, a.row0, c, lane) : row_sell<NT>(a.A, a.xg, a.row0, c, lane);
     }
-    if (MODE != 0) {
+    if (MODE == 3) {
+        double dummy = 0.0;
+        block_allreduce_sum3(acc, acc2, dummy, red);
+        if (threadIdx.x == 0) {
+            a.partial[blockIdx.x] = acc;
+            a.partial2[blockIdx.x] = acc2;
+        }
+    } else if (MODE != 0) {
         const double t = block_allreduce_sum(acc, red);
         if (threadIdx.x == 0) a.partial[blockIdx.x] = t;
     }
 }
 
-void launch_spmv(int mode, int grid, const SpmvArgs &a, bool nt, hipStream_t st)
+template <bool NT, bool DIA>
+static void launch_spmv_mode(int mode, dim3 g, dim3 b, const SpmvArgs &a, hipStream_t st)
+{
+    if (mode == 0) hipLaunchKernelGGL((k_spmv<0, NT, DIA>), g, b, 0, st, a);
+    else if (mode == 1) hipLaunchKernelGGL((k_spmv<1, NT, DIA>), g, b, 0, st, a);
+    else if (mode == 2) hipLaunchKernelGGL((k_spmv<2, NT, DIA>), g, b, 0, st, a);
+    else hipLaunchKernelGGL((k_spmv<3, NT, DIA>), g, b, 0, st, a);
+}
+
+void launch_spmv(int mode, int grid, const SpmvArgs &a, bool nt, bool dia, hipStream_t st)
 {
     dim3 g(grid), b(kBlock);
     if (nt) {
-        if (mode == 0) hipLaunchKernelGGL((k_spmv<0, true>), g, b, 0, st, a);
-        else if (mode == 1) hipLaunchKernelGGL((k_spmv<1, true>), g, b, 0, st, a);
-        else hipLaunchKernelGGL((k_spmv<2, true>), g, b, 0, st, a);
+        if (dia) launch_spmv_mode<true, true>(mode, g, b, a, st);
+        else launch_spmv_mode<true, false>(mode, g, b, a, st);
     } else {
-        if (mode == 0) hipLaunchKernelGGL((k_spmv<0, false>), g, b, 0, st, a);
-        else if (mode == 1) hipLaunchKernelGGL((k_spmv<1, false>), g, b, 0, st, a);
-        else hipLaunchKernelGGL((k_spmv<2, false>), g, b, 0, st, a);
+        if (dia) launch_spmv_mode<false, true>(mode, g, b, a, st);
+        else launch_spmv_mode<false, false>(mode, g, b, a, st);
     }
 }
 
@@ -219,6 +323,83 @@ __global__ __launch_bounds__(kBlock) void k_ortho(OrthoArgs a)
 void launch_ortho(int grid, const OrthoArgs &a, hipStream_t st)
 {
     hipLaunchKernelGGL(k_ortho, dim3(grid), dim3(kBlock), 0, st, a);
+}
+
+// both updates of an IOP(2) column in one pass (see Ortho2Args)
+__global__ __launch_bounds__(kBlock) void k_ortho2(Ortho2Args a)
+{
+    __shared__ double red[12];
+    if (*a.brk_flag) return;
+    double2 *w2 = reinterpret_cast<double2 *>(a.w);
+    const double2 *p1 = reinterpret_cast<const double2 *>(a.u1);
+    const double2 *p2 = reinterpret_cast<const double2 *>(a.u2);
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    // first trip's operands are requested before the scalars are finished, so
+    // the partial-sum round trip overlaps the first vector loads
+    const bool have0 = i < a.npairs, have1 = i + stride < a.npairs;
+    const double2 zero = make_double2(0.0, 0.0);
+    double2 wa = have0 ? w2[i] : zero, wb = have1 ? w2[i + stride] : zero;
+    double2 ya = have0 ? p2[i] : zero, yb = have1 ? p2[i + stride] : zero;
+    double2 xa = zero, xb = zero;
+    if (p1) {
+        xa = have0 ? p1[i] : zero;
+        xb = have1 ? p1[i + stride] : zero;
+    }
+
+    const double s2 = 1.0 / sqrt(*a.sq2);
+    double c1 = 0.0, h1 = 0.0, h2;
+    if (a.u1) {
+        const double s1 = 1.0 / sqrt(*a.sq1);
+        double sa, sb, g;
+        finish_sum3(a.a, a.b, a.g, sa, sb, g, red);
+        h1 = sa * s1;
+        c1 = h1 * s1;
+        h2 = (sb - c1 * g) * s2;
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            *a.h1_out = h1;
+            if (a.g_final) *a.g_final = g;
+        }
+    } else {
+        h2 = finish_sum(a.b, red) * s2;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *a.h2_out = h2;
+    const double c2 = h2 * s2;
+    double asq = 0.0, ag = 0.0;
+    for (;;) {
+        wa.x -= c1 * xa.x; wa.y -= c1 * xa.y;
+        wb.x -= c1 * xb.x; wb.y -= c1 * xb.y;
+        wa.x -= c2 * ya.x; wa.y -= c2 * ya.y;
+        wb.x -= c2 * yb.x; wb.y -= c2 * yb.y;
+        if (have0) w2[i] = wa;
+        if (i + stride < a.npairs) w2[i + stride] = wb;
+        asq += wa.x * wa.x; asq += wa.y * wa.y;
+        asq += wb.x * wb.x; asq += wb.y * wb.y;
+        ag += wa.x * ya.x; ag += wa.y * ya.y;
+        ag += wb.x * yb.x; ag += wb.y * yb.y;
+        i += 2 * stride;
+        if (i >= a.npairs) break;
+        const bool h1b = i + stride < a.npairs;
+        wa = w2[i];
+        ya = p2[i];
+        wb = h1b ? w2[i + stride] : zero;
+        yb = h1b ? p2[i + stride] : zero;
+        if (p1) {
+            xa = p1[i];
+            xb = h1b ? p1[i + stride] : zero;
+        }
+    }
+    double dummy = 0.0;
+    block_allreduce_sum3(asq, ag, dummy, red);
+    if (threadIdx.x == 0) {
+        a.partial_sq[blockIdx.x] = asq;
+        a.partial_g[blockIdx.x] = ag;
+    }
+}
+
+void launch_ortho2(int grid, const Ortho2Args &a, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_ortho2, dim3(grid), dim3(kBlock), 0, st, a);
 }
 
 // ------------------------------------------------------------------ combine

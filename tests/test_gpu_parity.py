@@ -303,3 +303,46 @@ def test_adaptive_solver_reports_needed_expansion(ctx, golden_dir):
     rc, st, log = ctx.dgexpv(1000.0, 1e-4, 1e-10, int(g["nr"]))
     assert rc == 10
     assert any(ev == 6 for ev, _ in log)
+
+
+# ------------------------------------------------------- formats and fused variants
+
+@pytest.mark.parametrize("opts", [dict(format=0, fused_ortho=1), dict(format=1, fused_ortho=1),
+                                  dict(format=0, fused_ortho=0), dict(format=1, fused_ortho=0)])
+def test_generator_formats_and_ortho_variants_agree_with_oracle(oracle, opts):
+    """Banded (DIA) vs SELL-64 generator kernels and the one-pass vs two-pass
+    IOP(2) orthogonalisation: every combination within the same tolerances."""
+    from krylovfspssa_amd import KfspContext, synth
+    mdl = synth.repressilator(dims=(37, 29, 23))
+    adj, off, diag = mdl.ell()
+    A = oracle.EllMatrix(adj, off, diag)
+    p0 = synth.poisson_p0(mdl, 9.0)
+    with KfspContext(0) as c:
+        for k, v in opts.items():
+            c.set_option(k, v)
+        c.set_matrix_ell(adj, off, diag)
+        info = c.matrix_info()
+        nact = -(-mdl.n // 64) * 64
+        assert info["slots"] == (6 * nact if opts["format"] == 0 else info["slots"])
+        x = np.random.default_rng(1).random(mdl.n)
+        y = c.spmv(x)
+        ref = oracle.spmv_ell(A, x)
+        assert np.abs(y - ref).max() <= 1e-13 * np.abs(oracle.spmv_ell(oracle.EllMatrix(adj, np.abs(off), -np.abs(diag)), x)).max()
+        c.set_vector(p0)
+        beta = c.begin_step()
+        H, mb, k1, av = c.arnoldi(25)
+        V, Href, _, _, avr = oracle.arnoldi(A, p0 / beta, 25)
+        assert np.abs(H - Href).max() <= 1e-11 * np.abs(Href).max()
+        assert av == pytest.approx(avr, rel=1e-10)
+        assert np.abs(c.get_basis(26) - V[:, 25]).max() < 1e-10
+        # dimension-change restart through the fused path
+        H2 = np.zeros((32, 32), order="F")
+        H2[:26, :25] = H[:26, :25]
+        H2, *_ = c.arnoldi(30, jold=25, H=H2)
+        _, Href2, *_ = oracle.arnoldi(A, p0 / beta, 30)
+        assert np.abs(H2 - Href2).max() <= 1e-11 * np.abs(Href2).max()
+        c.set_vector(p0)
+        ws = c.expv_fixed(30, 0.004, 3)
+        w = c.get_vector()
+    wref, wsref = oracle.expv_fixed(A, p0, 30, 0.004, 3)
+    assert np.abs(w - wref).sum() < 1e-10 and np.abs(ws - wsref).max() < 1e-12
