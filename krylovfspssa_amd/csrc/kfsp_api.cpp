@@ -1,10 +1,7 @@
 // Host side of libkfsp_hip: the C ABI of include/kfsp.h, the device context
 // (basis, vectors, generator, scalar staging), the ELL -> SELL transpose, the
 // RCCL row-partition plumbing and the host Pade exponential.
-#include "../../include/kfsp.h"
-#include "kfsp_internal.h"
-
-#include <rccl/rccl.h>
+#include "kfsp_ctx.h"
 
 #include <algorithm>
 #include <chrono>
@@ -18,99 +15,8 @@ using namespace kfsp;
 namespace {
 
 constexpr int kAbiVersion = 1;
-constexpr int kNumPartial = 4;   // rotating block-partial buffers
-constexpr int kNumStage = 8;     // rotating all-reduce staging scalars
-
-template <class T>
-struct DevBuf {
-    T *p = nullptr;
-    size_t cap = 0;
-    hipError_t reserve(size_t n, bool zero)
-    {
-        if (n <= cap) return hipSuccess;
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), n * sizeof(T));
-        if (e != hipSuccess) return e;
-        cap = n;
-        if (zero) e = hipMemset(p, 0, n * sizeof(T));
-        return e;
-    }
-    void release()
-    {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-    }
-};
-
-inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 
 }  // namespace
-
-struct kfsp_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    std::string err;
-
-    // partition
-    int nranks = 1, rank = 0;
-    ncclComm_t comm = nullptr;
-
-    // sizes
-    int64_t n = 0;        // global states
-    int64_t L = 0;        // rows per rank (padded block length), multiple of 64
-    int64_t row0 = 0;     // first global row of this rank
-    int64_t nloc = 0;     // rows owned
-    int64_t ldv = 0;      // column stride of the basis, multiple of 256
-
-    // generator
-    DevBuf<int64_t> d_off;
-    DevBuf<int32_t> d_col;
-    DevBuf<double> d_val, d_diag;
-    int64_t nchunks = 0, slots = 0, nnz = 0;
-    // banded (DIA) form, used instead of SELL when the rows allow it
-    DevBuf<double> d_dia;
-    bool use_dia = false;
-    int nd = 0;
-    int32_t delta[kMaxDiag] = {0};
-    int64_t dia_ld = 0;
-    // optional CSR copy for the CSR-stream kernel variant
-    DevBuf<int64_t> d_rowptr;
-    DevBuf<int32_t> d_ccol, d_tile;
-    DevBuf<double> d_cval;
-    int64_t ntiles = 0;
-    bool want_csr = false, have_csr = false;
-
-    // vectors
-    DevBuf<double> d_V;    // (kMMax+2) columns, stride ldv, unnormalised basis
-    DevBuf<double> d_w;    // probability vector, ldv
-    DevBuf<double> d_xg;   // nranks*L gathered source (nranks > 1) or scratch x (kfsp_spmv)
-    DevBuf<double> d_tmp;  // ldv scratch (kfsp_spmv output)
-
-    // scalars
-    DevBuf<double> d_part;   // kNumPartial * kMaxGrid
-    DevBuf<double> d_stage;  // kNumStage
-    DevBuf<double> d_H;      // kMH * kMH image + 2 (avnorm^2, avnorm)
-    DevBuf<double> d_sq;     // finished squared norms, index = column (1-based)
-    DevBuf<double> d_g;      // finished u_j . u_{j-1}, index = j
-    DevBuf<double> d_y;      // kMH coefficients
-    DevBuf<int> d_flag;
-    int part_rr = 0, stage_rr = 0;
-    std::vector<double> h_H;
-    double avnorm_last = 0.0;
-
-    // options
-    int64_t opt_grid = 0;   // cap on the product kernels' grid, 0 = auto (2048)
-    int64_t opt_vgrid = 0;  // cap on the streaming kernels' grid, 0 = auto (1024)
-    int64_t opt_nt = -1;    // -1 auto, 0 off, 1 on
-    int64_t opt_format = 0; // 0 auto (DIA when banded), 1 always SELL
-    int64_t opt_fused = 1;  // 1: one-pass IOP(2) orthogonalisation (k_ortho2)
-    bool timers = false;
-    double t_ms[KFSP_T_COUNT] = {0, 0, 0, 0, 0, 0};
-};
 
 namespace {
 
@@ -328,6 +234,7 @@ int upload_sell(kfsp_ctx *ctx, const HostSell &S)
     if (!S.diag.empty())
         HIP_TRY(hipMemcpyAsync(ctx->d_diag.p, S.diag.data(), S.diag.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->have_sell = true;
     return 0;
 }
 
@@ -581,6 +488,8 @@ int kfsp_destroy(kfsp_ctx *ctx)
     ctx->d_V.release(); ctx->d_w.release(); ctx->d_xg.release(); ctx->d_tmp.release();
     ctx->d_part.release(); ctx->d_stage.release(); ctx->d_H.release(); ctx->d_sq.release();
     ctx->d_y.release(); ctx->d_flag.release(); ctx->d_g.release(); ctx->d_dia.release();
+    ctx->d_ell_adj.release(); ctx->d_ell_off.release(); ctx->d_ell_diag.release(); ctx->d_cnt.release();
+    ctx->d_ticket.release(); ctx->d_slot.release(); ctx->d_scan.release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -659,6 +568,15 @@ int kfsp_set_matrix_ell(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, const 
     if (int rc = resize(ctx, n)) return rc;
     const int64_t row0 = ctx->row0, nloc = ctx->nloc;
 
+    if (!ctx->opt_host_build && !ctx->want_csr) {
+        // the arrays go to HBM verbatim and are transposed there (kfsp_build.hip)
+        const int rc = build_from_ell_device(ctx, n, bw, ld, adj, offdiag, diag);
+        ctx->have_csr = false;
+        ctx->t_ms[KFSP_T_UPLOAD] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return rc;
+    }
+
+    // host transpose (kept for A/B checks of the device build and for the CSR copy)
     // in-degree of every local row
     std::vector<int32_t> cnt((size_t)std::max<int64_t>(nloc, 1), 0);
     for (int64_t i = 0; i < n; ++i) {
@@ -1149,6 +1067,7 @@ int kfsp_spmv_bench(kfsp_ctx *ctx, int reps, int variant, float *ms_total)
     if (reps < 1) return fail(ctx, -2, "reps < 1");
     if (variant < 0 || variant > 2) return fail(ctx, -3, "unknown variant (0 auto, 1 CSR-stream, 2 SELL)");
     if (variant == 1 && !ctx->have_csr) return fail(ctx, -3, "CSR variant needs option build_csr=1 before the matrix is set");
+    if (variant == 2 && !ctx->have_sell) return fail(ctx, -3, "no SELL image resident (banded matrix built on the device)");
     if (!ms_total) return fail(ctx, -4, "null ms_total");
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
@@ -1220,6 +1139,7 @@ int kfsp_set_option(kfsp_ctx *ctx, const char *name, int64_t value)
     else if (k == "build_csr") ctx->want_csr = value != 0;
     else if (k == "format") ctx->opt_format = value;
     else if (k == "fused_ortho") ctx->opt_fused = value;
+    else if (k == "host_build") ctx->opt_host_build = value;
     else return fail(ctx, -2, "unknown option");
     return 0;
 }

@@ -1,0 +1,342 @@
+// Generator maintenance on the device: the reference's column-oriented arrays
+// (ADJ / OFFDIAG / DIAG of TYPE FSP_MATRIX, StateSpace.f90:13-17) are copied to
+// HBM as they are and turned into the row-gather forms the product kernel reads
+// - banded (DIA) when every reaction is a constant index shift, SELL-64
+// otherwise - without touching the host again.  This is what runs after every
+// MATRIX_STARTER / ONESTEP_EXTENDER / SSA_EXTENDER / DROP_STATES
+// (KrylovSolver.f90:130-134, 511, 528-529), i.e. between most time steps of an
+// adaptive solve, so it must cost milliseconds, not a host pass over nnz.
+//
+// SELL build = histogram of targets (integer atomics), per-chunk widths, one
+// block-wide exclusive scan, scatter with per-row slot tickets, and a per-row
+// sort by source index that makes the layout deterministic and identical to the
+// order in which FMATVEC accumulates (KrylovSolver.f90:598-604).
+#include "kfsp_ctx.h"
+
+#include <algorithm>
+#include <chrono>
+#include <climits>
+
+namespace kfsp {
+
+namespace {
+
+constexpr int kMaxBw = 64;
+
+struct ScanOut {            // device scratch, one instance
+    int dmin[kMaxBw];       // per slot: min / max of (target - source) over valid links
+    int dmax[kMaxBw];
+    unsigned long long dcount[kMaxBw];   // valid links with the target in this rank's rows
+    unsigned long long nnz_off;          // off-diagonal entries of the local rows
+    int bad;                // an ADJ entry exceeded n
+};
+
+__device__ __forceinline__ int wave_min_i(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_max_i(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// one lane per source state: link statistics per slot + in-degree of local rows
+__global__ __launch_bounds__(kBlock) void k_ell_scan(int64_t n, int bw, int ld, const int32_t *__restrict__ adj,
+                                                     int64_t row0, int64_t nloc, int32_t *__restrict__ cnt,
+                                                     ScanOut *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool live = i < n;
+    for (int j = 0; j < bw; ++j) {
+        const int k = live ? adj[i * ld + j] : 0;
+        if (k > n) out->bad = 1;
+        const bool valid = k >= 1 && k <= n;
+        const int64_t r = (int64_t)k - 1 - row0;
+        const bool local = valid && r >= 0 && r < nloc;
+        if (local) atomicAdd(&cnt[r], 1);
+        const int d = (int)((int64_t)k - 1 - i);
+        const int lo = wave_min_i(valid ? d : INT_MAX);
+        const int hi = wave_max_i(valid ? d : INT_MIN);
+        const unsigned long long m = __ballot(local);
+        if ((threadIdx.x & 63) == 0) {
+            if (lo != INT_MAX) {
+                atomicMin(&out->dmin[j], lo);
+                atomicMax(&out->dmax[j], hi);
+            }
+            if (m) {
+                atomicAdd(&out->dcount[j], (unsigned long long)__popcll(m));
+                atomicAdd(&out->nnz_off, (unsigned long long)__popcll(m));
+            }
+        }
+    }
+}
+
+// banded form: diagonal d is slot slot_of[d]; row r reads source r - shift
+__global__ __launch_bounds__(kBlock) void k_ell_to_dia(int64_t n, int ld, const int32_t *__restrict__ adj,
+                                                       const double *__restrict__ off,
+                                                       const double *__restrict__ diag_in, int64_t row0, int64_t nloc,
+                                                       int nd, DiaDev D, const int *__restrict__ slot_of,
+                                                       double *__restrict__ val, double *__restrict__ diag_out)
+{
+    const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= D.ld) return;
+    const bool live = r < nloc;
+    const int64_t g = row0 + r;
+    for (int d = 0; d < nd; ++d) {
+        double v = 0.0;
+        if (live) {
+            const int64_t src = g + D.delta[d];            // delta = source - target
+            if (src >= 0 && src < n) {
+                const int j = slot_of[d];
+                if (adj[src * ld + j] == g + 1) v = off[src * ld + j];
+            }
+        }
+        val[(int64_t)d * D.ld + r] = v;
+    }
+    diag_out[r] = live ? diag_in[g] : 0.0;
+}
+
+__global__ __launch_bounds__(kBlock) void k_chunk_width(int64_t nchunks, int64_t nloc, const int32_t *__restrict__ cnt,
+                                                        int64_t *__restrict__ off)
+{
+    const int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (c >= nchunks) return;
+    int w = 0;
+    const int64_t r1 = min(nloc, (c + 1) * kChunk);
+    for (int64_t r = c * kChunk; r < r1; ++r) w = max(w, cnt[r]);
+    off[c + 1] = (int64_t)w * kChunk;                      // scanned in place next
+}
+
+// exclusive scan of off[1..nchunks] by one workgroup (nchunks <= a few 1e5)
+__global__ __launch_bounds__(1024) void k_scan_offsets(int64_t nchunks, int64_t *__restrict__ off)
+{
+    __shared__ int64_t part[1024];
+    const int t = threadIdx.x;
+    const int64_t per = (nchunks + 1023) / 1024;
+    const int64_t b = (int64_t)t * per, e = min(nchunks, b + per);
+    int64_t s = 0;
+    for (int64_t c = b; c < e; ++c) s += off[c + 1];
+    part[t] = s;
+    __syncthreads();
+    if (t == 0) {
+        int64_t run = 0;
+        for (int i = 0; i < 1024; ++i) {
+            const int64_t v = part[i];
+            part[i] = run;
+            run += v;
+        }
+        off[0] = 0;
+    }
+    __syncthreads();
+    int64_t run = part[t];
+    for (int64_t c = b; c < e; ++c) {
+        const int64_t v = off[c + 1];
+        run += v;
+        off[c + 1] = run;
+    }
+}
+
+// padded slots: val = 0, column = the row itself (always a valid gather)
+__global__ __launch_bounds__(kBlock) void k_sell_init(int64_t nchunks, int64_t nloc, int64_t row0,
+                                                      const int64_t *__restrict__ off, int32_t *__restrict__ col,
+                                                      double *__restrict__ val, const double *__restrict__ diag_in,
+                                                      double *__restrict__ diag_out)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= nchunks) return;
+    const int64_t o = off[c];
+    const int w = (int)((off[c + 1] - o) >> 6);
+    const int64_t r = c * kChunk + lane;
+    const int64_t rr = r < nloc ? r : (nloc > 0 ? nloc - 1 : 0);
+    for (int k = 0; k < w; ++k) {
+        col[o + (int64_t)k * kChunk + lane] = (int32_t)(row0 + rr);
+        val[o + (int64_t)k * kChunk + lane] = 0.0;
+    }
+    diag_out[r] = r < nloc ? diag_in[row0 + r] : 0.0;
+}
+
+__global__ __launch_bounds__(kBlock) void k_sell_fill(int64_t n, int bw, int ld, const int32_t *__restrict__ adj,
+                                                      const double *__restrict__ offd, int64_t row0, int64_t nloc,
+                                                      const int64_t *__restrict__ off, int32_t *__restrict__ ticket,
+                                                      int32_t *__restrict__ col, double *__restrict__ val)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    for (int j = 0; j < bw; ++j) {
+        const int k = adj[i * ld + j];
+        if (k < 1) continue;
+        const int64_t r = (int64_t)k - 1 - row0;
+        if (r < 0 || r >= nloc) continue;
+        const int p = atomicAdd(&ticket[r], 1);
+        const int64_t pos = off[r >> 6] + (int64_t)p * kChunk + (r & 63);
+        col[pos] = (int32_t)i;
+        val[pos] = offd[i * ld + j];
+    }
+}
+
+// each row's entries ascending by (source, value): deterministic, and the order
+// in which the reference's scatter loop adds them
+__global__ __launch_bounds__(kBlock) void k_sell_sort_rows(int64_t nloc, const int32_t *__restrict__ cnt,
+                                                           const int64_t *__restrict__ off, int32_t *__restrict__ col,
+                                                           double *__restrict__ val)
+{
+    const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= nloc) return;
+    const int m = cnt[r];
+    if (m < 2) return;
+    const int64_t base = off[r >> 6] + (r & 63);
+    for (int a = 1; a < m; ++a) {                          // insertion sort, m <= #reactions
+        const int32_t ca = col[base + (int64_t)a * kChunk];
+        const double va = val[base + (int64_t)a * kChunk];
+        int b = a - 1;
+        while (b >= 0) {
+            const int32_t cb = col[base + (int64_t)b * kChunk];
+            const double vb = val[base + (int64_t)b * kChunk];
+            if (cb < ca || (cb == ca && vb <= va)) break;
+            col[base + (int64_t)(b + 1) * kChunk] = cb;
+            val[base + (int64_t)(b + 1) * kChunk] = vb;
+            --b;
+        }
+        col[base + (int64_t)(b + 1) * kChunk] = ca;
+        val[base + (int64_t)(b + 1) * kChunk] = va;
+    }
+}
+
+}  // namespace
+
+#define HIP_TRY_B(expr)                                                                    \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            ctx->err = std::string(#expr) + ": " + hipGetErrorString(e_);                  \
+            return 1000 + (int)e_;                                                         \
+        }                                                                                  \
+    } while (0)
+
+int build_from_ell_device(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, const int32_t *adj,
+                          const double *offdiag, const double *diag)
+{
+    if (bw > kMaxBw) {
+        ctx->err = "more than 64 reaction slots";
+        return -3;
+    }
+    hipStream_t st = ctx->stream;
+    const int64_t row0 = ctx->row0, nloc = ctx->nloc;
+    const int64_t nchunks = (nloc + kChunk - 1) / kChunk;
+    const int64_t nact = nchunks * kChunk;
+    const size_t nent = (size_t)n * (size_t)ld;
+
+    // the reference arrays, verbatim
+    HIP_TRY_B(ctx->d_ell_adj.reserve(nent, false));
+    HIP_TRY_B(ctx->d_ell_off.reserve(nent, false));
+    HIP_TRY_B(ctx->d_ell_diag.reserve((size_t)n, false));
+    HIP_TRY_B(hipMemcpyAsync(ctx->d_ell_adj.p, adj, nent * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY_B(hipMemcpyAsync(ctx->d_ell_off.p, offdiag, nent * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY_B(hipMemcpyAsync(ctx->d_ell_diag.p, diag, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
+
+    HIP_TRY_B(ctx->d_cnt.reserve((size_t)std::max<int64_t>(nact, 64), false));
+    HIP_TRY_B(ctx->d_scan.reserve(sizeof(ScanOut), false));
+    HIP_TRY_B(hipMemsetAsync(ctx->d_cnt.p, 0, (size_t)std::max<int64_t>(nact, 64) * sizeof(int32_t), st));
+    ScanOut init;
+    for (int j = 0; j < kMaxBw; ++j) {
+        init.dmin[j] = INT_MAX;
+        init.dmax[j] = INT_MIN;
+        init.dcount[j] = 0;
+    }
+    init.nnz_off = 0;
+    init.bad = 0;
+    HIP_TRY_B(hipMemcpyAsync(ctx->d_scan.p, &init, sizeof(init), hipMemcpyHostToDevice, st));
+    ScanOut *dscan = reinterpret_cast<ScanOut *>(ctx->d_scan.p);
+    const int gsrc = (int)((n + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_ell_scan, dim3(gsrc), dim3(kBlock), 0, st, (int64_t)n, (int)bw, (int)ld, ctx->d_ell_adj.p,
+                       row0, nloc, ctx->d_cnt.p, dscan);
+    ScanOut res;
+    HIP_TRY_B(hipMemcpyAsync(&res, dscan, sizeof(res), hipMemcpyDeviceToHost, st));
+    HIP_TRY_B(hipStreamSynchronize(st));
+    if (res.bad) {
+        ctx->err = "adj entry exceeds n";
+        return -5;
+    }
+    ctx->nchunks = nchunks;
+    ctx->nnz = nloc + (int64_t)res.nnz_off;
+    HIP_TRY_B(ctx->d_diag.reserve((size_t)std::max<int64_t>(nact, 64), false));
+
+    // banded?  every used slot is one constant shift, and the diagonals are full enough
+    int nd = 0;
+    bool banded = ctx->opt_format != 1 && nloc > 0;
+    std::pair<int, int> dl[kMaxBw];                        // (source - target, slot)
+    for (int j = 0; j < bw && banded; ++j) {
+        if (res.dmin[j] == INT_MAX) continue;              // slot never links
+        if (res.dmin[j] != res.dmax[j]) banded = false;
+        else dl[nd++] = {-res.dmin[j], j};
+    }
+    if (nd == 0 || nd > kMaxDiag) banded = false;
+    if (banded && (double)nd * (double)nloc > 1.25 * (double)res.nnz_off + 1024.0) banded = false;
+
+    ctx->use_dia = false;
+    ctx->nd = 0;
+    ctx->have_sell = false;
+    if (banded) {
+        std::sort(dl, dl + nd);
+        DiaDev D;
+        D.nd = nd;
+        int slot_of[kMaxDiag];
+        for (int d = 0; d < nd; ++d) {
+            D.delta[d] = dl[d].first;
+            slot_of[d] = dl[d].second;
+        }
+        D.ld = nact;
+        D.n = n;
+        D.nchunks = nchunks;
+        D.val = nullptr;
+        D.diag = nullptr;
+        HIP_TRY_B(ctx->d_dia.reserve((size_t)nd * (size_t)nact, false));
+        HIP_TRY_B(ctx->d_slot.reserve(kMaxDiag, false));
+        HIP_TRY_B(hipMemcpyAsync(ctx->d_slot.p, slot_of, sizeof(int) * (size_t)nd, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_ell_to_dia, dim3((int)((nact + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, (int64_t)n,
+                           (int)ld, ctx->d_ell_adj.p, ctx->d_ell_off.p, ctx->d_ell_diag.p, row0, nloc, nd, D,
+                           ctx->d_slot.p, ctx->d_dia.p, ctx->d_diag.p);
+        HIP_TRY_B(hipStreamSynchronize(st));
+        ctx->nd = nd;
+        ctx->dia_ld = nact;
+        for (int d = 0; d < nd; ++d) ctx->delta[d] = D.delta[d];
+        ctx->use_dia = true;
+        ctx->slots = 0;
+        return 0;
+    }
+
+    // SELL-64
+    HIP_TRY_B(ctx->d_off.reserve((size_t)nchunks + 1, false));
+    HIP_TRY_B(hipMemsetAsync(ctx->d_off.p, 0, sizeof(int64_t), st));
+    if (nchunks > 0) {
+        hipLaunchKernelGGL(k_chunk_width, dim3((int)((nchunks + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, nchunks,
+                           nloc, ctx->d_cnt.p, ctx->d_off.p);
+        hipLaunchKernelGGL(k_scan_offsets, dim3(1), dim3(1024), 0, st, nchunks, ctx->d_off.p);
+    }
+    int64_t slots = 0;
+    HIP_TRY_B(hipMemcpyAsync(&slots, ctx->d_off.p + nchunks, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY_B(hipStreamSynchronize(st));
+    ctx->slots = slots;
+    HIP_TRY_B(ctx->d_col.reserve((size_t)std::max<int64_t>(slots, 64), false));
+    HIP_TRY_B(ctx->d_val.reserve((size_t)std::max<int64_t>(slots, 64), false));
+    HIP_TRY_B(ctx->d_ticket.reserve((size_t)std::max<int64_t>(nact, 64), false));
+    HIP_TRY_B(hipMemsetAsync(ctx->d_ticket.p, 0, (size_t)std::max<int64_t>(nact, 64) * sizeof(int32_t), st));
+    if (nchunks > 0) {
+        hipLaunchKernelGGL(k_sell_init, dim3((int)((nchunks + 3) / 4)), dim3(kBlock), 0, st, nchunks, nloc, row0,
+                           ctx->d_off.p, ctx->d_col.p, ctx->d_val.p, ctx->d_ell_diag.p, ctx->d_diag.p);
+        hipLaunchKernelGGL(k_sell_fill, dim3(gsrc), dim3(kBlock), 0, st, (int64_t)n, (int)bw, (int)ld, ctx->d_ell_adj.p,
+                           ctx->d_ell_off.p, row0, nloc, ctx->d_off.p, ctx->d_ticket.p, ctx->d_col.p, ctx->d_val.p);
+        hipLaunchKernelGGL(k_sell_sort_rows, dim3((int)((nloc + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, nloc,
+                           ctx->d_cnt.p, ctx->d_off.p, ctx->d_col.p, ctx->d_val.p);
+    }
+    HIP_TRY_B(hipStreamSynchronize(st));
+    ctx->have_sell = true;
+    return 0;
+}
+
+}  // namespace kfsp

@@ -1,0 +1,123 @@
+// Private: the device context behind the opaque kfsp_ctx handle, shared by the
+// host translation units of libkfsp_hip.
+#pragma once
+
+#include "../../include/kfsp.h"
+#include "kfsp_internal.h"
+
+#include <rccl/rccl.h>
+
+#include <string>
+#include <vector>
+
+namespace kfsp {
+
+constexpr int kNumPartial = 4;   // rotating block-partial buffers
+constexpr int kNumStage = 8;     // rotating all-reduce staging scalars
+
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t n, bool zero)
+    {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), n * sizeof(T));
+        if (e != hipSuccess) return e;
+        cap = n;
+        if (zero) e = hipMemset(p, 0, n * sizeof(T));
+        return e;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+
+}  // namespace kfsp
+
+using kfsp::DevBuf;
+using kfsp::kMaxDiag;
+
+struct kfsp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+
+    // partition
+    int nranks = 1, rank = 0;
+    ncclComm_t comm = nullptr;
+
+    // sizes
+    int64_t n = 0;        // global states
+    int64_t L = 0;        // rows per rank (padded block length), multiple of 64
+    int64_t row0 = 0;     // first global row of this rank
+    int64_t nloc = 0;     // rows owned
+    int64_t ldv = 0;      // column stride of the basis, multiple of 256
+
+    // generator
+    DevBuf<int64_t> d_off;
+    DevBuf<int32_t> d_col;
+    DevBuf<double> d_val, d_diag;
+    int64_t nchunks = 0, slots = 0, nnz = 0;
+    // banded (DIA) form, used instead of SELL when the rows allow it
+    DevBuf<double> d_dia;
+    bool use_dia = false;
+    int nd = 0;
+    int32_t delta[kMaxDiag] = {0};
+    int64_t dia_ld = 0;
+    bool have_sell = false;
+    // device-side build from the reference layout (kfsp_build.hip)
+    DevBuf<int32_t> d_ell_adj, d_cnt, d_ticket;
+    DevBuf<double> d_ell_off, d_ell_diag;
+    DevBuf<int> d_slot;
+    DevBuf<char> d_scan;
+    // optional CSR copy for the CSR-stream kernel variant
+    DevBuf<int64_t> d_rowptr;
+    DevBuf<int32_t> d_ccol, d_tile;
+    DevBuf<double> d_cval;
+    int64_t ntiles = 0;
+    bool want_csr = false, have_csr = false;
+
+    // vectors
+    DevBuf<double> d_V;    // (kMMax+2) columns, stride ldv, unnormalised basis
+    DevBuf<double> d_w;    // probability vector, ldv
+    DevBuf<double> d_xg;   // nranks*L gathered source (nranks > 1) or scratch x (kfsp_spmv)
+    DevBuf<double> d_tmp;  // ldv scratch (kfsp_spmv output)
+
+    // scalars
+    DevBuf<double> d_part;   // kNumPartial * kMaxGrid
+    DevBuf<double> d_stage;  // kNumStage
+    DevBuf<double> d_H;      // kMH * kMH image + 2 (avnorm^2, avnorm)
+    DevBuf<double> d_sq;     // finished squared norms, index = column (1-based)
+    DevBuf<double> d_g;      // finished u_j . u_{j-1}, index = j
+    DevBuf<double> d_y;      // kMH coefficients
+    DevBuf<int> d_flag;
+    int part_rr = 0, stage_rr = 0;
+    std::vector<double> h_H;
+    double avnorm_last = 0.0;
+
+    // options
+    int64_t opt_grid = 0;   // cap on the product kernels' grid, 0 = auto (2048)
+    int64_t opt_vgrid = 0;  // cap on the streaming kernels' grid, 0 = auto (1024)
+    int64_t opt_nt = -1;    // -1 auto, 0 off, 1 on
+    int64_t opt_format = 0; // 0 auto (DIA when banded), 1 always SELL
+    int64_t opt_fused = 1;  // 1: one-pass IOP(2) orthogonalisation (k_ortho2)
+    int64_t opt_host_build = 0;   // 1: transpose reference-layout input on the host (A/B testing)
+    bool timers = false;
+    double t_ms[KFSP_T_COUNT] = {0, 0, 0, 0, 0, 0};
+};
+
+namespace kfsp {
+// generator build on the device from the reference layout (kfsp_build.hip)
+int build_from_ell_device(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, const int32_t *adj,
+                          const double *offdiag, const double *diag);
+}  // namespace kfsp
