@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--no-expv", action="store_true")
     ap.add_argument("--expv-steps", type=int, default=10)
     ap.add_argument("--opt", action="append", default=[], help="library option name=value")
+    ap.add_argument("--force-comm", action="store_true",
+                    help="create the RCCL communicator even with one rank (exercises the collective path on one GPU)")
     return ap.parse_args()
 
 
@@ -73,6 +75,10 @@ def main():
             sys.exit("bench.py --gpus N>1 must be launched by torch.distributed.run with N ranks")
         args.gpus = world
 
+    # RCCL prints a version banner on stdout at communicator creation when
+    # NCCL_DEBUG=VERSION; stdout must carry exactly one JSON line
+    if os.environ.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":
+        os.environ["NCCL_DEBUG"] = "WARN"
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
@@ -100,6 +106,8 @@ def main():
         ctx.set_option(k, int(v))
     if args.variant == 1:
         ctx.set_option("build_csr", 1)
+    if world == 1 and args.force_comm:
+        ctx.comm_init(1, 0, KfspContext.unique_id())
     if world > 1:
         idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
         if rank == 0:

@@ -185,12 +185,16 @@ int kfsp_spmv_bench(kfsp_ctx *ctx, int reps, int variant, float *ms_total);
  * calibrate the rocprofv3 FETCH_SIZE counter on a known byte count. */
 int kfsp_selftest_stream(kfsp_ctx *ctx, int64_t nbytes, int elem_bytes, int reps, float *ms_total);
 
-/* accumulated device time (ms) by phase since the last reset; HIP-event based
- * and only collected when enabled (it adds synchronisation). */
-enum { KFSP_T_SPMV = 0, KFSP_T_ORTHO = 1, KFSP_T_COMBINE = 2, KFSP_T_COMM = 3,
+/* accumulated wall time (ms) of the synchronous entry points by phase since
+ * the last reset: Arnoldi passes (product + orthogonalisation kernels and the
+ * copy of H), combine calls, begin_step calls, host Pade, generator uploads
+ * (host->device copy + device build), time spent inside the drop / expand
+ * callbacks of kfsp_dgexpv. */
+enum { KFSP_T_ARNOLDI = 0, KFSP_T_COMBINE = 1, KFSP_T_BEGIN = 2, KFSP_T_CALLBACKS = 3,
        KFSP_T_HOST_PADE = 4, KFSP_T_UPLOAD = 5, KFSP_T_COUNT = 6 };
-int kfsp_timers_enable(kfsp_ctx *ctx, int on);
 int kfsp_get_timers(kfsp_ctx *ctx, double *ms /* [KFSP_T_COUNT] */, int reset);
+/* add ms to a phase (used by kfsp_dgexpv, which is a client of this ABI) */
+int kfsp_add_timer(kfsp_ctx *ctx, int phase, double ms);
 
 /* tuning knobs (name/value); unknown name -> -2.  "grid_blocks", "nt_loads",
  * "deterministic" ... see DESIGN.md */

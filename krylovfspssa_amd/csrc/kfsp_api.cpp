@@ -20,6 +20,14 @@ constexpr int kAbiVersion = 1;
 
 namespace {
 
+struct PhaseTimer {
+    kfsp_ctx *c;
+    int phase;
+    std::chrono::steady_clock::time_point t0;
+    PhaseTimer(kfsp_ctx *c_, int p) : c(c_), phase(p), t0(std::chrono::steady_clock::now()) {}
+    ~PhaseTimer() { c->t_ms[phase] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
 int fail(kfsp_ctx *c, int code, const char *what)
 {
     if (c) c->err = what;
@@ -116,7 +124,7 @@ void set_matrix_args(const kfsp_ctx *c, SpmvArgs &a)
 // Make block partials a scalar every rank agrees on.
 int publish(kfsp_ctx *ctx, Pending local, Pending *out)
 {
-    if (ctx->nranks == 1) {
+    if (!ctx->use_comm) {
         *out = local;
         return 0;
     }
@@ -131,7 +139,7 @@ int publish(kfsp_ctx *ctx, Pending local, Pending *out)
 // Several scalars at once: one all-reduce for all of them.
 int publish_n(kfsp_ctx *ctx, const Pending *local, int k, Pending *out)
 {
-    if (ctx->nranks == 1) {
+    if (!ctx->use_comm) {
         for (int i = 0; i < k; ++i) out[i] = local[i];
         return 0;
     }
@@ -147,7 +155,7 @@ int publish_n(kfsp_ctx *ctx, const Pending *local, int k, Pending *out)
 // The source column must be visible in full on every rank before a product.
 int gather_source(kfsp_ctx *ctx, const double *src_local, const double **xg)
 {
-    if (ctx->nranks == 1) {
+    if (!ctx->use_comm) {
         *xg = src_local;
         return 0;
     }
@@ -523,10 +531,14 @@ int kfsp_comm_init(kfsp_ctx *ctx, int nranks, int rank, const void *id_bytes)
     }
     ctx->nranks = nranks;
     ctx->rank = rank;
-    if (nranks > 1) {
+    // a unique id with nranks == 1 still creates a (one-rank) communicator, so the
+    // collective code path can be exercised on a single GPU
+    ctx->use_comm = false;
+    if (id_bytes) {
         ncclUniqueId id;
         std::memcpy(&id, id_bytes, sizeof(id));
         NCCL_TRY(ncclCommInitRank(&ctx->comm, nranks, id, rank));
+        ctx->use_comm = true;
     }
     ctx->ldv = 0;   // force re-layout on the next matrix
     return 0;
@@ -721,6 +733,7 @@ int kfsp_begin_step(kfsp_ctx *ctx, double *beta)
     if (!ctx) return -1;
     if (ctx->ldv == 0) return fail(ctx, -1, "no matrix set");
     if (!beta) return fail(ctx, -2, "null beta");
+    PhaseTimer timer(ctx, KFSP_T_BEGIN);
     HIP_TRY(hipSetDevice(ctx->device));
     double *part = next_partial(ctx);
     const int g = vec_grid(ctx);
@@ -747,6 +760,7 @@ int kfsp_arnoldi(kfsp_ctx *ctx, int m, int jold, int qiop, double break_tol, dou
     if (!H) return fail(ctx, -6, "null H");
     if (ldh < m + 2) return fail(ctx, -7, "ldh < m+2");
     if (!mbrkdwn || !k1 || !avnorm) return fail(ctx, -8, "null output");
+    PhaseTimer timer(ctx, KFSP_T_ARNOLDI);
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const int64_t ldv = ctx->ldv;
@@ -772,7 +786,7 @@ int kfsp_arnoldi(kfsp_ctx *ctx, int m, int jold, int qiop, double break_tol, dou
         SpmvArgs a;
         set_matrix_args(ctx, a);
         a.xg = xg;
-        a.row0 = ctx->nranks == 1 ? 0 : ctx->row0;
+        a.row0 = ctx->row0;
         a.y = dst;
         a.sq = pend_sq;
         a.sq_final = sq + j;
@@ -851,7 +865,7 @@ int kfsp_arnoldi(kfsp_ctx *ctx, int m, int jold, int qiop, double break_tol, dou
         SpmvArgs a;
         set_matrix_args(ctx, a);
         a.xg = xg;
-        a.row0 = ctx->nranks == 1 ? 0 : ctx->row0;
+        a.row0 = ctx->row0;
         a.y = V + (size_t)jl * ldv;
         a.sq = looped ? pend_sq : Pending{sq + jold, 1};
         a.sq_final = sq + jl;
@@ -898,6 +912,7 @@ int kfsp_combine(kfsp_ctx *ctx, int mx, double beta, const double *y, double *ws
     if (mx < 1 || mx > kMMax + 2) return fail(ctx, -2, "bad mx");
     if (!y) return fail(ctx, -4, "null y");
     if (!wsum) return fail(ctx, -5, "null wsum");
+    PhaseTimer timer(ctx, KFSP_T_COMBINE);
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     HIP_TRY(hipMemcpyAsync(ctx->d_y.p, y, (size_t)mx * sizeof(double), hipMemcpyHostToDevice, st));
@@ -942,7 +957,7 @@ static int spmv_plain(kfsp_ctx *ctx, const double *src_local_or_full, bool src_i
     SpmvArgs a;
     set_matrix_args(ctx, a);
     a.xg = xg;
-    a.row0 = (ctx->nranks == 1) ? 0 : ctx->row0;
+    a.row0 = ctx->row0;
     a.y = y_dev;
     a.sq = Pending{nullptr, 0};
     a.sq_final = nullptr;
@@ -1082,7 +1097,7 @@ int kfsp_spmv_bench(kfsp_ctx *ctx, int reps, int variant, float *ms_total)
             if (int rc = gather_source(ctx, src, &xg)) return rc;
             CsrDev A{ctx->nloc, ctx->d_rowptr.p, ctx->d_ccol.p, ctx->d_cval.p, ctx->d_diag.p, ctx->d_tile.p, ctx->ntiles};
             const int g = (int)std::min<int64_t>(ctx->ntiles, kMaxGrid);
-            launch_spmv_csr_stream(std::max(g, 1), A, xg, ctx->nranks == 1 ? 0 : ctx->row0, dst, st);
+            launch_spmv_csr_stream(std::max(g, 1), A, xg, ctx->row0, dst, st);
         }
     }
     HIP_TRY(hipEventRecord(ctx->ev1, st));
@@ -1111,10 +1126,11 @@ int kfsp_selftest_stream(kfsp_ctx *ctx, int64_t nbytes, int elem_bytes, int reps
     return 0;
 }
 
-int kfsp_timers_enable(kfsp_ctx *ctx, int on)
+int kfsp_add_timer(kfsp_ctx *ctx, int phase, double ms)
 {
     if (!ctx) return -1;
-    ctx->timers = on != 0;
+    if (phase < 0 || phase >= KFSP_T_COUNT) return -2;
+    ctx->t_ms[phase] += ms;
     return 0;
 }
 

@@ -55,6 +55,7 @@ struct kfsp_ctx {
     // partition
     int nranks = 1, rank = 0;
     ncclComm_t comm = nullptr;
+    bool use_comm = false;   // collectives on the data path (nranks > 1, or a 1-rank communicator for testing)
 
     // sizes
     int64_t n = 0;        // global states
@@ -112,7 +113,6 @@ struct kfsp_ctx {
     int64_t opt_format = 0; // 0 auto (DIA when banded), 1 always SELL
     int64_t opt_fused = 1;  // 1: one-pass IOP(2) orthogonalisation (k_ortho2)
     int64_t opt_host_build = 0;   // 1: transpose reference-layout input on the host (A/B testing)
-    bool timers = false;
     double t_ms[KFSP_T_COUNT] = {0, 0, 0, 0, 0, 0};
 };
 

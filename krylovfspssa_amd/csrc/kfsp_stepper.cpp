@@ -11,6 +11,7 @@
 #include "../../include/kfsp.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -179,7 +180,12 @@ extern "C" int kfsp_dgexpv(kfsp_ctx *ctx, double t, double fsptol, double krytol
             // label 401: exp(t_step * H) of order MBRKDWN + K1   :270-277
             ++st.nexph;
             mx = mbrkdwn + k1;
-            if ((rc = kfsp_padm(kIdeg, mx, S.sgn * t_step, H.data(), mh, E.data(), &ns, &hnorm))) return 3000 - rc;
+            {
+                const auto t0 = std::chrono::steady_clock::now();
+                rc = kfsp_padm(kIdeg, mx, S.sgn * t_step, H.data(), mh, E.data(), &ns, &hnorm);
+                kfsp_add_timer(ctx, KFSP_T_HOST_PADE, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+                if (rc) return 3000 - rc;
+            }
             st.nscale += ns;
             // local error estimate :290-305
             if (k1 == 0) {
@@ -316,7 +322,10 @@ extern "C" int kfsp_dgexpv(kfsp_ctx *ctx, double t, double fsptol, double krytol
                 if (dsum > 0.0 && ops && ops->drop) {
                     int64_t nn = S.n;
                     ++st.n_drop_calls;
-                    if ((rc = ops->drop(ops->user, dsum, &nn))) return rc;
+                    const auto t0 = std::chrono::steady_clock::now();
+                    rc = ops->drop(ops->user, dsum, &nn);
+                    kfsp_add_timer(ctx, KFSP_T_CALLBACKS, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+                    if (rc) return rc;
                     S.n = nn;
                 }
             }
@@ -332,7 +341,12 @@ extern "C" int kfsp_dgexpv(kfsp_ctx *ctx, double t, double fsptol, double krytol
             }
             int64_t nn = S.n;
             ++st.n_expand;
-            if ((rc = ops->expand(ops->user, t_ssa, &nn))) return rc;
+            {
+                const auto t0 = std::chrono::steady_clock::now();
+                rc = ops->expand(ops->user, t_ssa, &nn);
+                kfsp_add_timer(ctx, KFSP_T_CALLBACKS, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+                if (rc) return rc;
+            }
             S.n = nn;
             need_expand = false;
         }

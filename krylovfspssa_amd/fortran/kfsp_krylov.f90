@@ -64,7 +64,9 @@ CONTAINS
     INTEGER :: IFLAG
     TYPE(KFSP_FSP_OPS) :: OPS
     DOUBLE PRECISION, ALLOCATABLE :: P0(:)
+    REAL(C_DOUBLE) :: TMS(6)
     INTEGER :: I, N0, RC
+    INTEGER(8) :: C0, C1, CRATE
 
     IFLAG = 0
     N0 = FSP%SIZE
@@ -80,6 +82,8 @@ CONTAINS
     IF (FSP%SIZE > N0) FSP%VECTOR(N0 + 1:FSP%SIZE) = 0.0D0
 
     CALL ENSURE_CONTEXT()
+    CALL SYSTEM_CLOCK(C0, CRATE)
+    RC = KFSP_GET_TIMERS(CTX, TMS, 1_C_INT)
     CUR_FSP => FSP
     CUR_MODEL => MODEL
     CUR_TRACE = ITRACE
@@ -99,6 +103,18 @@ CONTAINS
        IF (SIZE(W) >= FSP%SIZE) W(1:FSP%SIZE) = FSP%VECTOR(1:FSP%SIZE)
     ENDIF
     NULLIFY(CUR_FSP, CUR_MODEL)
+    IF (ITRACE /= 0) THEN
+       ! where the wall time of the solve went (ms); FSP_CALLBACKS = host state-space
+       ! code (DROP_STATES / SSA_EXTENDER / ONESTEP_EXTENDER) incl. its uploads
+       CALL SYSTEM_CLOCK(C1)
+       RC = KFSP_GET_TIMERS(CTX, TMS, 0_C_INT)
+       PRINT '(A,F12.1,A,6(1X,A,F11.1))', ' KFSP WALL MS =', 1.0D3 * DBLE(C1 - C0) / DBLE(CRATE), ' :', &
+            'ARNOLDI', TMS(1), 'COMBINE', TMS(2), 'BEGIN_STEP', TMS(3), 'FSP_CALLBACKS', TMS(4), &
+            'HOST_PADE', TMS(5), 'UPLOAD', TMS(6)
+       PRINT '(A,I8,A,I8,A,I8,A,I6,A,I6)', ' KFSP STATS: NMULT =', LAST_SOLVE_STATS%NMULT, ' NEXPH =', &
+            LAST_SOLVE_STATS%NEXPH, ' WSUM_EVALS =', LAST_SOLVE_STATS%N_WSUM, ' EXPANSIONS =', &
+            LAST_SOLVE_STATS%N_EXPAND, ' DROP_CALLS =', LAST_SOLVE_STATS%N_DROP_CALLS
+    ENDIF
   END SUBROUTINE DGEXPV_FSP
 
   ! ------------------------------------------------------------- plumbing

@@ -14,7 +14,7 @@ import numpy as np
 from . import build as _build
 
 M_MAX = 100
-T_NAMES = ("spmv", "ortho", "combine", "comm", "host_pade", "upload")
+T_NAMES = ("arnoldi", "combine", "begin_step", "fsp_callbacks", "host_pade", "upload")
 
 _lib = None
 
@@ -67,7 +67,7 @@ def load_library():
         "kfsp_expv_fixed": [vp, C.c_int, dbl, C.c_int, vp],
         "kfsp_spmv_bench": [vp, C.c_int, C.c_int, C.POINTER(C.c_float)],
         "kfsp_selftest_stream": [vp, i64, C.c_int, C.c_int, C.POINTER(C.c_float)],
-        "kfsp_timers_enable": [vp, C.c_int],
+        "kfsp_add_timer": [vp, C.c_int, dbl],
         "kfsp_get_timers": [vp, vp, C.c_int],
         "kfsp_set_option": [vp, C.c_char_p, i64],
     }

@@ -388,3 +388,36 @@ def test_device_build_detects_banded_generators(oracle):
     assert out[0][1]["nnz"] == out[1][1]["nnz"] == mdl.nnz()
     assert np.array_equal(out[0][0], out[1][0])
     assert np.abs(out[0][0] - ref).max() <= 1e-13 * np.abs(ref).max() + 1e-300
+
+
+# ------------------------------------------------------------- collective path
+
+def test_one_rank_communicator_runs_the_collective_path(oracle):
+    """kfsp_comm_init with a unique id and nranks = 1 creates a real RCCL
+    communicator: every product is preceded by ncclAllGather into the padded
+    global vector, every scalar goes through finish + ncclAllReduce.  Results
+    must be bit-identical to the collective-free path."""
+    from krylovfspssa_amd import KfspContext, synth
+    mdl = synth.repressilator(dims=(31, 23, 19))
+    rp, cc, vv = mdl.csr_rows()
+    p0 = synth.poisson_p0(mdl, 8.0)
+    out = []
+    for use_comm in (False, True):
+        with KfspContext(0) as c:
+            if use_comm:
+                c.comm_init(1, 0, KfspContext.unique_id())
+            assert c.row_block(mdl.n) == (0, mdl.n)
+            c.set_matrix_csr(mdl.n, rp, cc, vv)
+            c.set_vector(p0)
+            beta = c.begin_step()
+            H, mb, k1, av = c.arnoldi(20)
+            c.set_vector(p0)
+            ws = c.expv_fixed(20, 0.01, 3)
+            ms = c.spmv_bench(3)
+            out.append((beta, H.copy(), av, ws.copy(), c.get_vector()))
+    assert out[0][0] == out[1][0] and out[0][2] == out[1][2]
+    assert np.array_equal(out[0][1], out[1][1])
+    assert np.array_equal(out[0][3], out[1][3]) and np.array_equal(out[0][4], out[1][4])
+    adj, off, diag = mdl.ell()
+    wref, _ = oracle.expv_fixed(oracle.EllMatrix(adj, off, diag), p0, 20, 0.01, 3)
+    assert np.abs(out[1][4] - wref).sum() < 1e-10
