@@ -75,10 +75,12 @@ def main():
             sys.exit("bench.py --gpus N>1 must be launched by torch.distributed.run with N ranks")
         args.gpus = world
 
-    # RCCL prints a version banner on stdout at communicator creation when
-    # NCCL_DEBUG=VERSION; stdout must carry exactly one JSON line
-    if os.environ.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":
-        os.environ["NCCL_DEBUG"] = "WARN"
+    # stdout must carry exactly one JSON line, but RCCL writes its version banner
+    # and topology warnings there: keep the real stdout aside and point fd 1 at
+    # stderr for everything else
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
@@ -131,6 +133,45 @@ def main():
     b_alg_global = synth.spmv_alg_bytes(nnz_global, mdl.n)
     b_alg_local = synth.spmv_alg_bytes(nnz_local, nrows)
 
+    def distributed_product_ok():
+        """y = A x through the solver's own exchange (halo strips or all-gather)
+        against numpy on a sample of this rank's rows; collective verdict."""
+        y = ctx.spmv_w()
+        if world > 1:
+            xs = torch.zeros(L, dtype=torch.float64, device="cuda")
+            xs[:nrows] = torch.from_numpy(x).cuda()
+            xall = torch.zeros(world * L, dtype=torch.float64, device="cuda")
+            dist.all_gather_into_tensor(xall, xs)
+            xg = xall.cpu().numpy()
+        else:
+            xg = x
+        bad = 0.0
+        if nrows > 0:
+            rows = np.unique(np.concatenate([np.arange(min(nrows, 256)), np.arange(max(nrows - 256, 0), nrows),
+                                             np.random.default_rng(7).integers(0, nrows, 2048)]))
+            ref = np.array([val[rowptr[r]:rowptr[r + 1]] @ xg[col[rowptr[r]:rowptr[r + 1]]] for r in rows])
+            mag = np.array([np.abs(val[rowptr[r]:rowptr[r + 1]]) @ np.abs(xg[col[rowptr[r]:rowptr[r + 1]]]) for r in rows])
+            bad = float(np.max(np.abs(y[rows] - ref) / (mag + 1e-300)))
+        return max_over_ranks(bad) < 1e-12
+
+    L = 0
+    exchange = "none (single rank)"
+    if world > 1 or args.force_comm:
+        from krylovfspssa_amd import host as _host
+        L = _host.partition(mdl.n, world, rank)[2]
+        exchange = "halo strips (banded generator)"
+        if not distributed_product_ok():
+            # never report a number from a wrong product: fall back to the plain all-gather
+            ctx.set_option("halo", 0)
+            ctx.set_matrix_csr(mdl.n, rowptr, col, val)
+            ctx.set_vector(x)
+            ctx.begin_step()
+            exchange = "all-gather of the whole vector (halo self-check failed)"
+            if not distributed_product_ok():
+                exchange = "all-gather; SELF-CHECK FAILED"
+        ctx.set_vector(x)
+        ctx.begin_step()
+
     ctx.spmv_bench(max(args.warmup, 1), args.variant)
     barrier()
     t0 = time.perf_counter()
@@ -168,6 +209,7 @@ def main():
             "states_per_gpu": int(nrows), "states_total": int(mdl.n),
             "nnz_total": int(nnz_global), "alg_bytes_per_launch_total": int(b_alg_global),
             "partition": f"rows x{world}" if world > 1 else "single GPU",
+            "exchange": exchange,
             "kernel_variant": {0: "auto (banded DIA when the rows allow it, else SELL-64)", 1: "csr_stream", 2: "sell64"}[args.variant],
             "stored_slots_local": info["slots"],
         },
@@ -177,7 +219,7 @@ def main():
             "kernel": "k_spmv", "avg_launch_ms": round(kern_ms, 5),
             "alg_bytes_per_launch": int(b_alg_local),
             "note": "per-GPU algorithmic bytes (12 nnz + 20 N) / HIP-event time of the timed launches"
-                    + ("; includes the all-gather" if world > 1 else ""),
+                    + ("; includes the exchange of the source vector" if world > 1 else ""),
         },
         "input_generation_s": round(t_gen, 2),
     }
@@ -254,7 +296,8 @@ def main():
 
     ctx.close()
     if rank == 0:
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.destroy_process_group()
 

@@ -152,11 +152,34 @@ int publish_n(kfsp_ctx *ctx, const Pending *local, int k, Pending *out)
     return 0;
 }
 
+int resize(kfsp_ctx *ctx, int64_t n);
+
 // The source column must be visible in full on every rank before a product.
 int gather_source(kfsp_ctx *ctx, const double *src_local, const double **xg)
 {
     if (!ctx->use_comm) {
-        *xg = src_local;
+        *xg = src_local - ctx->row0;       // row0 == 0 here
+        return 0;
+    }
+    if (ctx->use_halo) {
+        // Banded generator: only the `halo` boundary rows of the two neighbours are
+        // ever read.  Every rank contributes [its first halo rows | its last halo
+        // rows]; one all-gather of these strips, then the two strips this rank
+        // needs are dropped into the margins of the source column itself.
+        const int64_t H = ctx->halo, L = ctx->L;
+        hipStream_t st = ctx->stream;
+        double *send = ctx->d_strip.p, *recv = ctx->d_strip.p + 2 * H;
+        HIP_TRY(hipMemcpyAsync(send, src_local, (size_t)H * sizeof(double), hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(send + H, src_local + (L - H), (size_t)H * sizeof(double), hipMemcpyDeviceToDevice, st));
+        NCCL_TRY(ncclAllGather(send, recv, (size_t)(2 * H), ncclDouble, ctx->comm, st));
+        double *col = const_cast<double *>(src_local);
+        if (ctx->rank > 0)                 // the previous rank's LAST rows sit just below row 0
+            HIP_TRY(hipMemcpyAsync(col - H, recv + (size_t)(ctx->rank - 1) * 2 * H + H, (size_t)H * sizeof(double),
+                                   hipMemcpyDeviceToDevice, st));
+        if (ctx->rank + 1 < ctx->nranks)   // the next rank's FIRST rows follow row L-1
+            HIP_TRY(hipMemcpyAsync(col + L, recv + (size_t)(ctx->rank + 1) * 2 * H, (size_t)H * sizeof(double),
+                                   hipMemcpyDeviceToDevice, st));
+        *xg = src_local - ctx->row0;       // global index g lives at src_local[g - row0]
         return 0;
     }
     NCCL_TRY(ncclAllGather(src_local, ctx->d_xg.p, (size_t)ctx->L, ncclDouble, ctx->comm, ctx->stream));
@@ -164,7 +187,44 @@ int gather_source(kfsp_ctx *ctx, const double *src_local, const double **xg)
     return 0;
 }
 
+// After a generator was set: agree across ranks on the exchange mode.  Halo
+// exchange needs every rank to hold a banded block whose reach max|delta| does
+// not exceed one block length (only the two neighbours are involved then).
+int setup_exchange(kfsp_ctx *ctx)
+{
+    ctx->use_halo = false;
+    ctx->halo = 0;
+    if (!ctx->use_comm) return 0;
+    int64_t reach = 0;
+    for (int d = 0; d < ctx->nd; ++d) reach = std::max<int64_t>(reach, std::llabs((long long)ctx->delta[d]));
+    // ranks without rows take part with neutral values
+    const bool ok_local = ctx->opt_halo != 0 && (ctx->nloc == 0 || ctx->use_dia);
+    double h[2] = {ok_local ? 0.0 : 1.0, (double)reach};          // max over ranks of (not ok, reach)
+    double *st = ctx->d_stage.p;
+    HIP_TRY(hipMemcpyAsync(st, h, sizeof(h), hipMemcpyHostToDevice, ctx->stream));
+    NCCL_TRY(ncclAllReduce(st, st, 2, ncclDouble, ncclMax, ctx->comm, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(h, st, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const int64_t H = round_up(std::max<int64_t>((int64_t)h[1], 1), 8);
+    if (h[0] != 0.0 || H > ctx->L) return 0;                      // someone is not banded, or reach > one block
+    ctx->halo = H;
+    if (H > ctx->margin) {
+        // re-lay the basis with room for the strips (its contents are rebuilt by
+        // the next begin_step anyway)
+        ctx->margin = round_up(H + H / 4, 64);
+        if (int rc = resize(ctx, ctx->n)) return rc;
+    }
+    HIP_TRY(ctx->d_strip.reserve((size_t)(2 * H) * (size_t)(ctx->nranks + 1), true));
+    ctx->use_halo = true;
+    return 0;
+}
+
 // (Re)size everything that depends on the number of states.
+constexpr int kNumCols = kMMax + 3;   // M_MAX + 2 basis columns and one scratch column
+
+// column j (0-based) of the basis: `margin` halo rows sit on either side of it
+inline double *vcol(const kfsp_ctx *c, int j) { return c->d_V.p + (size_t)j * (size_t)c->ldv + (size_t)c->margin; }
+
 int resize(kfsp_ctx *ctx, int64_t n)
 {
     ctx->n = n;
@@ -172,18 +232,18 @@ int resize(kfsp_ctx *ctx, int64_t n)
     if (ctx->L == 0) ctx->L = kChunk;
     ctx->row0 = (int64_t)ctx->rank * ctx->L;
     ctx->nloc = std::max<int64_t>(0, std::min<int64_t>(ctx->L, n - ctx->row0));
-    const int64_t ldv = round_up(ctx->L, 256);
-    if (ldv > ctx->ldv || (size_t)ldv * (kMMax + 2) > ctx->d_V.cap) {
+    const int64_t ldv = round_up(ctx->L + 2 * ctx->margin, 256);
+    if (ldv > ctx->ldv || (size_t)ldv * kNumCols > ctx->d_V.cap) {
         // grow with head room: the FSP usually keeps growing
         const int64_t cap = round_up(ldv + ldv / 2, 256);
-        HIP_TRY(ctx->d_V.reserve((size_t)cap * (kMMax + 2), false));
+        HIP_TRY(ctx->d_V.reserve((size_t)cap * kNumCols, false));
         HIP_TRY(ctx->d_w.reserve((size_t)cap, false));
         HIP_TRY(ctx->d_tmp.reserve((size_t)cap, false));
     }
     if (ldv != ctx->ldv) {
         ctx->ldv = ldv;
         // padding rows must read as zero in every kernel
-        HIP_TRY(hipMemsetAsync(ctx->d_V.p, 0, (size_t)ldv * (kMMax + 2) * sizeof(double), ctx->stream));
+        HIP_TRY(hipMemsetAsync(ctx->d_V.p, 0, (size_t)ldv * kNumCols * sizeof(double), ctx->stream));
         HIP_TRY(hipMemsetAsync(ctx->d_w.p, 0, (size_t)ldv * sizeof(double), ctx->stream));
         HIP_TRY(hipMemsetAsync(ctx->d_tmp.p, 0, (size_t)ldv * sizeof(double), ctx->stream));
     }
@@ -497,7 +557,7 @@ int kfsp_destroy(kfsp_ctx *ctx)
     ctx->d_part.release(); ctx->d_stage.release(); ctx->d_H.release(); ctx->d_sq.release();
     ctx->d_y.release(); ctx->d_flag.release(); ctx->d_g.release(); ctx->d_dia.release();
     ctx->d_ell_adj.release(); ctx->d_ell_off.release(); ctx->d_ell_diag.release(); ctx->d_cnt.release();
-    ctx->d_ticket.release(); ctx->d_slot.release(); ctx->d_scan.release();
+    ctx->d_ticket.release(); ctx->d_slot.release(); ctx->d_scan.release(); ctx->d_strip.release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -541,6 +601,7 @@ int kfsp_comm_init(kfsp_ctx *ctx, int nranks, int rank, const void *id_bytes)
         ctx->use_comm = true;
     }
     ctx->ldv = 0;   // force re-layout on the next matrix
+    ctx->use_halo = false;
     return 0;
 }
 
@@ -582,7 +643,8 @@ int kfsp_set_matrix_ell(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, const 
 
     if (!ctx->opt_host_build && !ctx->want_csr) {
         // the arrays go to HBM verbatim and are transposed there (kfsp_build.hip)
-        const int rc = build_from_ell_device(ctx, n, bw, ld, adj, offdiag, diag);
+        int rc = build_from_ell_device(ctx, n, bw, ld, adj, offdiag, diag);
+        if (!rc) rc = setup_exchange(ctx);
         ctx->have_csr = false;
         ctx->t_ms[KFSP_T_UPLOAD] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         return rc;
@@ -627,6 +689,7 @@ int kfsp_set_matrix_ell(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, const 
     S.nnz = nnz;
     if (int rc = upload_sell(ctx, S)) return rc;
     if (int rc = maybe_upload_dia(ctx, S, cnt)) return rc;
+    if (int rc = setup_exchange(ctx)) return rc;
     ctx->have_csr = false;
     if (ctx->want_csr)
         if (int rc = upload_csr_from_sell(ctx, S, cnt)) return rc;
@@ -678,6 +741,7 @@ int kfsp_set_matrix_csr(kfsp_ctx *ctx, int64_t n, int64_t row0, int64_t nrows, c
     S.nnz = rowptr[nloc];
     if (int rc = upload_sell(ctx, S)) return rc;
     if (int rc = maybe_upload_dia(ctx, S, cnt)) return rc;
+    if (int rc = setup_exchange(ctx)) return rc;
     ctx->have_csr = false;
     if (ctx->want_csr)
         if (int rc = upload_csr_from_sell(ctx, S, cnt)) return rc;
@@ -737,7 +801,7 @@ int kfsp_begin_step(kfsp_ctx *ctx, double *beta)
     HIP_TRY(hipSetDevice(ctx->device));
     double *part = next_partial(ctx);
     const int g = vec_grid(ctx);
-    launch_copy_nrm2(g, act_pairs(ctx), ctx->d_w.p, ctx->d_V.p, part, ctx->stream);
+    launch_copy_nrm2(g, act_pairs(ctx), ctx->d_w.p, vcol(ctx, 0), part, ctx->stream);
     Pending s;
     if (int rc = publish(ctx, Pending{part, g}, &s)) return rc;
     double *hb = ctx->d_H.p + (size_t)kMH * kMH;   // scratch pair behind the H image
@@ -766,7 +830,7 @@ int kfsp_arnoldi(kfsp_ctx *ctx, int m, int jold, int qiop, double break_tol, dou
     const int64_t ldv = ctx->ldv;
     const int gs = spmv_grid(ctx), gv = vec_grid(ctx);
     const bool nt = use_nt(ctx);
-    double *V = ctx->d_V.p, *Hd = ctx->d_H.p, *sq = ctx->d_sq.p;
+    double *V = vcol(ctx, 0), *Hd = ctx->d_H.p, *sq = ctx->d_sq.p;
     int *flag = ctx->d_flag.p;
     HIP_TRY(hipMemsetAsync(flag, 0, sizeof(int), st));
     // entries this pass will not write must not look like a breakdown
@@ -920,7 +984,7 @@ int kfsp_combine(kfsp_ctx *ctx, int mx, double beta, const double *y, double *ws
     a.npairs = act_pairs(ctx);
     a.mx = mx;
     a.beta = beta;
-    a.V = ctx->d_V.p;
+    a.V = vcol(ctx, 0);
     a.ldv = ctx->ldv;
     a.sq = ctx->d_sq.p;
     a.y = ctx->d_y.p;
@@ -943,7 +1007,7 @@ int kfsp_restore_w(kfsp_ctx *ctx, double beta)
     if (!ctx) return -1;
     if (ctx->ldv == 0) return fail(ctx, -1, "no matrix set");
     HIP_TRY(hipSetDevice(ctx->device));
-    launch_scale_copy(vec_grid(ctx), act_pairs(ctx), ctx->d_V.p, ctx->d_sq.p + 1, beta, ctx->d_w.p, ctx->stream);
+    launch_scale_copy(vec_grid(ctx), act_pairs(ctx), vcol(ctx, 0), ctx->d_sq.p + 1, beta, ctx->d_w.p, ctx->stream);
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return 0;
 }
@@ -1002,7 +1066,14 @@ int kfsp_spmv_w(kfsp_ctx *ctx, double *y)
     if (ctx->ldv == 0) return fail(ctx, -1, "no matrix set");
     if (!y && ctx->nloc > 0) return fail(ctx, -2, "null y");
     HIP_TRY(hipSetDevice(ctx->device));
-    if (int rc = spmv_plain(ctx, ctx->d_w.p, false, ctx->d_tmp.p)) return rc;
+    const double *src = ctx->d_w.p;
+    if (ctx->use_halo) {
+        // w carries no halo margins: stage it in the scratch column
+        double *scratch = vcol(ctx, kNumCols - 1);
+        HIP_TRY(hipMemcpyAsync(scratch, ctx->d_w.p, (size_t)ctx->L * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        src = scratch;
+    }
+    if (int rc = spmv_plain(ctx, src, false, ctx->d_tmp.p)) return rc;
     if (ctx->nloc > 0)
         HIP_TRY(hipMemcpyAsync(y, ctx->d_tmp.p, (size_t)ctx->nloc * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -1041,7 +1112,7 @@ int kfsp_get_basis(kfsp_ctx *ctx, int j, int64_t nlocal, double *v)
     double sq = 0.0;
     HIP_TRY(hipMemcpyAsync(&sq, ctx->d_sq.p + j, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     if (nlocal > 0)
-        HIP_TRY(hipMemcpyAsync(v, ctx->d_V.p + (size_t)(j - 1) * ctx->ldv, (size_t)nlocal * sizeof(double),
+        HIP_TRY(hipMemcpyAsync(v, vcol(ctx, j - 1), (size_t)nlocal * sizeof(double),
                                hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     const double s = 1.0 / std::sqrt(sq);
@@ -1086,8 +1157,8 @@ int kfsp_spmv_bench(kfsp_ctx *ctx, int reps, int variant, float *ms_total)
     if (!ms_total) return fail(ctx, -4, "null ms_total");
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    const double *src = ctx->d_V.p;
-    double *dst = ctx->d_V.p + ctx->ldv;
+    const double *src = vcol(ctx, 0);
+    double *dst = vcol(ctx, 1);
     HIP_TRY(hipEventRecord(ctx->ev0, st));
     for (int r = 0; r < reps; ++r) {
         if (variant != 1) {
@@ -1156,6 +1227,7 @@ int kfsp_set_option(kfsp_ctx *ctx, const char *name, int64_t value)
     else if (k == "format") ctx->opt_format = value;
     else if (k == "fused_ortho") ctx->opt_fused = value;
     else if (k == "host_build") ctx->opt_host_build = value;
+    else if (k == "halo") ctx->opt_halo = value;
     else return fail(ctx, -2, "unknown option");
     return 0;
 }

@@ -56,6 +56,13 @@ struct kfsp_ctx {
     int nranks = 1, rank = 0;
     ncclComm_t comm = nullptr;
     bool use_comm = false;   // collectives on the data path (nranks > 1, or a 1-rank communicator for testing)
+    // halo exchange instead of the full all-gather (banded generators only):
+    // every basis column carries `margin` rows on either side that receive the
+    // neighbours' boundary strips, so the product kernel reads x in place
+    bool use_halo = false;
+    int64_t halo = 0;        // rows needed from each neighbour = max |delta|, agreed by all ranks
+    int64_t margin = 0;      // rows reserved on either side of every column (>= halo)
+    DevBuf<double> d_strip;  // [2*halo] send + [nranks*2*halo] receive
 
     // sizes
     int64_t n = 0;        // global states
@@ -112,6 +119,7 @@ struct kfsp_ctx {
     int64_t opt_nt = -1;    // -1 auto, 0 off, 1 on
     int64_t opt_format = 0; // 0 auto (DIA when banded), 1 always SELL
     int64_t opt_fused = 1;  // 1: one-pass IOP(2) orthogonalisation (k_ortho2)
+    int64_t opt_halo = 1;         // 0: always all-gather the whole source vector
     int64_t opt_host_build = 0;   // 1: transpose reference-layout input on the host (A/B testing)
     double t_ms[KFSP_T_COUNT] = {0, 0, 0, 0, 0, 0};
 };

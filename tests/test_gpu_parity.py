@@ -421,3 +421,28 @@ def test_one_rank_communicator_runs_the_collective_path(oracle):
     adj, off, diag = mdl.ell()
     wref, _ = oracle.expv_fixed(oracle.EllMatrix(adj, off, diag), p0, 20, 0.01, 3)
     assert np.abs(out[1][4] - wref).sum() < 1e-10
+
+
+def test_one_rank_communicator_halo_layout(oracle):
+    """Banded generator + communicator: basis columns get halo margins, every
+    product packs / all-gathers the boundary strips.  With one rank there is no
+    neighbour, so the result must equal the plain path bit for bit; the
+    all-gather fallback (option halo=0) likewise."""
+    from krylovfspssa_amd import KfspContext, synth
+    mdl = synth.toggle(300, 211)
+    rp, cc, vv = mdl.csr_rows()
+    p0 = synth.poisson_p0(mdl, 25.0)
+    res = []
+    for mode in ("plain", "halo", "allgather"):
+        with KfspContext(0) as c:
+            if mode != "plain":
+                c.comm_init(1, 0, KfspContext.unique_id())
+            if mode == "allgather":
+                c.set_option("halo", 0)
+            c.set_matrix_csr(mdl.n, rp, cc, vv)
+            c.set_vector(p0)
+            y = c.spmv_w()
+            ws = c.expv_fixed(25, 0.01, 2)
+            res.append((y, ws.copy(), c.get_vector()))
+    for r in res[1:]:
+        assert np.array_equal(r[0], res[0][0]) and np.array_equal(r[1], res[0][1]) and np.array_equal(r[2], res[0][2])

@@ -47,8 +47,36 @@ def _worker(rank, world, port, dims, m, out):
             dist.all_reduce(t)
             return float(t.item())
 
-        def spmv(slab):                                       # gather, then local rows
-            return O.spmv_csr(rowptr, col, val, allgather(slab))
+        # halo exchange of the banded case (kfsp_api.cpp gather_source): every rank
+        # contributes [first HALO rows | last HALO rows], one all-gather of the strips,
+        # the previous rank's LAST and the next rank's FIRST strip go into the
+        # margins; the product then only reads global indices in
+        # [row0 - HALO, row0 + L + HALO)
+        HALO = int(np.max(np.abs(col - np.repeat(np.arange(row0, row0 + nrows), np.diff(rowptr))))) if nrows else 1
+        HALO = -(-max(HALO, 1) // 8) * 8
+
+        def halo_gather(slab):
+            full = np.zeros(L)
+            full[:nrows] = slab
+            send = torch.from_numpy(np.concatenate([full[:HALO], full[L - HALO:]]))
+            recv = torch.zeros(world * 2 * HALO, dtype=torch.float64)
+            dist.all_gather_into_tensor(recv, send)
+            recv = recv.numpy()
+            xg = np.full(world * L + 2 * HALO, np.nan)          # NaN = never delivered
+            base = HALO                                          # xg[base + g] holds global index g
+            xg[base + row0:base + row0 + L] = full
+            if rank > 0:
+                xg[base + row0 - HALO:base + row0] = recv[(rank - 1) * 2 * HALO + HALO:(rank - 1) * 2 * HALO + 2 * HALO]
+            if rank + 1 < world:
+                xg[base + row0 + L:base + row0 + L + HALO] = recv[(rank + 1) * 2 * HALO:(rank + 1) * 2 * HALO + HALO]
+            return xg[base:]
+
+        def spmv(slab):                                       # exchange, then local rows
+            y = O.spmv_csr(rowptr, col, val, allgather(slab))
+            if HALO <= L:
+                yh = O.spmv_csr(rowptr, col, val, halo_gather(slab))
+                assert np.array_equal(y, yh), "halo exchange delivers a different source vector"
+            return y
 
         p0 = synth.poisson_p0(mdl, 6.0)[row0:row0 + nrows]
         beta = np.sqrt(allsum(float(p0 @ p0)))
