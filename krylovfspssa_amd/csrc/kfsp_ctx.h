@@ -12,7 +12,7 @@
 
 namespace kfsp {
 
-constexpr int kNumPartial = 4;   // rotating block-partial buffers
+constexpr int kNumPartial = 8;   // rotating block-partial buffers: a kernel never writes one of the last 7 it may read
 constexpr int kNumStage = 8;     // rotating all-reduce staging scalars
 
 template <class T>
