@@ -60,7 +60,9 @@ int nccl_fail(kfsp_ctx *c, ncclResult_t r, const char *where)
 
 int spmv_grid(const kfsp_ctx *c)
 {
-    int64_t g = round_up((c->nchunks + 3) / 4, 8);
+    // a wavefront trip covers 64 rows (SELL) or 128 rows (banded, two rows per lane)
+    const int64_t trips = c->use_dia ? (c->nchunks + 1) / 2 : c->nchunks;
+    int64_t g = round_up((trips + 3) / 4, 8);
     // 1024 workgroups (4 per CU, 16 waves per CU) already saturate HBM with the
     // 5-9 independent loads a lane keeps in flight, and halve the partial sums
     // every consumer has to re-add (measured: profiles/r01_sweep.log)
@@ -293,7 +295,8 @@ int upload_sell(kfsp_ctx *ctx, const HostSell &S)
     HIP_TRY(ctx->d_off.reserve(S.off.size(), false));
     HIP_TRY(ctx->d_col.reserve(std::max<size_t>(S.col.size(), 64), false));
     HIP_TRY(ctx->d_val.reserve(std::max<size_t>(S.val.size(), 64), false));
-    HIP_TRY(ctx->d_diag.reserve(std::max<size_t>(S.diag.size(), 64), false));
+    HIP_TRY(ctx->d_diag.reserve(S.diag.size() + 2 * kChunk, false));
+    HIP_TRY(hipMemsetAsync(ctx->d_diag.p, 0, (S.diag.size() + 2 * kChunk) * sizeof(double), ctx->stream));
     HIP_TRY(hipMemcpyAsync(ctx->d_off.p, S.off.data(), S.off.size() * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
     if (!S.col.empty()) {
         HIP_TRY(hipMemcpyAsync(ctx->d_col.p, S.col.data(), S.col.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
@@ -332,7 +335,7 @@ int maybe_upload_dia(kfsp_ctx *ctx, const HostSell &S, const std::vector<int32_t
     }
     if (nd == 0 || (double)nd * (double)nloc > 1.25 * (double)nnz_off + 1024.0) return 0;
     std::sort(delta, delta + nd);
-    const int64_t ld = ctx->nchunks * kChunk;
+    const int64_t ld = round_up(ctx->nchunks * kChunk, 2 * kChunk);   // the banded kernel works on 128-row groups
     std::vector<double> val((size_t)nd * (size_t)ld, 0.0);
     for (int64_t r = 0; r < nloc; ++r) {
         const int64_t c = r / kChunk, l = r % kChunk, o = S.off[(size_t)c];

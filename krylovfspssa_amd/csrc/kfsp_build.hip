@@ -264,7 +264,8 @@ int build_from_ell_device(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, cons
     }
     ctx->nchunks = nchunks;
     ctx->nnz = nloc + (int64_t)res.nnz_off;
-    HIP_TRY_B(ctx->d_diag.reserve((size_t)std::max<int64_t>(nact, 64), false));
+    const int64_t nact2 = round_up(nact, 2 * kChunk);      // the banded kernel works on 128-row groups
+    HIP_TRY_B(ctx->d_diag.reserve((size_t)std::max<int64_t>(nact2, 128), false));
 
     // banded?  every used slot is one constant shift, and the diagonals are full enough
     int nd = 0;
@@ -290,20 +291,20 @@ int build_from_ell_device(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, cons
             D.delta[d] = dl[d].first;
             slot_of[d] = dl[d].second;
         }
-        D.ld = nact;
+        D.ld = nact2;
         D.n = n;
         D.nchunks = nchunks;
         D.val = nullptr;
         D.diag = nullptr;
-        HIP_TRY_B(ctx->d_dia.reserve((size_t)nd * (size_t)nact, false));
+        HIP_TRY_B(ctx->d_dia.reserve((size_t)nd * (size_t)nact2, false));
         HIP_TRY_B(ctx->d_slot.reserve(kMaxDiag, false));
         HIP_TRY_B(hipMemcpyAsync(ctx->d_slot.p, slot_of, sizeof(int) * (size_t)nd, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_ell_to_dia, dim3((int)((nact + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, (int64_t)n,
+        hipLaunchKernelGGL(k_ell_to_dia, dim3((int)((nact2 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, (int64_t)n,
                            (int)ld, ctx->d_ell_adj.p, ctx->d_ell_off.p, ctx->d_ell_diag.p, row0, nloc, nd, D,
                            ctx->d_slot.p, ctx->d_dia.p, ctx->d_diag.p);
         HIP_TRY_B(hipStreamSynchronize(st));
         ctx->nd = nd;
-        ctx->dia_ld = nact;
+        ctx->dia_ld = nact2;
         for (int d = 0; d < nd; ++d) ctx->delta[d] = D.delta[d];
         ctx->use_dia = true;
         ctx->slots = 0;

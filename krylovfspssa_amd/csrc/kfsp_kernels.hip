@@ -139,33 +139,55 @@ __device__ __forceinline__ double row_sell(const SellDev &A, const double *__res
     return sum;
 }
 
+typedef double d2 __attribute__((ext_vector_type(2)));
+
 template <bool NT>
-__device__ __forceinline__ double row_dia(const DiaDev &D, const double *__restrict__ xg, int64_t row0,
-                                          int64_t c, int lane)
+__device__ __forceinline__ d2 ld_stream2(const double *p)
 {
-    const int64_t r = (c << 6) + lane;
+    if (NT) return __builtin_nontemporal_load(reinterpret_cast<const d2 *>(p));
+    return *reinterpret_cast<const d2 *>(p);
+}
+
+// Banded form, TWO consecutive rows per lane (a wavefront covers 128 rows): the
+// value streams - the bulk of the traffic - are read 16 B per lane, which is
+// worth ~9 % of HBM rate over 8 B per lane (profiles/r01_stream_widths.log).
+// x is read as two 8-B loads (shifted by delta, so not 16-B aligned in
+// general; it is served from L2 anyway).
+template <bool NT>
+__device__ __forceinline__ d2 rows_dia(const DiaDev &D, const double *__restrict__ xg, int64_t row0,
+                                       int64_t c, int lane)
+{
+    const int64_t r = (c << 7) + 2 * lane;
     const int64_t g = row0 + r;
     const int64_t last = D.n - 1;
     const double *vp = D.val + r;
-    double sum = -ld_stream<NT>(D.diag + r) * xg[g < last ? g : last];
+    const d2 dg = ld_stream2<NT>(D.diag + r);
+    d2 sum;
+    sum.x = -dg.x * xg[g < last ? g : last];
+    sum.y = -dg.y * xg[g + 1 < last ? g + 1 : last];
     int d = 0;
-    for (; d + 4 <= D.nd; d += 4) {
-        const double v0 = ld_stream<NT>(vp + (int64_t)(d + 0) * D.ld), v1 = ld_stream<NT>(vp + (int64_t)(d + 1) * D.ld);
-        const double v2 = ld_stream<NT>(vp + (int64_t)(d + 2) * D.ld), v3 = ld_stream<NT>(vp + (int64_t)(d + 3) * D.ld);
-        int64_t i0 = g + D.delta[d + 0], i1 = g + D.delta[d + 1], i2 = g + D.delta[d + 2], i3 = g + D.delta[d + 3];
+    for (; d + 2 <= D.nd; d += 2) {
+        const d2 v0 = ld_stream2<NT>(vp + (int64_t)(d + 0) * D.ld);
+        const d2 v1 = ld_stream2<NT>(vp + (int64_t)(d + 1) * D.ld);
+        int64_t i0 = g + D.delta[d + 0], i1 = g + D.delta[d + 1];
+        int64_t j0 = i0 + 1, j1 = i1 + 1;
         i0 = i0 < 0 ? 0 : (i0 > last ? last : i0);
+        j0 = j0 < 0 ? 0 : (j0 > last ? last : j0);
         i1 = i1 < 0 ? 0 : (i1 > last ? last : i1);
-        i2 = i2 < 0 ? 0 : (i2 > last ? last : i2);
-        i3 = i3 < 0 ? 0 : (i3 > last ? last : i3);
-        sum += v0 * xg[i0];
-        sum += v1 * xg[i1];
-        sum += v2 * xg[i2];
-        sum += v3 * xg[i3];
+        j1 = j1 < 0 ? 0 : (j1 > last ? last : j1);
+        sum.x += v0.x * xg[i0];
+        sum.y += v0.y * xg[j0];
+        sum.x += v1.x * xg[i1];
+        sum.y += v1.y * xg[j1];
     }
     for (; d < D.nd; ++d) {
+        const d2 v0 = ld_stream2<NT>(vp + (int64_t)d * D.ld);
         int64_t i0 = g + D.delta[d];
+        int64_t j0 = i0 + 1;
         i0 = i0 < 0 ? 0 : (i0 > last ? last : i0);
-        sum += ld_stream<NT>(vp + (int64_t)d * D.ld) * xg[i0];
+        j0 = j0 < 0 ? 0 : (j0 > last ? last : j0);
+        sum.x += v0.x * xg[i0];
+        sum.y += v0.y * xg[j0];
     }
     return sum;
 }
@@ -180,7 +202,8 @@ __global__ __launch_bounds__(kBlock) void k_spmv(SpmvArgs a)
         if (*a.brk_flag) return;
     }
 
-    const int64_t nchunks = DIA ? a.D.nchunks : a.A.nchunks;
+    // SELL: one 64-row chunk per wavefront trip; DIA: one 128-row group
+    const int64_t nchunks = DIA ? (a.D.nchunks + 1) >> 1 : a.A.nchunks;
     const int xcd = blockIdx.x & 7;
     const int slot = blockIdx.x >> 3;
     const int bx = gridDim.x >> 3;                        // workgroups per XCD
@@ -190,10 +213,13 @@ __global__ __launch_bounds__(kBlock) void k_spmv(SpmvArgs a)
     const int64_t cstep = (int64_t)bx * 4;
     int64_t c = cbeg + (int64_t)slot * 4 + wave;
 
-    // The first chunk's row sums are started before the pending norm is
+    // The first trip's row sums are started before the pending norm is
     // finished: the partial-sum round trip overlaps the first generator loads.
-    double sum = 0.0;
-    if (c < cend) sum = DIA ? row_dia<NT>(a.D, a.xg, a.row0, c, lane) : row_sell<NT>(a.A, a.xg, a.row0, c, lane);
+    d2 sum = {0.0, 0.0};
+    if (c < cend) {
+        if (DIA) sum = rows_dia<NT>(a.D, a.xg, a.row0, c, lane);
+        else sum.x = row_sell<NT>(a.A, a.xg, a.row0, c, lane);
+    }
 
     double s = 1.0;
     if (MODE != 0) {
@@ -212,14 +238,41 @@ __global__ __launch_bounds__(kBlock) void k_spmv(SpmvArgs a)
 
     double acc = 0.0, acc2 = 0.0;
     while (c < cend) {
-        const int64_t r = (c << 6) + lane;
-        if (MODE != 0) sum *= s;
-        a.y[r] = sum;
-        if (MODE == 1 || MODE == 3) acc += a.udot[r] * sum;
-        if (MODE == 2) acc += sum * sum;
-        if (MODE == 3) acc2 += a.udot2[r] * sum;
+        if (DIA) {
+            const int64_t r = (c << 7) + 2 * lane;
+            if (MODE != 0) {
+                sum.x *= s;
+                sum.y *= s;
+            }
+            *reinterpret_cast<d2 *>(a.y + r) = sum;
+            if (MODE == 1 || MODE == 3) {
+                const d2 u = *reinterpret_cast<const d2 *>(a.udot + r);
+                acc += u.x * sum.x;
+                acc += u.y * sum.y;
+            }
+            if (MODE == 2) {
+                acc += sum.x * sum.x;
+                acc += sum.y * sum.y;
+            }
+            if (MODE == 3) {
+                const d2 u = *reinterpret_cast<const d2 *>(a.udot2 + r);
+                acc2 += u.x * sum.x;
+                acc2 += u.y * sum.y;
+            }
+        } else {
+            const int64_t r = (c << 6) + lane;
+            double v = sum.x;
+            if (MODE != 0) v *= s;
+            a.y[r] = v;
+            if (MODE == 1 || MODE == 3) acc += a.udot[r] * v;
+            if (MODE == 2) acc += v * v;
+            if (MODE == 3) acc2 += a.udot2[r] * v;
+        }
         c += cstep;
-        if (c < cend) sum = DIA ? row_dia<NT>(a.D, a.xg, a.row0, c, lane) : row_sell<NT>(a.A, a.xg, a.row0, c, lane);
+        if (c < cend) {
+            if (DIA) sum = rows_dia<NT>(a.D, a.xg, a.row0, c, lane);
+            else sum.x = row_sell<NT>(a.A, a.xg, a.row0, c, lane);
+        }
     }
     if (MODE == 3) {
         double dummy = 0.0;
@@ -529,7 +582,6 @@ void launch_scale_copy(int grid, int64_t npairs, const double *u, const double *
 // Reads n elements of width W bytes per lane (4, 8 or 16) in the SpMV's own
 // access shape (one contiguous 64-lane piece per wave instruction) and folds
 // them into one value per block, so the traffic is exactly n*W bytes read.
-typedef double d2v __attribute__((ext_vector_type(2)));
 template <class T>
 __global__ __launch_bounds__(kBlock) void k_stream_read(int64_t n, const T *__restrict__ p, double *__restrict__ sink)
 {
@@ -549,7 +601,7 @@ void launch_stream_read(int grid, int elem_bytes, int64_t nbytes, const void *p,
     else if (elem_bytes == 8)
         hipLaunchKernelGGL((k_stream_read<double>), dim3(grid), dim3(kBlock), 0, st, nbytes / 8, (const double *)p, sink);
     else
-        hipLaunchKernelGGL((k_stream_read<d2v>), dim3(grid), dim3(kBlock), 0, st, nbytes / 16, (const d2v *)p, sink);
+        hipLaunchKernelGGL((k_stream_read<d2>), dim3(grid), dim3(kBlock), 0, st, nbytes / 16, (const d2 *)p, sink);
 }
 
 }  // namespace kfsp

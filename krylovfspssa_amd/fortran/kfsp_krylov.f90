@@ -27,8 +27,12 @@ MODULE KRYLOVSOLVER
   TYPE(FINITE_STATE_PROJECTION), POINTER, SAVE, PRIVATE :: CUR_FSP => NULL()
   TYPE(CME_MODEL), POINTER, SAVE, PRIVATE :: CUR_MODEL => NULL()
   INTEGER, SAVE, PRIVATE :: CUR_TRACE = 0
+  ! wall seconds spent in the host state-space code of the current solve:
+  ! (1) DROP_STATES decision + compaction, (2) SSA_EXTENDER, (3) ONESTEP_EXTENDER,
+  ! (4) uploads of the changed FSP
+  DOUBLE PRECISION, SAVE, PRIVATE :: HOST_SEC(4) = 0.0D0
 
-  PRIVATE :: ENSURE_CONTEXT, UPLOAD_FSP, CHECK, CB_DROP, CB_EXPAND, CB_LOG
+  PRIVATE :: ENSURE_CONTEXT, UPLOAD_FSP, CHECK, CB_DROP, CB_EXPAND, CB_LOG, WALL
 
 CONTAINS
 
@@ -84,6 +88,7 @@ CONTAINS
     CALL ENSURE_CONTEXT()
     CALL SYSTEM_CLOCK(C0, CRATE)
     RC = KFSP_GET_TIMERS(CTX, TMS, 1_C_INT)
+    HOST_SEC = 0.0D0
     CUR_FSP => FSP
     CUR_MODEL => MODEL
     CUR_TRACE = ITRACE
@@ -114,10 +119,18 @@ CONTAINS
        PRINT '(A,I8,A,I8,A,I8,A,I6,A,I6)', ' KFSP STATS: NMULT =', LAST_SOLVE_STATS%NMULT, ' NEXPH =', &
             LAST_SOLVE_STATS%NEXPH, ' WSUM_EVALS =', LAST_SOLVE_STATS%N_WSUM, ' EXPANSIONS =', &
             LAST_SOLVE_STATS%N_EXPAND, ' DROP_CALLS =', LAST_SOLVE_STATS%N_DROP_CALLS
+       PRINT '(A,4(1X,A,F10.1))', ' KFSP HOST STATE-SPACE MS:', 'DROP_STATES', 1.0D3 * HOST_SEC(1), &
+            'SSA_EXTENDER', 1.0D3 * HOST_SEC(2), 'ONESTEP_EXTENDER', 1.0D3 * HOST_SEC(3), 'UPLOADS', 1.0D3 * HOST_SEC(4)
     ENDIF
   END SUBROUTINE DGEXPV_FSP
 
   ! ------------------------------------------------------------- plumbing
+
+  DOUBLE PRECISION FUNCTION WALL()
+    INTEGER(8) :: C, R
+    CALL SYSTEM_CLOCK(C, R)
+    WALL = DBLE(C) / DBLE(R)
+  END FUNCTION WALL
 
   SUBROUTINE ENSURE_CONTEXT()
     CHARACTER(LEN=16) :: ENV
@@ -160,7 +173,7 @@ CONTAINS
     INTEGER(C_INT64_T) :: N_NEW
     INTEGER(C_INT) :: RC
     DOUBLE PRECISION, ALLOCATABLE :: WLOC(:), AW(:)
-    DOUBLE PRECISION :: D
+    DOUBLE PRECISION :: D, T0
     LOGICAL :: CHANGED
     INTEGER :: N
     N = CUR_FSP%SIZE
@@ -170,10 +183,14 @@ CONTAINS
     RC = KFSP_SPMV_W(CTX, AW)
     IF (RC /= 0) RETURN
     D = DSUM
+    T0 = WALL()
     CALL DROP_STATES_CORE(WLOC, CUR_FSP, CUR_MODEL, D, AW, CHANGED)
+    HOST_SEC(1) = HOST_SEC(1) + (WALL() - T0)
     IF (CHANGED) THEN
        CUR_FSP%VECTOR(1:N) = WLOC
+       T0 = WALL()
        CALL UPLOAD_FSP(CUR_FSP, CUR_MODEL)
+       HOST_SEC(4) = HOST_SEC(4) + (WALL() - T0)
     ENDIF
     N_NEW = CUR_FSP%SIZE
     RC = 0
@@ -186,13 +203,19 @@ CONTAINS
     REAL(C_DOUBLE), VALUE :: T_SSA
     INTEGER(C_INT64_T) :: N_NEW
     INTEGER(C_INT) :: RC
-    DOUBLE PRECISION :: TS
+    DOUBLE PRECISION :: TS, T0, T1, T2
     RC = KFSP_GET_VECTOR(CTX, INT(CUR_FSP%SIZE, C_INT64_T), CUR_FSP%VECTOR)
     IF (RC /= 0) RETURN
     TS = T_SSA
+    T0 = WALL()
     CALL SSA_EXTENDER(TS, CUR_FSP, CUR_MODEL)
+    T1 = WALL()
     CALL ONESTEP_EXTENDER(CUR_FSP, CUR_MODEL)
+    T2 = WALL()
     CALL UPLOAD_FSP(CUR_FSP, CUR_MODEL)
+    HOST_SEC(2) = HOST_SEC(2) + (T1 - T0)
+    HOST_SEC(3) = HOST_SEC(3) + (T2 - T1)
+    HOST_SEC(4) = HOST_SEC(4) + (WALL() - T2)
     N_NEW = CUR_FSP%SIZE
     RC = 0
   END FUNCTION CB_EXPAND

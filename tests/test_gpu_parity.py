@@ -322,7 +322,7 @@ def test_generator_formats_and_ortho_variants_agree_with_oracle(oracle, opts):
             c.set_option(k, v)
         c.set_matrix_ell(adj, off, diag)
         info = c.matrix_info()
-        nact = -(-mdl.n // 64) * 64
+        nact = -(-mdl.n // 128) * 128
         assert info["slots"] == (6 * nact if opts["format"] == 0 else info["slots"])
         x = np.random.default_rng(1).random(mdl.n)
         y = c.spmv(x)
@@ -383,7 +383,7 @@ def test_device_build_detects_banded_generators(oracle):
             c.set_option("host_build", host_build)
             c.set_matrix_ell(adj, off, diag)
             out[host_build] = (c.spmv(x), c.matrix_info())
-    nact = -(-mdl.n // 64) * 64
+    nact = -(-mdl.n // 128) * 128
     assert out[0][1]["slots"] == out[1][1]["slots"] == 8 * nact           # 8 diagonals, no index array
     assert out[0][1]["nnz"] == out[1][1]["nnz"] == mdl.nnz()
     assert np.array_equal(out[0][0], out[1][0])
