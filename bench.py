@@ -218,7 +218,9 @@ def main():
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "kernel": "k_spmv", "avg_launch_ms": round(kern_ms, 5),
             "alg_bytes_per_launch": int(b_alg_local),
-            "note": "per-GPU algorithmic bytes (12 nnz + 20 N) / HIP-event time of the timed launches"
+            "note": "per-GPU algorithmic bytes (CSR figure 12 nnz + 20 N, SURVEY 8d) / HIP-event time of the timed "
+                    "launches; the banded kernel stores no column indices, so its real traffic (see traffic) is ~0.7x "
+                    "the algorithmic bytes and frac can approach or exceed 1"
                     + ("; includes the exchange of the source vector" if world > 1 else ""),
         },
         "input_generation_s": round(t_gen, 2),
