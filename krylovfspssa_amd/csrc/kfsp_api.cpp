@@ -3,6 +3,8 @@
 // RCCL row-partition plumbing and the host Pade exponential.
 #include "kfsp_ctx.h"
 
+#include <xmmintrin.h>
+
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -404,49 +406,110 @@ struct Dense {
     double operator()(int i, int j) const { return a[(size_t)j * m + i]; }
 };
 
-// C = alpha * A * B
+// C = alpha * A * B, column major.  Column j of C is a linear combination of
+// the columns of A; four of them are folded per sweep over the column and zero
+// coefficients are skipped (the Hessenberg matrices of the IOP process are
+// banded, only the squaring phase is dense).  The same body is compiled twice:
+// baseline x86-64 and AVX2+FMA, picked once at run time.
+#define KFSP_MATMUL_BODY                                                                      \
+    const int m = A.m;                                                                        \
+    const double *a = A.a.data();                                                             \
+    const double *b = B.a.data();                                                             \
+    double *c = C.a.data();                                                                   \
+    for (int j = 0; j < m; ++j) {                                                             \
+        double *__restrict__ cj = c + (size_t)j * m;                                          \
+        for (int i = 0; i < m; ++i) cj[i] = 0.0;                                              \
+        int idx[4];                                                                           \
+        double coef[4];                                                                       \
+        int nk = 0;                                                                           \
+        for (int k = 0; k <= m; ++k) {                                                        \
+            if (k < m) {                                                                      \
+                const double v = alpha * b[(size_t)j * m + k];                                \
+                if (v == 0.0) continue;                                                       \
+                idx[nk] = k;                                                                  \
+                coef[nk] = v;                                                                 \
+                ++nk;                                                                         \
+            }                                                                                 \
+            if (nk == 4 || (k == m && nk > 0)) {                                              \
+                for (int q = nk; q < 4; ++q) {                                                \
+                    idx[q] = idx[0];                                                          \
+                    coef[q] = 0.0;                                                            \
+                }                                                                             \
+                const double *__restrict__ a0 = a + (size_t)idx[0] * m;                       \
+                const double *__restrict__ a1 = a + (size_t)idx[1] * m;                       \
+                const double *__restrict__ a2 = a + (size_t)idx[2] * m;                       \
+                const double *__restrict__ a3 = a + (size_t)idx[3] * m;                       \
+                const double c0 = coef[0], c1 = coef[1], c2 = coef[2], c3 = coef[3];          \
+                for (int i = 0; i < m; ++i) cj[i] += (c0 * a0[i] + c1 * a1[i]) + (c2 * a2[i] + c3 * a3[i]); \
+                nk = 0;                                                                       \
+            }                                                                                 \
+        }                                                                                     \
+    }
+
+void matmul_base(double alpha, const Dense &A, const Dense &B, Dense &C) { KFSP_MATMUL_BODY }
+__attribute__((target("avx2,fma"))) void matmul_avx2(double alpha, const Dense &A, const Dense &B, Dense &C)
+{
+    KFSP_MATMUL_BODY
+}
+#undef KFSP_MATMUL_BODY
+
 void matmul(double alpha, const Dense &A, const Dense &B, Dense &C)
 {
-    const int m = A.m;
-    std::fill(C.a.begin(), C.a.end(), 0.0);
-    for (int j = 0; j < m; ++j)
-        for (int k = 0; k < m; ++k) {
-            const double b = alpha * B(k, j);
-            if (b == 0.0) continue;
-            const double *ak = &A.a[(size_t)k * m];
-            double *cj = &C.a[(size_t)j * m];
-            for (int i = 0; i < m; ++i) cj[i] += b * ak[i];
-        }
+    static const bool wide = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma");
+    if (wide) matmul_avx2(alpha, A, B, C);
+    else matmul_base(alpha, A, B, C);
 }
 
-// X <- Q^{-1} X by Gaussian elimination with row pivoting; false if singular
+// X <- Q^{-1} X: LU with row pivoting, then forward and back substitution, all
+// written as column operations (the matrices are column major, so every inner
+// loop runs over contiguous memory); false if singular.  Zero multipliers are
+// skipped: the Pade numerator / denominator of a banded H are banded.
 bool solve_in_place(Dense &Q, Dense &X)
 {
     const int m = Q.m;
+    double *q = Q.a.data();
+    double *x = X.a.data();
     for (int k = 0; k < m; ++k) {
+        double *qk = q + (size_t)k * m;
         int p = k;
         for (int i = k + 1; i < m; ++i)
-            if (std::fabs(Q(i, k)) > std::fabs(Q(p, k))) p = i;
-        if (Q(p, k) == 0.0) return false;
+            if (std::fabs(qk[i]) > std::fabs(qk[p])) p = i;
+        if (qk[p] == 0.0) return false;
         if (p != k)
             for (int j = 0; j < m; ++j) {
-                std::swap(Q(k, j), Q(p, j));
-                std::swap(X(k, j), X(p, j));
+                std::swap(q[(size_t)j * m + k], q[(size_t)j * m + p]);
+                std::swap(x[(size_t)j * m + k], x[(size_t)j * m + p]);
             }
+        const double inv = 1.0 / qk[k];
+        int last = k;                                    // last row with a non-zero multiplier
         for (int i = k + 1; i < m; ++i) {
-            const double f = Q(i, k) / Q(k, k);
+            qk[i] *= inv;
+            if (qk[i] != 0.0) last = i;
+        }
+        if (last == k) continue;
+        for (int j = k + 1; j < m; ++j) {                // trailing update, column by column
+            double *qj = q + (size_t)j * m;
+            const double f = qj[k];
             if (f == 0.0) continue;
-            Q(i, k) = 0.0;
-            for (int j = k + 1; j < m; ++j) Q(i, j) -= f * Q(k, j);
-            for (int j = 0; j < m; ++j) X(i, j) -= f * X(k, j);
+            for (int i = k + 1; i <= last; ++i) qj[i] -= qk[i] * f;
+        }
+        for (int j = 0; j < m; ++j) {                    // L^{-1} applied to the right-hand sides
+            double *xj = x + (size_t)j * m;
+            const double f = xj[k];
+            if (f == 0.0) continue;
+            for (int i = k + 1; i <= last; ++i) xj[i] -= qk[i] * f;
         }
     }
-    for (int j = 0; j < m; ++j)
-        for (int i = m - 1; i >= 0; --i) {
-            double s = X(i, j);
-            for (int k = i + 1; k < m; ++k) s -= Q(i, k) * X(k, j);
-            X(i, j) = s / Q(i, i);
+    for (int j = 0; j < m; ++j) {                        // U^{-1}, column-oriented back substitution
+        double *xj = x + (size_t)j * m;
+        for (int k = m - 1; k >= 0; --k) {
+            const double *qk = q + (size_t)k * m;
+            const double v = xj[k] / qk[k];
+            xj[k] = v;
+            if (v == 0.0) continue;
+            for (int i = 0; i < k; ++i) xj[i] -= qk[i] * v;
         }
+    }
     return true;
 }
 
@@ -463,6 +526,14 @@ int kfsp_padm(int ideg, int m, double t, const double *H, int ldh, double *E, in
     if (!H) return -4;
     if (ldh < m) return -5;
     if (!E) return -6;
+    // Entries of exp(tH) far from the band underflow during the squaring phase;
+    // subnormal operands make x86 arithmetic ~100x slower and carry no
+    // information here (|value| < 1e-307), so flush them for the duration of the call.
+    struct FlushSubnormals {
+        unsigned saved = _mm_getcsr();
+        FlushSubnormals() { _mm_setcsr(saved | 0x8040u); }
+        ~FlushSubnormals() { _mm_setcsr(saved); }
+    } flush_guard;
     Dense A(m);
     double hnorm = 0.0;
     for (int i = 0; i < m; ++i) {
