@@ -95,14 +95,16 @@ CONTAINS
   END FUNCTION LEGAL
 
   PURE INTEGER(8) FUNCTION STATE_HASH(X)
+    ! multiplicative hash of the coordinates; H < 2**40 and the multiplier
+    ! < 2**20, so the 64-bit product never overflows
     INTEGER, INTENT(IN) :: X(:)
-    INTEGER(8), PARAMETER :: P = 2305843009213693951_8      ! 2**61 - 1
+    INTEGER(8), PARAMETER :: MASK40 = 1099511627775_8     ! 2**40 - 1
     INTEGER(8) :: H
     INTEGER :: K
     H = 1469598103_8
     DO K = 1, SIZE(X)
-       ! stays below 2**61 * 2**1: no overflow in 64 bits
-       H = MOD(MOD(H, 2147483647_8) * 1000003_8 + INT(X(K), 8) + 1_8 + ISHFT(H, -31), P)
+       H = IAND(H * 1000003_8 + INT(X(K), 8) + 1_8, MASK40)
+       H = IEOR(H, ISHFT(H, -17))
     ENDDO
     STATE_HASH = H
   END FUNCTION STATE_HASH
@@ -114,7 +116,8 @@ CONTAINS
     INTEGER, INTENT(IN) :: X(:)
     INTEGER, INTENT(OUT) :: IDX, SLOT
     INTEGER(8), INTENT(OUT) :: H
-    INTEGER :: MASK, J
+    INTEGER :: MASK, J, K
+    LOGICAL :: SAME
     H = STATE_HASH(X)
     MASK = FSP%KTLEN - 1
     SLOT = INT(IAND(H, INT(MASK, 8))) + 1
@@ -125,7 +128,14 @@ CONTAINS
           RETURN
        ENDIF
        IF (FSP%KEYTAB(SLOT) == H) THEN
-          IF (ALL(FSP%STATE(1:SIZE(X), J) == X)) THEN
+          SAME = .TRUE.
+          DO K = 1, SIZE(X)
+             IF (FSP%STATE(K, J) /= X(K)) THEN
+                SAME = .FALSE.
+                EXIT
+             ENDIF
+          ENDDO
+          IF (SAME) THEN
              IDX = J
              RETURN
           ENDIF

@@ -1,0 +1,122 @@
+"""Edge cases and error behaviour of the C ABI on the device (status codes
+instead of exits, wide / irregular rows, other orthogonalisation windows)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from krylovfspssa_amd import KfspContext
+    c = KfspContext(0)
+    yield c
+    c.close()
+
+
+def _random_generator(n, bw, rng, fill=0.7):
+    """a random, unstructured 'reaction network' in the reference layout: every slot of
+    every state links to a random state, is outside the FSP (0) or illegal (-1)"""
+    adj = rng.integers(1, n + 1, size=(n, bw)).astype(np.int32)
+    u = rng.random((n, bw))
+    adj[u > fill] = 0
+    adj[u > 0.5 * (1 + fill)] = -1
+    off = rng.random((n, bw)) * 10.0
+    return adj, off, off.sum(axis=1)
+
+
+def test_bad_arguments_return_status_codes(ctx):
+    from krylovfspssa_amd import KfspError
+    rng = np.random.default_rng(0)
+    adj, off, diag = _random_generator(100, 3, rng)
+    bad = adj.copy()
+    bad[5, 1] = 101                                  # link beyond n
+    with pytest.raises(KfspError, match="-5"):
+        ctx.set_matrix_ell(bad, off, diag)
+    ctx.set_matrix_ell(adj, off, diag)
+    with pytest.raises(KfspError, match="-2"):
+        ctx.set_vector(np.ones(99))                  # not this rank's block length
+    ctx.set_vector(np.ones(100) / 100)
+    with pytest.raises(KfspError, match="-2"):
+        ctx.arnoldi(101)                             # m > M_MAX
+    with pytest.raises(KfspError, match="-2"):
+        ctx.get_basis(200)
+    with pytest.raises(KfspError, match="-2"):
+        ctx.combine(0, 1.0, np.ones(4))
+    with pytest.raises(KfspError):
+        ctx.dgexpv(0.0, 1e-4, 1e-8, 3)               # T = 0
+    with pytest.raises(KfspError):
+        ctx.dgexpv(1.0, -1.0, 1e-8, 3)               # FSPTOL <= 0
+    # the context is still usable afterwards
+    assert ctx.begin_step() == pytest.approx(0.1)
+
+
+@pytest.mark.parametrize("n,bw", [(2, 1), (3, 2), (65, 20), (1000, 33), (4097, 64)])
+def test_unstructured_generators_any_width(ctx, oracle, n, bw):
+    """rows with up to 64 incoming links, nothing banded: SELL path, device build"""
+    rng = np.random.default_rng(n * 131 + bw)
+    adj, off, diag = _random_generator(n, bw, rng)
+    A = oracle.EllMatrix(adj, off, diag)
+    ctx.set_matrix_ell(adj, off, diag)
+    assert ctx.matrix_info()["nnz"] == A.nnz()
+    x = rng.standard_normal(n)
+    y = ctx.spmv(x)
+    ref = oracle.spmv_ell(A, x)
+    scale = oracle.spmv_ell(oracle.EllMatrix(adj, np.abs(off), -np.abs(diag)), np.abs(x))
+    assert np.all(np.abs(y - ref) <= 1e-13 * scale + 1e-300)
+    assert np.array_equal(y, ctx.spmv(x))
+
+
+@pytest.mark.parametrize("qiop", [0, 1, 3, 5])
+def test_other_orthogonalisation_windows(ctx, oracle, golden_dir, qiop):
+    """QIOP is a constant 2 in the reference (KrylovSolver.f90:137) but the loop
+    (:241-246) is general: 0 = against every previous vector"""
+    import os
+    g = np.load(os.path.join(golden_dir, "solve_ring4.npz"))
+    A = oracle.EllMatrix(g["adj"], g["offdiag"], g["diag"])
+    w = g["in_vector"]
+    ctx.set_matrix_ell(g["adj"], g["offdiag"], g["diag"])
+    ctx.set_vector(w)
+    beta = ctx.begin_step()
+    m = 14
+    H, mb, k1, av = ctx.arnoldi(m, qiop=qiop)
+    V, Href, mbr, k1r, avr = oracle.arnoldi(A, w / beta, m, qiop=qiop)
+    assert (mb, k1) == (mbr, k1r)
+    assert np.abs(H - Href).max() <= 1e-11 * np.abs(Href).max()
+    assert av == pytest.approx(avr, rel=1e-10)
+
+
+def test_tiny_state_spaces(ctx, oracle):
+    """n = 3: Krylov dimension capped at n-1 by the solver (KrylovSolver.f90:211)"""
+    adj = np.array([[2, -1], [3, 1], [0, 2]], dtype=np.int32)
+    off = np.array([[2.0, 0.0], [1.0, 3.0], [0.5, 1.5]])
+    diag = off.sum(axis=1)
+    A = oracle.EllMatrix(adj, off, diag)
+    p0 = np.array([1.0, 0.0, 0.0])
+    ctx.set_matrix_ell(adj, off, diag)
+    ctx.set_vector(p0)
+    ws = ctx.expv_fixed(2, 0.05, 3)
+    wref, wsref = oracle.expv_fixed(A, p0, 2, 0.05, 3)
+    assert np.abs(ctx.get_vector() - wref).sum() < 1e-13 and np.abs(ws - wsref).max() < 1e-14
+
+
+def test_growing_and_shrinking_fsp_reuses_the_context(ctx, oracle, golden_dir):
+    """generator re-uploads of changing size (what every FSP change does): results never
+    depend on what an earlier, larger FSP left in device memory"""
+    import os
+    rng = np.random.default_rng(9)
+    names = ["assembly_goutsias_k16.npz", "assembly_toggle_k5.npz", "assembly_goutsias_k10.npz",
+             "assembly_repressilator_k10.npz", "assembly_goutsias_k16.npz"]
+    for name in names:
+        g = np.load(os.path.join(golden_dir, name))
+        n = int(g["n"])
+        A = oracle.EllMatrix(g["adj"], g["offdiag"], g["diag"])
+        ctx.set_matrix_ell(g["adj"], g["offdiag"], g["diag"])
+        w = rng.random(n)
+        w /= w.sum()
+        ctx.set_vector(w)
+        m = min(20, n - 1)
+        ws = ctx.expv_fixed(m, 1e-3, 2)
+        wref, wsref = oracle.expv_fixed(A, w, m, 1e-3, 2)
+        assert np.abs(ctx.get_vector() - wref).sum() < 1e-11
+        assert np.abs(ws - wsref).max() < 1e-12
