@@ -9,6 +9,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 
@@ -873,15 +874,36 @@ int kfsp_begin_step(kfsp_ctx *ctx, double *beta)
     if (!beta) return fail(ctx, -2, "null beta");
     PhaseTimer timer(ctx, KFSP_T_BEGIN);
     HIP_TRY(hipSetDevice(ctx->device));
+    const bool dbg = std::getenv("KFSP_DEBUG_SLOW") != nullptr;
+    auto lap = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - timer.t0).count(); };
+    double t_pre = 0, t_l1 = 0, t_l2 = 0, t_cp = 0;
+    if (dbg) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        t_pre = lap();
+    }
     double *part = next_partial(ctx);
     const int g = vec_grid(ctx);
     launch_copy_nrm2(g, act_pairs(ctx), ctx->d_w.p, vcol(ctx, 0), part, ctx->stream);
+    if (dbg) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        t_l1 = lap();
+    }
     Pending s;
     if (int rc = publish(ctx, Pending{part, g}, &s)) return rc;
     double *hb = ctx->d_H.p + (size_t)kMH * kMH;   // scratch pair behind the H image
     launch_finalize(s, ctx->d_sq.p + 1, hb, ctx->stream);
+    if (dbg) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        t_l2 = lap();
+    }
     HIP_TRY(hipMemcpyAsync(beta, hb, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (dbg) {
+        t_cp = lap();
+        if (t_cp > 2.0)
+            std::fprintf(stderr, "kfsp: slow begin_step n=%lld: pending %.2f, copy_nrm2 %.2f, finalize %.2f, d2h %.2f ms\n",
+                         (long long)ctx->n, t_pre, t_l1 - t_pre, t_l2 - t_l1, t_cp - t_l2);
+    }
     return 0;
 }
 
