@@ -213,10 +213,12 @@ int setup_exchange(kfsp_ctx *ctx)
     const int64_t H = round_up(std::max<int64_t>((int64_t)h[1], 1), 8);
     if (h[0] != 0.0 || H > ctx->L) return 0;                      // someone is not banded, or reach > one block
     ctx->halo = H;
-    if (H > ctx->margin) {
+    if (H + 2 * kChunk > ctx->margin) {
         // re-lay the basis with room for the strips (its contents are rebuilt by
         // the next begin_step anyway)
-        ctx->margin = round_up(H + H / 4, 64);
+        // + 128: the banded kernel works on 128-row groups, whose padded rows read up
+        // to one group beyond the block end
+        ctx->margin = round_up(H + H / 4 + 2 * kChunk, 64);
         if (int rc = resize(ctx, ctx->n)) return rc;
     }
     HIP_TRY(ctx->d_strip.reserve((size_t)(2 * H) * (size_t)(ctx->nranks + 1), true));
