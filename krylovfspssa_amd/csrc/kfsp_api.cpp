@@ -3,8 +3,6 @@
 // RCCL row-partition plumbing and the host Pade exponential.
 #include "kfsp_ctx.h"
 
-#include <xmmintrin.h>
-
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -400,200 +398,11 @@ int upload_csr_from_sell(kfsp_ctx *ctx, const HostSell &S, const std::vector<int
     return 0;
 }
 
-// ---- host dense exponential (dgpadm.f:2-169 semantics) -------------------
-struct Dense {
-    int m;
-    std::vector<double> a;
-    explicit Dense(int m_) : m(m_), a((size_t)m_ * m_, 0.0) {}
-    double &operator()(int i, int j) { return a[(size_t)j * m + i]; }
-    double operator()(int i, int j) const { return a[(size_t)j * m + i]; }
-};
-
-// C = alpha * A * B, column major.  Column j of C is a linear combination of
-// the columns of A; four of them are folded per sweep over the column and zero
-// coefficients are skipped (the Hessenberg matrices of the IOP process are
-// banded, only the squaring phase is dense).  The same body is compiled twice:
-// baseline x86-64 and AVX2+FMA, picked once at run time.
-#define KFSP_MATMUL_BODY                                                                      \
-    const int m = A.m;                                                                        \
-    const double *a = A.a.data();                                                             \
-    const double *b = B.a.data();                                                             \
-    double *c = C.a.data();                                                                   \
-    for (int j = 0; j < m; ++j) {                                                             \
-        double *__restrict__ cj = c + (size_t)j * m;                                          \
-        for (int i = 0; i < m; ++i) cj[i] = 0.0;                                              \
-        int idx[4];                                                                           \
-        double coef[4];                                                                       \
-        int nk = 0;                                                                           \
-        for (int k = 0; k <= m; ++k) {                                                        \
-            if (k < m) {                                                                      \
-                const double v = alpha * b[(size_t)j * m + k];                                \
-                if (v == 0.0) continue;                                                       \
-                idx[nk] = k;                                                                  \
-                coef[nk] = v;                                                                 \
-                ++nk;                                                                         \
-            }                                                                                 \
-            if (nk == 4 || (k == m && nk > 0)) {                                              \
-                for (int q = nk; q < 4; ++q) {                                                \
-                    idx[q] = idx[0];                                                          \
-                    coef[q] = 0.0;                                                            \
-                }                                                                             \
-                const double *__restrict__ a0 = a + (size_t)idx[0] * m;                       \
-                const double *__restrict__ a1 = a + (size_t)idx[1] * m;                       \
-                const double *__restrict__ a2 = a + (size_t)idx[2] * m;                       \
-                const double *__restrict__ a3 = a + (size_t)idx[3] * m;                       \
-                const double c0 = coef[0], c1 = coef[1], c2 = coef[2], c3 = coef[3];          \
-                for (int i = 0; i < m; ++i) cj[i] += (c0 * a0[i] + c1 * a1[i]) + (c2 * a2[i] + c3 * a3[i]); \
-                nk = 0;                                                                       \
-            }                                                                                 \
-        }                                                                                     \
-    }
-
-void matmul_base(double alpha, const Dense &A, const Dense &B, Dense &C) { KFSP_MATMUL_BODY }
-__attribute__((target("avx2,fma"))) void matmul_avx2(double alpha, const Dense &A, const Dense &B, Dense &C)
-{
-    KFSP_MATMUL_BODY
-}
-#undef KFSP_MATMUL_BODY
-
-void matmul(double alpha, const Dense &A, const Dense &B, Dense &C)
-{
-    static const bool wide = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma");
-    if (wide) matmul_avx2(alpha, A, B, C);
-    else matmul_base(alpha, A, B, C);
-}
-
-// X <- Q^{-1} X: LU with row pivoting, then forward and back substitution, all
-// written as column operations (the matrices are column major, so every inner
-// loop runs over contiguous memory); false if singular.  Zero multipliers are
-// skipped: the Pade numerator / denominator of a banded H are banded.
-bool solve_in_place(Dense &Q, Dense &X)
-{
-    const int m = Q.m;
-    double *q = Q.a.data();
-    double *x = X.a.data();
-    for (int k = 0; k < m; ++k) {
-        double *qk = q + (size_t)k * m;
-        int p = k;
-        for (int i = k + 1; i < m; ++i)
-            if (std::fabs(qk[i]) > std::fabs(qk[p])) p = i;
-        if (qk[p] == 0.0) return false;
-        if (p != k)
-            for (int j = 0; j < m; ++j) {
-                std::swap(q[(size_t)j * m + k], q[(size_t)j * m + p]);
-                std::swap(x[(size_t)j * m + k], x[(size_t)j * m + p]);
-            }
-        const double inv = 1.0 / qk[k];
-        int last = k;                                    // last row with a non-zero multiplier
-        for (int i = k + 1; i < m; ++i) {
-            qk[i] *= inv;
-            if (qk[i] != 0.0) last = i;
-        }
-        if (last == k) continue;
-        for (int j = k + 1; j < m; ++j) {                // trailing update, column by column
-            double *qj = q + (size_t)j * m;
-            const double f = qj[k];
-            if (f == 0.0) continue;
-            for (int i = k + 1; i <= last; ++i) qj[i] -= qk[i] * f;
-        }
-        for (int j = 0; j < m; ++j) {                    // L^{-1} applied to the right-hand sides
-            double *xj = x + (size_t)j * m;
-            const double f = xj[k];
-            if (f == 0.0) continue;
-            for (int i = k + 1; i <= last; ++i) xj[i] -= qk[i] * f;
-        }
-    }
-    for (int j = 0; j < m; ++j) {                        // U^{-1}, column-oriented back substitution
-        double *xj = x + (size_t)j * m;
-        for (int k = m - 1; k >= 0; --k) {
-            const double *qk = q + (size_t)k * m;
-            const double v = xj[k] / qk[k];
-            xj[k] = v;
-            if (v == 0.0) continue;
-            for (int i = 0; i < k; ++i) xj[i] -= qk[i] * v;
-        }
-    }
-    return true;
-}
-
 }  // namespace
 
 extern "C" {
 
 int kfsp_abi_version(void) { return kAbiVersion; }
-
-int kfsp_padm(int ideg, int m, double t, const double *H, int ldh, double *E, int *ns_out, double *hnorm_out)
-{
-    if (ideg < 1 || ideg > 20) return -1;
-    if (m < 1) return -2;
-    if (!H) return -4;
-    if (ldh < m) return -5;
-    if (!E) return -6;
-    // Entries of exp(tH) far from the band underflow during the squaring phase;
-    // subnormal operands make x86 arithmetic ~100x slower and carry no
-    // information here (|value| < 1e-307), so flush them for the duration of the call.
-    struct FlushSubnormals {
-        unsigned saved = _mm_getcsr();
-        FlushSubnormals() { _mm_setcsr(saved | 0x8040u); }
-        ~FlushSubnormals() { _mm_setcsr(saved); }
-    } flush_guard;
-    Dense A(m);
-    double hnorm = 0.0;
-    for (int i = 0; i < m; ++i) {
-        double rs = 0.0;
-        for (int j = 0; j < m; ++j) {
-            A(i, j) = H[(size_t)j * ldh + i];
-            rs += std::fabs(A(i, j));
-        }
-        hnorm = std::max(hnorm, rs);
-    }
-    hnorm = std::fabs(t * hnorm);
-    if (hnorm_out) *hnorm_out = hnorm;
-    if (hnorm == 0.0) return -3;   // 'null H', dgpadm.f:84
-    const int ns = std::max(0, (int)(std::log(hnorm) / std::log(2.0)) + 2);
-    if (ns_out) *ns_out = ns;
-    const double scale = t / std::ldexp(1.0, ns);
-
-    std::vector<double> c((size_t)ideg + 1);
-    c[0] = 1.0;
-    for (int k = 1; k <= ideg; ++k)
-        c[(size_t)k] = c[(size_t)k - 1] * (double)(ideg + 1 - k) / (double)(k * (2 * ideg + 1 - k));
-
-    Dense H2(m), P(m), Q(m), T(m);
-    matmul(scale * scale, A, A, H2);
-    for (int i = 0; i < m; ++i) {
-        P(i, i) = c[(size_t)ideg - 1];
-        Q(i, i) = c[(size_t)ideg];
-    }
-    // Horner in H2, alternately on the even (q) and odd (p) coefficient sets
-    bool odd = true;
-    for (int k = ideg - 1; k > 0; --k) {
-        Dense &U = odd ? Q : P;
-        matmul(1.0, U, H2, T);
-        for (int i = 0; i < m; ++i) T(i, i) += c[(size_t)k - 1];
-        std::swap(U.a, T.a);
-        odd = !odd;
-    }
-    {
-        Dense &U = odd ? Q : P;
-        matmul(scale, U, A, T);
-        std::swap(U.a, T.a);
-    }
-    for (size_t i = 0; i < Q.a.size(); ++i) Q.a[i] -= P.a[i];
-    if (!solve_in_place(Q, P)) return -7;
-    for (double &x : P.a) x *= 2.0;
-    for (int i = 0; i < m; ++i) P(i, i) += 1.0;
-    if (ns == 0 && odd) {
-        for (double &x : P.a) x = -x;
-    } else {
-        for (int k = 0; k < ns; ++k) {
-            matmul(1.0, P, P, T);
-            std::swap(P.a, T.a);
-        }
-    }
-    std::memcpy(E, P.a.data(), P.a.size() * sizeof(double));
-    return 0;
-}
 
 int kfsp_create(int device, kfsp_ctx **out)
 {
@@ -876,36 +685,15 @@ int kfsp_begin_step(kfsp_ctx *ctx, double *beta)
     if (!beta) return fail(ctx, -2, "null beta");
     PhaseTimer timer(ctx, KFSP_T_BEGIN);
     HIP_TRY(hipSetDevice(ctx->device));
-    const bool dbg = std::getenv("KFSP_DEBUG_SLOW") != nullptr;
-    auto lap = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - timer.t0).count(); };
-    double t_pre = 0, t_l1 = 0, t_l2 = 0, t_cp = 0;
-    if (dbg) {
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-        t_pre = lap();
-    }
     double *part = next_partial(ctx);
     const int g = vec_grid(ctx);
     launch_copy_nrm2(g, act_pairs(ctx), ctx->d_w.p, vcol(ctx, 0), part, ctx->stream);
-    if (dbg) {
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-        t_l1 = lap();
-    }
     Pending s;
     if (int rc = publish(ctx, Pending{part, g}, &s)) return rc;
     double *hb = ctx->d_H.p + (size_t)kMH * kMH;   // scratch pair behind the H image
     launch_finalize(s, ctx->d_sq.p + 1, hb, ctx->stream);
-    if (dbg) {
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-        t_l2 = lap();
-    }
     HIP_TRY(hipMemcpyAsync(beta, hb, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    if (dbg) {
-        t_cp = lap();
-        if (t_cp > 2.0)
-            std::fprintf(stderr, "kfsp: slow begin_step n=%lld: pending %.2f, copy_nrm2 %.2f, finalize %.2f, d2h %.2f ms\n",
-                         (long long)ctx->n, t_pre, t_l1 - t_pre, t_l2 - t_l1, t_cp - t_l2);
-    }
     return 0;
 }
 
