@@ -159,14 +159,18 @@ def main():
     if world > 1 or args.force_comm:
         from krylovfspssa_amd import host as _host
         L = _host.partition(mdl.n, world, rank)[2]
-        exchange = "halo strips (banded generator)"
-        if not distributed_product_ok():
-            # never report a number from a wrong product: fall back to the plain all-gather
-            ctx.set_option("halo", 0)
+        exchange = "halo strips (banded generator), overlapped with the interior rows when the block is large"
+        # never report a number from a wrong product: step down to the simpler exchanges
+        for opt, label in (("overlap", "halo strips, not overlapped (overlap self-check failed)"),
+                           ("halo", "all-gather of the whole vector (halo self-check failed)")):
+            if distributed_product_ok():
+                break
+            ctx.set_option(opt, 0)
             ctx.set_matrix_csr(mdl.n, rowptr, col, val)
             ctx.set_vector(x)
             ctx.begin_step()
-            exchange = "all-gather of the whole vector (halo self-check failed)"
+            exchange = label
+        else:
             if not distributed_product_ok():
                 exchange = "all-gather; SELF-CHECK FAILED"
         ctx.set_vector(x)

@@ -139,6 +139,88 @@ int publish(kfsp_ctx *ctx, Pending local, Pending *out)
     return 0;
 }
 
+int gather_source(kfsp_ctx *ctx, const double *src_local, const double **xg);
+int exchange_strips(kfsp_ctx *ctx, const double *src_local, hipStream_t st);
+
+int trips_grid(int64_t trips, int64_t cap)
+{
+    int64_t g = round_up((trips + 3) / 4, 8);
+    g = std::min<int64_t>(g, cap);
+    return (int)std::max<int64_t>(g, 8);
+}
+
+// One generator product y = (s) A x from the local source column `src` (or from
+// a full global vector when src_is_global).  `a` carries everything except the
+// source pointer, the trip range and the partial buffers.  With a banded
+// generator and a communicator the product is split: the interior trips, which
+// read no halo row, start at once on the compute stream while the strips are
+// exchanged on the communication stream; the few boundary trips follow once
+// the halo has landed.  p1/p2 receive the block partials (modes 1-3).
+int run_product(kfsp_ctx *ctx, int mode, SpmvArgs a, const double *src, bool src_is_global, Pending *p1, Pending *p2,
+                bool force_sell = false)
+{
+    hipStream_t st = ctx->stream;
+    const bool dia = ctx->use_dia && !force_sell;
+    const bool nt = use_nt(ctx);
+    const int64_t trips = dia ? (ctx->nchunks + 1) / 2 : ctx->nchunks;
+    const int64_t cap = ctx->opt_grid > 0 ? round_up(ctx->opt_grid, 8) : 1024;
+    double *P1 = mode != 0 ? next_partial(ctx) : nullptr;
+    double *P2 = mode == 3 ? next_partial(ctx) : nullptr;
+    a.row0 = ctx->row0;
+
+    const int64_t H = ctx->halo, L = ctx->L;
+    int64_t lo = 0, hi = 0;
+    bool split = !src_is_global && dia && ctx->use_halo && ctx->opt_overlap != 0 && ctx->comm_stream != nullptr;
+    if (split) {
+        lo = (H + 127) / 128;                        // first trip whose rows all lie >= H
+        hi = std::min<int64_t>((L - H) / 128, trips); // trips [lo, hi) end below L - H
+        // Three launches and two cross-stream waits cost ~10-15 us; that only pays once
+        // the product itself is several times longer (>= ~2M rows per rank), or when
+        // the caller insists (overlap = 2, used by the tests)
+        const int64_t min_trips = ctx->opt_overlap >= 2 ? 64 : 16384;
+        if (hi - lo < min_trips) split = false;
+    }
+    if (!split) {
+        const double *xg = src;
+        if (!src_is_global)
+            if (int rc = gather_source(ctx, src, &xg)) return rc;
+        a.xg = xg;
+        a.partial = P1;
+        a.partial2 = P2;
+        a.trip_begin = 0;
+        a.trip_end = trips;
+        const int g = trips_grid(trips, cap);
+        launch_spmv(mode, g, a, nt, dia, st);
+        if (p1) *p1 = Pending{P1, g};
+        if (p2) *p2 = Pending{P2, g};
+        return 0;
+    }
+    // exchange on the communication stream, behind everything that produced src
+    HIP_TRY(hipEventRecord(ctx->ev_src, st));
+    HIP_TRY(hipStreamWaitEvent(ctx->comm_stream, ctx->ev_src, 0));
+    if (int rc = exchange_strips(ctx, src, ctx->comm_stream)) return rc;
+    HIP_TRY(hipEventRecord(ctx->ev_halo, ctx->comm_stream));
+    a.xg = src - ctx->row0;
+    int used = 0;
+    auto launch_range = [&](int64_t b, int64_t e, int64_t gcap) {
+        if (e <= b) return;
+        const int g = trips_grid(e - b, gcap);
+        a.partial = P1 ? P1 + used : nullptr;
+        a.partial2 = P2 ? P2 + used : nullptr;
+        a.trip_begin = b;
+        a.trip_end = e;
+        launch_spmv(mode, g, a, nt, true, st);
+        used += g;
+    };
+    launch_range(lo, hi, std::min<int64_t>(cap, kMaxGrid - 512));   // interior: no halo row is read
+    HIP_TRY(hipStreamWaitEvent(st, ctx->ev_halo, 0));
+    launch_range(0, lo, 256);                                        // rows that read the previous rank's strip
+    launch_range(hi, trips, 256);                                    // rows that read the next rank's strip
+    if (p1) *p1 = Pending{P1, used};
+    if (p2) *p2 = Pending{P2, used};
+    return 0;
+}
+
 // Several scalars at once: one all-reduce for all of them.
 int publish_n(kfsp_ctx *ctx, const Pending *local, int k, Pending *out)
 {
@@ -157,6 +239,27 @@ int publish_n(kfsp_ctx *ctx, const Pending *local, int k, Pending *out)
 
 int resize(kfsp_ctx *ctx, int64_t n);
 
+// Banded generator: only the `halo` boundary rows of the two neighbours are ever
+// read.  Every rank contributes [its first halo rows | its last halo rows]; one
+// all-gather of these strips, then the two strips this rank needs are dropped
+// into the margins of the source column itself.  All on stream st.
+int exchange_strips(kfsp_ctx *ctx, const double *src_local, hipStream_t st)
+{
+    const int64_t H = ctx->halo, L = ctx->L;
+    double *send = ctx->d_strip.p, *recv = ctx->d_strip.p + 2 * H;
+    HIP_TRY(hipMemcpyAsync(send, src_local, (size_t)H * sizeof(double), hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(send + H, src_local + (L - H), (size_t)H * sizeof(double), hipMemcpyDeviceToDevice, st));
+    NCCL_TRY(ncclAllGather(send, recv, (size_t)(2 * H), ncclDouble, ctx->comm, st));
+    double *col = const_cast<double *>(src_local);
+    if (ctx->rank > 0)                 // the previous rank's LAST rows sit just below row 0
+        HIP_TRY(hipMemcpyAsync(col - H, recv + (size_t)(ctx->rank - 1) * 2 * H + H, (size_t)H * sizeof(double),
+                               hipMemcpyDeviceToDevice, st));
+    if (ctx->rank + 1 < ctx->nranks)   // the next rank's FIRST rows follow row L-1
+        HIP_TRY(hipMemcpyAsync(col + L, recv + (size_t)(ctx->rank + 1) * 2 * H, (size_t)H * sizeof(double),
+                               hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
 // The source column must be visible in full on every rank before a product.
 int gather_source(kfsp_ctx *ctx, const double *src_local, const double **xg)
 {
@@ -165,23 +268,7 @@ int gather_source(kfsp_ctx *ctx, const double *src_local, const double **xg)
         return 0;
     }
     if (ctx->use_halo) {
-        // Banded generator: only the `halo` boundary rows of the two neighbours are
-        // ever read.  Every rank contributes [its first halo rows | its last halo
-        // rows]; one all-gather of these strips, then the two strips this rank
-        // needs are dropped into the margins of the source column itself.
-        const int64_t H = ctx->halo, L = ctx->L;
-        hipStream_t st = ctx->stream;
-        double *send = ctx->d_strip.p, *recv = ctx->d_strip.p + 2 * H;
-        HIP_TRY(hipMemcpyAsync(send, src_local, (size_t)H * sizeof(double), hipMemcpyDeviceToDevice, st));
-        HIP_TRY(hipMemcpyAsync(send + H, src_local + (L - H), (size_t)H * sizeof(double), hipMemcpyDeviceToDevice, st));
-        NCCL_TRY(ncclAllGather(send, recv, (size_t)(2 * H), ncclDouble, ctx->comm, st));
-        double *col = const_cast<double *>(src_local);
-        if (ctx->rank > 0)                 // the previous rank's LAST rows sit just below row 0
-            HIP_TRY(hipMemcpyAsync(col - H, recv + (size_t)(ctx->rank - 1) * 2 * H + H, (size_t)H * sizeof(double),
-                                   hipMemcpyDeviceToDevice, st));
-        if (ctx->rank + 1 < ctx->nranks)   // the next rank's FIRST rows follow row L-1
-            HIP_TRY(hipMemcpyAsync(col + L, recv + (size_t)(ctx->rank + 1) * 2 * H, (size_t)H * sizeof(double),
-                                   hipMemcpyDeviceToDevice, st));
+        if (int rc = exchange_strips(ctx, src_local, ctx->stream)) return rc;
         *xg = src_local - ctx->row0;       // global index g lives at src_local[g - row0]
         return 0;
     }
@@ -436,7 +523,11 @@ int kfsp_destroy(kfsp_ctx *ctx)
     if (!ctx) return 0;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->comm_stream) (void)hipStreamSynchronize(ctx->comm_stream);
     if (ctx->comm) (void)ncclCommDestroy(ctx->comm);
+    if (ctx->ev_src) (void)hipEventDestroy(ctx->ev_src);
+    if (ctx->ev_halo) (void)hipEventDestroy(ctx->ev_halo);
+    if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);
     ctx->d_off.release(); ctx->d_col.release(); ctx->d_val.release(); ctx->d_diag.release();
     ctx->d_rowptr.release(); ctx->d_ccol.release(); ctx->d_cval.release(); ctx->d_tile.release();
     ctx->d_V.release(); ctx->d_w.release(); ctx->d_xg.release(); ctx->d_tmp.release();
@@ -485,6 +576,11 @@ int kfsp_comm_init(kfsp_ctx *ctx, int nranks, int rank, const void *id_bytes)
         std::memcpy(&id, id_bytes, sizeof(id));
         NCCL_TRY(ncclCommInitRank(&ctx->comm, nranks, id, rank));
         ctx->use_comm = true;
+        if (!ctx->comm_stream) {
+            HIP_TRY(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&ctx->ev_src, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&ctx->ev_halo, hipEventDisableTiming));
+        }
     }
     ctx->ldv = 0;   // force re-layout on the next matrix
     ctx->use_halo = false;
@@ -714,15 +810,13 @@ int kfsp_arnoldi(kfsp_ctx *ctx, int m, int jold, int qiop, double break_tol, dou
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const int64_t ldv = ctx->ldv;
-    const int gs = spmv_grid(ctx), gv = vec_grid(ctx);
-    const bool nt = use_nt(ctx);
+    const int gv = vec_grid(ctx);
     double *V = vcol(ctx, 0), *Hd = ctx->d_H.p, *sq = ctx->d_sq.p;
     int *flag = ctx->d_flag.p;
     HIP_TRY(hipMemsetAsync(flag, 0, sizeof(int), st));
     // entries this pass will not write must not look like a breakdown
     HIP_TRY(hipMemsetAsync(Hd, 0, (size_t)kMH * kMH * sizeof(double), st));
 
-    const bool dia = ctx->use_dia;
     const bool fused = (qiop == 2) && ctx->opt_fused != 0;
     double *gfin = ctx->d_g.p;
     Pending pend_sq{sq + jold, 1};
@@ -730,13 +824,9 @@ int kfsp_arnoldi(kfsp_ctx *ctx, int m, int jold, int qiop, double break_tol, dou
     for (int j = jold; j <= m; ++j) {
         const double *src = V + (size_t)(j - 1) * ldv;
         double *dst = V + (size_t)j * ldv;
-        const double *xg = nullptr;
-        if (int rc = gather_source(ctx, src, &xg)) return rc;
         const int istart = (qiop > 0) ? std::max(1, j - qiop + 1) : 1;
         SpmvArgs a;
         set_matrix_args(ctx, a);
-        a.xg = xg;
-        a.row0 = ctx->row0;
         a.y = dst;
         a.sq = pend_sq;
         a.sq_final = sq + j;
@@ -747,18 +837,9 @@ int kfsp_arnoldi(kfsp_ctx *ctx, int m, int jold, int qiop, double break_tol, dou
             // one product kernel with both dot products, one update kernel
             const bool two = j >= 2;
             a.udot = two ? V + (size_t)(j - 2) * ldv : src;      // u_{j-1} (or u_1 for the first column)
-            a.partial = next_partial(ctx);
             a.udot2 = two ? src : nullptr;                        // u_j
-            a.partial2 = two ? next_partial(ctx) : nullptr;
-            launch_spmv(two ? 3 : 1, gs, a, nt, dia, st);
-            Pending loc[3], pub[3];
-            int k = 0;
-            loc[k++] = Pending{a.partial, gs};
-            if (two) {
-                loc[k++] = Pending{a.partial2, gs};
-                loc[k++] = pend_g;
-            }
-            // pend_g is already global (finished or all-reduced); publish the new ones only
+            Pending loc[2], pub[2];
+            if (int rc = run_product(ctx, two ? 3 : 1, a, src, false, &loc[0], &loc[1])) return rc;
             if (int rc = publish_n(ctx, loc, two ? 2 : 1, pub)) return rc;
             Ortho2Args o;
             o.npairs = act_pairs(ctx);
@@ -784,10 +865,9 @@ int kfsp_arnoldi(kfsp_ctx *ctx, int m, int jold, int qiop, double break_tol, dou
             continue;
         }
         a.udot = V + (size_t)(istart - 1) * ldv;
-        a.partial = next_partial(ctx);
-        launch_spmv(1, gs, a, nt, dia, st);
         Pending pend;
-        if (int rc = publish(ctx, Pending{a.partial, gs}, &pend)) return rc;
+        if (int rc = run_product(ctx, 1, a, src, false, &pend, nullptr)) return rc;
+        if (int rc = publish(ctx, pend, &pend)) return rc;
         for (int i = istart; i <= j; ++i) {
             OrthoArgs o;
             o.npairs = act_pairs(ctx);
@@ -810,23 +890,18 @@ int kfsp_arnoldi(kfsp_ctx *ctx, int m, int jold, int qiop, double break_tol, dou
     const int jl = looped ? m + 1 : jold;
     {
         const double *src = V + (size_t)(jl - 1) * ldv;
-        const double *xg = nullptr;
-        if (int rc = gather_source(ctx, src, &xg)) return rc;
         SpmvArgs a;
         set_matrix_args(ctx, a);
-        a.xg = xg;
-        a.row0 = ctx->row0;
         a.y = V + (size_t)jl * ldv;
         a.sq = looped ? pend_sq : Pending{sq + jold, 1};
         a.sq_final = sq + jl;
         a.h_sub = looped ? Hd + (size_t)(m - 1) * kMH + m : nullptr;   // H(m+1,m)
         a.udot = nullptr;
-        a.partial = next_partial(ctx);
         a.break_tol = looped ? break_tol : -1.0;
         a.brk_flag = flag;
-        launch_spmv(2, gs, a, nt, dia, st);
         Pending pend;
-        if (int rc = publish(ctx, Pending{a.partial, gs}, &pend)) return rc;
+        if (int rc = run_product(ctx, 2, a, src, false, &pend, nullptr)) return rc;
+        if (int rc = publish(ctx, pend, &pend)) return rc;
         launch_finalize(pend, Hd + (size_t)kMH * kMH, Hd + (size_t)kMH * kMH + 1, st);
         // u_{m+1} . u_m for a later restart at column m+1 is never needed (a
         // restart resumes at jold <= m), but finish it so that gfin stays final
@@ -901,23 +976,16 @@ int kfsp_restore_w(kfsp_ctx *ctx, double beta)
 static int spmv_plain(kfsp_ctx *ctx, const double *src_local_or_full, bool src_is_full, double *y_dev,
                       bool force_sell = false)
 {
-    const double *xg = src_local_or_full;
-    if (!src_is_full)
-        if (int rc = gather_source(ctx, src_local_or_full, &xg)) return rc;
     SpmvArgs a;
     set_matrix_args(ctx, a);
-    a.xg = xg;
-    a.row0 = ctx->row0;
     a.y = y_dev;
     a.sq = Pending{nullptr, 0};
     a.sq_final = nullptr;
     a.h_sub = nullptr;
     a.udot = nullptr;
-    a.partial = nullptr;
     a.break_tol = -1.0;
     a.brk_flag = ctx->d_flag.p;
-    launch_spmv(0, spmv_grid(ctx), a, use_nt(ctx), ctx->use_dia && !force_sell, ctx->stream);
-    return 0;
+    return run_product(ctx, 0, a, src_local_or_full, src_is_full, nullptr, nullptr, force_sell);
 }
 
 int kfsp_spmv(kfsp_ctx *ctx, const double *x, double *y)
@@ -1114,6 +1182,7 @@ int kfsp_set_option(kfsp_ctx *ctx, const char *name, int64_t value)
     else if (k == "fused_ortho") ctx->opt_fused = value;
     else if (k == "host_build") ctx->opt_host_build = value;
     else if (k == "halo") ctx->opt_halo = value;
+    else if (k == "overlap") ctx->opt_overlap = value;
     else return fail(ctx, -2, "unknown option");
     return 0;
 }

@@ -63,6 +63,10 @@ struct kfsp_ctx {
     int64_t halo = 0;        // rows needed from each neighbour = max |delta|, agreed by all ranks
     int64_t margin = 0;      // rows reserved on either side of every column (>= halo)
     DevBuf<double> d_strip;  // [2*halo] send + [nranks*2*halo] receive
+    // the exchange runs on its own stream so that the interior rows of a product
+    // (which read no halo) are computed while the strips travel
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_src = nullptr, ev_halo = nullptr;
 
     // sizes
     int64_t n = 0;        // global states
@@ -120,6 +124,7 @@ struct kfsp_ctx {
     int64_t opt_format = 0; // 0 auto (DIA when banded), 1 always SELL
     int64_t opt_fused = 1;  // 1: one-pass IOP(2) orthogonalisation (k_ortho2)
     int64_t opt_halo = 1;         // 0: always all-gather the whole source vector
+    int64_t opt_overlap = 1;      // 0: exchange and product strictly one after the other
     int64_t opt_host_build = 0;   // 1: transpose reference-layout input on the host (A/B testing)
     double t_ms[KFSP_T_COUNT] = {0, 0, 0, 0, 0, 0};
 };

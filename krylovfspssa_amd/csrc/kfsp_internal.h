@@ -81,6 +81,10 @@ struct SpmvArgs {
     double *partial2;
     double break_tol;     // <0: no breakdown test
     int *brk_flag;
+    // wavefront trips covered by this launch (a trip = one 64-row chunk, or one
+    // 128-row group of the banded form); lets a product be split into an interior
+    // launch and boundary launches that wait for the halo exchange
+    int64_t trip_begin, trip_end;
 };
 
 // Both Gram-Schmidt updates of an IOP(2) column in one pass.  With

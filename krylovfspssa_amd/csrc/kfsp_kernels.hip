@@ -203,13 +203,12 @@ __global__ __launch_bounds__(kBlock) void k_spmv(SpmvArgs a)
     }
 
     // SELL: one 64-row chunk per wavefront trip; DIA: one 128-row group
-    const int64_t nchunks = DIA ? (a.D.nchunks + 1) >> 1 : a.A.nchunks;
     const int xcd = blockIdx.x & 7;
     const int slot = blockIdx.x >> 3;
     const int bx = gridDim.x >> 3;                        // workgroups per XCD
-    const int64_t cpx = (nchunks + 7) >> 3;
-    const int64_t cbeg = (int64_t)xcd * cpx;
-    const int64_t cend = (cbeg + cpx < nchunks) ? cbeg + cpx : nchunks;
+    const int64_t cpx = (a.trip_end - a.trip_begin + 7) >> 3;
+    const int64_t cbeg = a.trip_begin + (int64_t)xcd * cpx;
+    const int64_t cend = (cbeg + cpx < a.trip_end) ? cbeg + cpx : a.trip_end;
     const int64_t cstep = (int64_t)bx * 4;
     int64_t c = cbeg + (int64_t)slot * 4 + wave;
 

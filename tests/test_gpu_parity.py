@@ -429,14 +429,18 @@ def test_one_rank_communicator_halo_layout(oracle):
     neighbour, so the result must equal the plain path bit for bit; the
     all-gather fallback (option halo=0) likewise."""
     from krylovfspssa_amd import KfspContext, synth
-    mdl = synth.toggle(300, 211)
+    mdl = synth.toggle(300, 211)          # 63 300 rows: interior + two boundary launches when overlapped
     rp, cc, vv = mdl.csr_rows()
     p0 = synth.poisson_p0(mdl, 25.0)
     res = []
-    for mode in ("plain", "halo", "allgather"):
+    for mode in ("plain", "halo+overlap", "halo", "allgather"):
         with KfspContext(0) as c:
             if mode != "plain":
                 c.comm_init(1, 0, KfspContext.unique_id())
+            if mode == "halo+overlap":
+                c.set_option("overlap", 2)      # force the split even at this small size
+            if mode == "halo":
+                c.set_option("overlap", 0)      # exchange, then one launch
             if mode == "allgather":
                 c.set_option("halo", 0)
             c.set_matrix_csr(mdl.n, rp, cc, vv)
@@ -444,5 +448,10 @@ def test_one_rank_communicator_halo_layout(oracle):
             y = c.spmv_w()
             ws = c.expv_fixed(25, 0.01, 2)
             res.append((y, ws.copy(), c.get_vector()))
-    for r in res[1:]:
-        assert np.array_equal(r[0], res[0][0]) and np.array_equal(r[1], res[0][1]) and np.array_equal(r[2], res[0][2])
+    for mode, r in zip(("halo+overlap", "halo", "allgather"), res[1:]):
+        assert np.array_equal(r[0], res[0][0])                     # the product itself: same rows, same order
+        if mode == "halo+overlap":
+            # three launches group the dot-product partials differently: rounding-level only
+            assert np.abs(r[1] - res[0][1]).max() < 1e-14 and np.abs(r[2] - res[0][2]).sum() < 1e-14
+        else:
+            assert np.array_equal(r[1], res[0][1]) and np.array_equal(r[2], res[0][2])
