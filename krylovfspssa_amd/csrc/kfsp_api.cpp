@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -189,6 +190,8 @@ int run_product(kfsp_ctx *ctx, int mode, SpmvArgs a, const double *src, bool src
         a.partial2 = P2;
         a.trip_begin = 0;
         a.trip_end = trips;
+        a.trip_split = INT64_MAX;
+        a.trip_jump = 0;
         const int g = trips_grid(trips, cap);
         launch_spmv(mode, g, a, nt, dia, st);
         if (p1) *p1 = Pending{P1, g};
@@ -202,20 +205,23 @@ int run_product(kfsp_ctx *ctx, int mode, SpmvArgs a, const double *src, bool src
     HIP_TRY(hipEventRecord(ctx->ev_halo, ctx->comm_stream));
     a.xg = src - ctx->row0;
     int used = 0;
-    auto launch_range = [&](int64_t b, int64_t e, int64_t gcap) {
+    auto launch_range = [&](int64_t b, int64_t e, int64_t split, int64_t jump, int64_t gcap) {
         if (e <= b) return;
         const int g = trips_grid(e - b, gcap);
         a.partial = P1 ? P1 + used : nullptr;
         a.partial2 = P2 ? P2 + used : nullptr;
         a.trip_begin = b;
         a.trip_end = e;
+        a.trip_split = split;
+        a.trip_jump = jump;
         launch_spmv(mode, g, a, nt, true, st);
         used += g;
     };
-    launch_range(lo, hi, std::min<int64_t>(cap, kMaxGrid - 512));   // interior: no halo row is read
+    launch_range(lo, hi, INT64_MAX, 0, std::min<int64_t>(cap, kMaxGrid - 512));   // interior: no halo row is read
     HIP_TRY(hipStreamWaitEvent(st, ctx->ev_halo, 0));
-    launch_range(0, lo, 256);                                        // rows that read the previous rank's strip
-    launch_range(hi, trips, 256);                                    // rows that read the next rank's strip
+    // one launch for both boundary ranges: linear trips [0, lo) are themselves,
+    // [lo, lo + trips - hi) stand for [hi, trips)
+    launch_range(0, lo + (trips - hi), lo, hi - lo, 512);
     if (p1) *p1 = Pending{P1, used};
     if (p2) *p2 = Pending{P2, used};
     return 0;

@@ -85,6 +85,9 @@ struct SpmvArgs {
     // 128-row group of the banded form); lets a product be split into an interior
     // launch and boundary launches that wait for the halo exchange
     int64_t trip_begin, trip_end;
+    // linear trip t stands for trip (t < trip_split ? t : t + trip_jump): one launch
+    // can cover the two boundary ranges [0, lo) and [hi, trips)
+    int64_t trip_split, trip_jump;
 };
 
 // Both Gram-Schmidt updates of an IOP(2) column in one pass.  With

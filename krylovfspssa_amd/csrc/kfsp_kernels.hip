@@ -215,9 +215,10 @@ __global__ __launch_bounds__(kBlock) void k_spmv(SpmvArgs a)
     // The first trip's row sums are started before the pending norm is
     // finished: the partial-sum round trip overlaps the first generator loads.
     d2 sum = {0.0, 0.0};
+    int64_t ct = c < a.trip_split ? c : c + a.trip_jump;   // actual trip of linear index c
     if (c < cend) {
-        if (DIA) sum = rows_dia<NT>(a.D, a.xg, a.row0, c, lane);
-        else sum.x = row_sell<NT>(a.A, a.xg, a.row0, c, lane);
+        if (DIA) sum = rows_dia<NT>(a.D, a.xg, a.row0, ct, lane);
+        else sum.x = row_sell<NT>(a.A, a.xg, a.row0, ct, lane);
     }
 
     double s = 1.0;
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv(SpmvArgs a)
     double acc = 0.0, acc2 = 0.0;
     while (c < cend) {
         if (DIA) {
-            const int64_t r = (c << 7) + 2 * lane;
+            const int64_t r = (ct << 7) + 2 * lane;
             if (MODE != 0) {
                 sum.x *= s;
                 sum.y *= s;
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv(SpmvArgs a)
                 acc2 += u.y * sum.y;
             }
         } else {
-            const int64_t r = (c << 6) + lane;
+            const int64_t r = (ct << 6) + lane;
             double v = sum.x;
             if (MODE != 0) v *= s;
             a.y[r] = v;
@@ -268,9 +269,10 @@ __global__ __launch_bounds__(kBlock) void k_spmv(SpmvArgs a)
             if (MODE == 3) acc2 += a.udot2[r] * v;
         }
         c += cstep;
+        ct = c < a.trip_split ? c : c + a.trip_jump;
         if (c < cend) {
-            if (DIA) sum = rows_dia<NT>(a.D, a.xg, a.row0, c, lane);
-            else sum.x = row_sell<NT>(a.A, a.xg, a.row0, c, lane);
+            if (DIA) sum = rows_dia<NT>(a.D, a.xg, a.row0, ct, lane);
+            else sum.x = row_sell<NT>(a.A, a.xg, a.row0, ct, lane);
         }
     }
     if (MODE == 3) {
