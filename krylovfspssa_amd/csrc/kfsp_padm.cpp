@@ -68,9 +68,74 @@ __attribute__((target("avx2,fma"))) void matmul_avx2(double alpha, const Dense &
 }
 #undef KFSP_MATMUL_BODY
 
+// Dense case (the squaring phase): two output columns share every load of A and
+// eight columns of A are folded per sweep - 12 memory operations per 16 fused
+// multiply-adds instead of 6 per 4.
+#define KFSP_MATMUL_DENSE_BODY                                                                \
+    const int m = A.m;                                                                        \
+    const double *a = A.a.data();                                                             \
+    const double *b = B.a.data();                                                             \
+    double *c = C.a.data();                                                                   \
+    int j = 0;                                                                                \
+    for (; j + 2 <= m; j += 2) {                                                              \
+        double *__restrict__ c0 = c + (size_t)j * m;                                          \
+        double *__restrict__ c1 = c0 + m;                                                     \
+        const double *b0 = b + (size_t)j * m, *b1 = b0 + m;                                   \
+        for (int i = 0; i < m; ++i) {                                                         \
+            c0[i] = 0.0;                                                                      \
+            c1[i] = 0.0;                                                                      \
+        }                                                                                     \
+        int k = 0;                                                                            \
+        for (; k + 8 <= m; k += 8) {                                                          \
+            const double *__restrict__ ak = a + (size_t)k * m;                                \
+            double p[8], q[8];                                                                \
+            for (int r = 0; r < 8; ++r) {                                                     \
+                p[r] = alpha * b0[k + r];                                                     \
+                q[r] = alpha * b1[k + r];                                                     \
+            }                                                                                 \
+            for (int i = 0; i < m; ++i) {                                                     \
+                const double x0 = ak[i], x1 = ak[i + m], x2 = ak[i + 2 * m], x3 = ak[i + 3 * m];       \
+                const double x4 = ak[i + 4 * m], x5 = ak[i + 5 * m], x6 = ak[i + 6 * m], x7 = ak[i + 7 * m]; \
+                c0[i] += ((p[0] * x0 + p[1] * x1) + (p[2] * x2 + p[3] * x3)) + ((p[4] * x4 + p[5] * x5) + (p[6] * x6 + p[7] * x7)); \
+                c1[i] += ((q[0] * x0 + q[1] * x1) + (q[2] * x2 + q[3] * x3)) + ((q[4] * x4 + q[5] * x5) + (q[6] * x6 + q[7] * x7)); \
+            }                                                                                 \
+        }                                                                                     \
+        for (; k < m; ++k) {                                                                  \
+            const double *__restrict__ ak = a + (size_t)k * m;                                \
+            const double p0 = alpha * b0[k], q0 = alpha * b1[k];                              \
+            for (int i = 0; i < m; ++i) {                                                     \
+                c0[i] += p0 * ak[i];                                                          \
+                c1[i] += q0 * ak[i];                                                          \
+            }                                                                                 \
+        }                                                                                     \
+    }                                                                                         \
+    for (; j < m; ++j) {                                                                      \
+        double *__restrict__ c0 = c + (size_t)j * m;                                          \
+        for (int i = 0; i < m; ++i) c0[i] = 0.0;                                              \
+        for (int k = 0; k < m; ++k) {                                                         \
+            const double p0 = alpha * b[(size_t)j * m + k];                                   \
+            const double *__restrict__ ak = a + (size_t)k * m;                                \
+            for (int i = 0; i < m; ++i) c0[i] += p0 * ak[i];                                  \
+        }                                                                                     \
+    }
+
+void matmul_dense_base(double alpha, const Dense &A, const Dense &B, Dense &C) { KFSP_MATMUL_DENSE_BODY }
+__attribute__((target("avx2,fma"))) void matmul_dense_avx2(double alpha, const Dense &A, const Dense &B, Dense &C)
+{
+    KFSP_MATMUL_DENSE_BODY
+}
+#undef KFSP_MATMUL_DENSE_BODY
+
 void matmul(double alpha, const Dense &A, const Dense &B, Dense &C)
 {
     static const bool wide = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma");
+    size_t nz = 0;
+    for (double v : B.a) nz += v != 0.0;
+    if (2 * nz > B.a.size()) {                            // mostly non-zero: no point in skipping
+        if (wide) matmul_dense_avx2(alpha, A, B, C);
+        else matmul_dense_base(alpha, A, B, C);
+        return;
+    }
     if (wide) matmul_avx2(alpha, A, B, C);
     else matmul_base(alpha, A, B, C);
 }
@@ -115,6 +180,14 @@ bool solve_in_place(Dense &Q, Dense &X)
             for (int i = k + 1; i <= last; ++i) xj[i] -= qk[i] * f;
         }
     }
+    // first non-zero row of every column of U: banded factors stay banded
+    std::vector<int> top((size_t)m);
+    for (int k = 0; k < m; ++k) {
+        const double *qk = q + (size_t)k * m;
+        int f = 0;
+        while (f < k && qk[f] == 0.0) ++f;
+        top[(size_t)k] = f;
+    }
     for (int j = 0; j < m; ++j) {                        // U^{-1}, column-oriented back substitution
         double *xj = x + (size_t)j * m;
         for (int k = m - 1; k >= 0; --k) {
@@ -122,7 +195,7 @@ bool solve_in_place(Dense &Q, Dense &X)
             const double v = xj[k] / qk[k];
             xj[k] = v;
             if (v == 0.0) continue;
-            for (int i = 0; i < k; ++i) xj[i] -= qk[i] * v;
+            for (int i = top[(size_t)k]; i < k; ++i) xj[i] -= qk[i] * v;
         }
     }
     return true;
