@@ -519,7 +519,9 @@ int kfsp_create(int device, kfsp_ctx **out)
     HIP_TRY(ctx->d_g.reserve(kMH + 2, true));
     HIP_TRY(ctx->d_y.reserve(kMH, true));
     HIP_TRY(ctx->d_flag.reserve(4, true));
-    ctx->h_H.assign((size_t)kMH * kMH + 2, 0.0);
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_H), ((size_t)kMH * kMH + 2) * sizeof(double), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_pin), (size_t)(kMH + 8) * sizeof(double), hipHostMallocDefault));
+    std::memset(ctx->h_H, 0, ((size_t)kMH * kMH + 2) * sizeof(double));
     *out = c.release();
     return 0;
 }
@@ -541,6 +543,8 @@ int kfsp_destroy(kfsp_ctx *ctx)
     ctx->d_y.release(); ctx->d_flag.release(); ctx->d_g.release(); ctx->d_dia.release();
     ctx->d_ell_adj.release(); ctx->d_ell_off.release(); ctx->d_ell_diag.release(); ctx->d_cnt.release();
     ctx->d_ticket.release(); ctx->d_slot.release(); ctx->d_scan.release(); ctx->d_strip.release();
+    if (ctx->h_H) (void)hipHostFree(ctx->h_H);
+    if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -794,8 +798,9 @@ int kfsp_begin_step(kfsp_ctx *ctx, double *beta)
     if (int rc = publish(ctx, Pending{part, g}, &s)) return rc;
     double *hb = ctx->d_H.p + (size_t)kMH * kMH;   // scratch pair behind the H image
     launch_finalize(s, ctx->d_sq.p + 1, hb, ctx->stream);
-    HIP_TRY(hipMemcpyAsync(beta, hb, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->h_pin, hb, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    *beta = ctx->h_pin[0];
     return 0;
 }
 
@@ -825,9 +830,30 @@ int kfsp_arnoldi(kfsp_ctx *ctx, int m, int jold, int qiop, double break_tol, dou
 
     const bool fused = (qiop == 2) && ctx->opt_fused != 0;
     double *gfin = ctx->d_g.p;
+    // small state spaces: the whole pass in one launch of one workgroup
+    const bool small = fused && !ctx->use_comm && ctx->opt_small != 0 && ctx->nchunks * kChunk <= kSmallRows &&
+                       (ctx->use_dia || ctx->have_sell);
+    if (small) {
+        SmallArnoldiArgs sa;
+        SpmvArgs tmp;
+        set_matrix_args(ctx, tmp);
+        sa.A = tmp.A;
+        sa.D = tmp.D;
+        sa.V = V;
+        sa.ldv = ldv;
+        sa.nact = ctx->nchunks * kChunk;
+        sa.m = m;
+        sa.jold = jold;
+        sa.sq = sq;
+        sa.gfin = gfin;
+        sa.Hd = Hd;
+        sa.break_tol = break_tol;
+        sa.brk_flag = flag;
+        launch_arnoldi_small(sa, ctx->use_dia, st);
+    }
     Pending pend_sq{sq + jold, 1};
     Pending pend_g{gfin + jold, 1};      // u_jold . u_{jold-1}, finished by the pass that built column jold
-    for (int j = jold; j <= m; ++j) {
+    for (int j = jold; j <= m && !small; ++j) {
         const double *src = V + (size_t)(j - 1) * ldv;
         double *dst = V + (size_t)j * ldv;
         const int istart = (qiop > 0) ? std::max(1, j - qiop + 1) : 1;
@@ -894,7 +920,7 @@ int kfsp_arnoldi(kfsp_ctx *ctx, int m, int jold, int qiop, double break_tol, dou
     // dimension shrank below jold (J1V is only advanced inside the loop)
     const bool looped = jold <= m;
     const int jl = looped ? m + 1 : jold;
-    {
+    if (!small) {
         const double *src = V + (size_t)(jl - 1) * ldv;
         SpmvArgs a;
         set_matrix_args(ctx, a);
@@ -913,10 +939,14 @@ int kfsp_arnoldi(kfsp_ctx *ctx, int m, int jold, int qiop, double break_tol, dou
         // restart resumes at jold <= m), but finish it so that gfin stays final
         if (fused && looped) launch_finalize(pend_g, gfin + (m + 1), nullptr, st);
     }
-    HIP_TRY(hipMemcpyAsync(ctx->h_H.data(), Hd, ((size_t)kMH * kMH + 2) * sizeof(double), hipMemcpyDeviceToHost, st));
+    {
+        // only what this pass wrote: columns jold..m (+ the sub-diagonal of column m) and the AVNORM pair
+        const size_t first = (size_t)(jold - 1) * kMH, last = (size_t)kMH * kMH + 2;
+        HIP_TRY(hipMemcpyAsync(ctx->h_H + first, Hd + first, (last - first) * sizeof(double), hipMemcpyDeviceToHost, st));
+    }
     HIP_TRY(hipStreamSynchronize(st));
 
-    const std::vector<double> &hh = ctx->h_H;
+    const double *hh = ctx->h_H;
     *mbrkdwn = m;
     *k1 = 2;
     for (int j = jold; j <= m; ++j) {
@@ -946,7 +976,8 @@ int kfsp_combine(kfsp_ctx *ctx, int mx, double beta, const double *y, double *ws
     PhaseTimer timer(ctx, KFSP_T_COMBINE);
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    HIP_TRY(hipMemcpyAsync(ctx->d_y.p, y, (size_t)mx * sizeof(double), hipMemcpyHostToDevice, st));
+    std::memcpy(ctx->h_pin + 8, y, (size_t)mx * sizeof(double));
+    HIP_TRY(hipMemcpyAsync(ctx->d_y.p, ctx->h_pin + 8, (size_t)mx * sizeof(double), hipMemcpyHostToDevice, st));
     CombineArgs a;
     a.npairs = act_pairs(ctx);
     a.mx = mx;
@@ -964,8 +995,9 @@ int kfsp_combine(kfsp_ctx *ctx, int mx, double beta, const double *y, double *ws
     if (int rc = publish(ctx, Pending{a.partial, g}, &s)) return rc;
     double *hb = ctx->d_H.p + (size_t)kMH * kMH;
     launch_finalize(s, hb, nullptr, st);
-    HIP_TRY(hipMemcpyAsync(wsum, hb, sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(ctx->h_pin, hb, sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    *wsum = ctx->h_pin[0];
     return 0;
 }
 
@@ -1189,6 +1221,7 @@ int kfsp_set_option(kfsp_ctx *ctx, const char *name, int64_t value)
     else if (k == "host_build") ctx->opt_host_build = value;
     else if (k == "halo") ctx->opt_halo = value;
     else if (k == "overlap") ctx->opt_overlap = value;
+    else if (k == "small_kernel") ctx->opt_small = value;
     else return fail(ctx, -2, "unknown option");
     return 0;
 }

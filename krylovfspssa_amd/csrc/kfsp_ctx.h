@@ -114,7 +114,8 @@ struct kfsp_ctx {
     DevBuf<double> d_y;      // kMH coefficients
     DevBuf<int> d_flag;
     int part_rr = 0, stage_rr = 0;
-    std::vector<double> h_H;
+    double *h_H = nullptr;     // pinned image of d_H (+2) for the one copy per Arnoldi pass
+    double *h_pin = nullptr;   // pinned scratch for scalars and the combine coefficients (kMH + 8 doubles)
     double avnorm_last = 0.0;
 
     // options
@@ -124,6 +125,7 @@ struct kfsp_ctx {
     int64_t opt_format = 0; // 0 auto (DIA when banded), 1 always SELL
     int64_t opt_fused = 1;  // 1: one-pass IOP(2) orthogonalisation (k_ortho2)
     int64_t opt_halo = 1;         // 0: always all-gather the whole source vector
+    int64_t opt_small = 1;        // 1: one-launch Arnoldi pass for <= 16384 rows
     int64_t opt_overlap = 1;      // 0: exchange and product strictly one after the other
     int64_t opt_host_build = 0;   // 1: transpose reference-layout input on the host (A/B testing)
     double t_ms[KFSP_T_COUNT] = {0, 0, 0, 0, 0, 0};

@@ -132,6 +132,26 @@ struct CombineArgs {
     double *partial;
 };
 
+// A whole IOP(2) Arnoldi pass in ONE launch of ONE workgroup, for state spaces
+// small enough (<= kSmallRows rows, source vector resident in LDS) that kernel boundaries, not bytes, set the
+// time: BASELINE config 1 (toggle, ~10^3 states) spends ~10 us per column in two
+// launches of which < 1 us is work.
+constexpr int kSmallRows = 4096;     // 4 rows per lane in registers, source column in 32 KB of LDS
+struct SmallArnoldiArgs {
+    SellDev A;
+    DiaDev D;
+    double *V;            // column 0 of the basis (halo margin already applied)
+    int64_t ldv;
+    int64_t nact;         // rows each column carries (multiple of 64)
+    int m, jold;
+    double *sq;           // squared norms, index = column (1-based)
+    double *gfin;         // u_j . u_{j-1}, index = j
+    double *Hd;           // kMH x kMH image + avnorm^2, avnorm behind it
+    double break_tol;
+    int *brk_flag;
+};
+void launch_arnoldi_small(const SmallArnoldiArgs &a, bool dia, hipStream_t s);
+
 // kernel launchers (kfsp_kernels.hip)
 void launch_spmv(int mode, int grid, const SpmvArgs &a, bool nontemporal, bool dia, hipStream_t s);
 void launch_ortho2(int grid, const Ortho2Args &a, hipStream_t s);

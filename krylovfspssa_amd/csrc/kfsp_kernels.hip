@@ -456,6 +456,226 @@ void launch_ortho2(int grid, const Ortho2Args &a, hipStream_t st)
     hipLaunchKernelGGL(k_ortho2, dim3(grid), dim3(kBlock), 0, st, a);
 }
 
+// ----------------------------------------------- small-N Arnoldi pass, one launch
+// One workgroup of 1024 lanes owns every row (<= 4 per lane).  Columns are
+// separated by workgroup barriers instead of kernel boundaries, the current
+// source vector lives in LDS (32 KB: the x gathers of the product never leave
+// the CU), each lane keeps its own rows of the new column in registers between
+// the product and the update, and scalars never leave registers.  Per column
+// the only global round trip left is the stream of generator entries.  H, the
+// squared norms and the breakdown flag are written exactly as the multi-launch
+// path writes them, so the host side is unchanged.
+constexpr int kSmallBlock = 1024;
+constexpr int kSmallTrips = kSmallRows / kSmallBlock;      // rows per lane
+
+__device__ __forceinline__ void small_reduce2(double &a, double &b, double *red)
+{
+    a = wave_allreduce_sum(a);
+    b = wave_allreduce_sum(b);
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();                                   // red free to be overwritten
+    if ((threadIdx.x & 63) == 0) {
+        red[wave] = a;
+        red[16 + wave] = b;
+    }
+    __syncthreads();
+    double sa = 0.0, sb = 0.0;
+#pragma unroll
+    for (int w = 0; w < kSmallBlock / 64; ++w) {
+        sa += red[w];
+        sb += red[16 + w];
+    }
+    a = sa;
+    b = sb;
+}
+
+__device__ __forceinline__ double row_dia1(const DiaDev &D, const double *x, int64_t r)
+{
+    const int64_t last = D.n - 1;
+    double sum = -D.diag[r] * x[r < last ? r : last];
+    for (int d = 0; d < D.nd; ++d) {
+        int64_t i = r + D.delta[d];
+        i = i < 0 ? 0 : (i > last ? last : i);
+        sum += D.val[(int64_t)d * D.ld + r] * x[i];
+    }
+    return sum;
+}
+
+// row t of this lane: SELL lanes own (chunk = wave + 16 t, lane), DIA lanes own tid + 1024 t
+template <bool DIA>
+__device__ __forceinline__ int64_t small_row(int t)
+{
+    if (DIA) return (int64_t)threadIdx.x + (int64_t)t * kSmallBlock;
+    return (((int64_t)(threadIdx.x >> 6) + (int64_t)t * (kSmallBlock / 64)) << 6) + (threadIdx.x & 63);
+}
+
+// SELL row with the chunk's offset and width already in registers (they do not
+// change from column to column, so the dependent off[] load is paid once per pass)
+__device__ __forceinline__ double row_sell_pre(const SellDev &A, const double *xs, int64_t r, int64_t off, int w)
+{
+    const int lane = (int)(r & 63);
+    const int32_t *cp = A.col + off + lane;
+    const double *vp = A.val + off + lane;
+    double sum = -A.diag[r] * xs[r];
+    int k = 0;
+    for (; k + 4 <= w; k += 4) {
+        const int32_t c0 = cp[(k + 0) * 64], c1 = cp[(k + 1) * 64], c2 = cp[(k + 2) * 64], c3 = cp[(k + 3) * 64];
+        const double v0 = vp[(k + 0) * 64], v1 = vp[(k + 1) * 64], v2 = vp[(k + 2) * 64], v3 = vp[(k + 3) * 64];
+        sum += v0 * xs[c0];
+        sum += v1 * xs[c1];
+        sum += v2 * xs[c2];
+        sum += v3 * xs[c3];
+    }
+    for (; k < w; ++k) sum += vp[k * 64] * xs[cp[k * 64]];
+    return sum;
+}
+
+template <bool DIA>
+__device__ __forceinline__ double small_product_row(const SmallArnoldiArgs &a, const double *xs, int64_t r,
+                                                    int64_t off, int w)
+{
+    if (DIA) return row_dia1(a.D, xs, r);
+    return row_sell_pre(a.A, xs, r, off, w);
+}
+
+template <bool DIA>
+__global__ __launch_bounds__(kSmallBlock) void k_arnoldi_small(SmallArnoldiArgs a)
+{
+    __shared__ double xs[kSmallRows];                  // the source column u_j
+    __shared__ double red[32];
+    const int tid = threadIdx.x;
+    double *Hd = a.Hd;
+    double S = a.sq[a.jold];          // squared norm of the column about to be multiplied
+    double g = a.gfin[a.jold];        // u_jold . u_{jold-1}
+    double s1 = a.jold >= 2 ? 1.0 / sqrt(a.sq[a.jold - 1]) : 0.0;   // 1/||u_{j-1}||, carried in a register
+    int64_t offs[kSmallTrips];
+    int wid[kSmallTrips];
+#pragma unroll
+    for (int t = 0; t < kSmallTrips; ++t) {
+        const int64_t r = small_row<DIA>(t);
+        offs[t] = 0;
+        wid[t] = 0;
+        if (!DIA && r < a.nact) {
+            offs[t] = a.A.off[r >> 6];
+            wid[t] = (int)((a.A.off[(r >> 6) + 1] - offs[t]) >> 6);
+        }
+    }
+    {
+        const double *src = a.V + (size_t)(a.jold - 1) * a.ldv;
+        for (int64_t r = tid; r < a.nact; r += kSmallBlock) xs[r] = src[r];
+    }
+    __syncthreads();
+    bool broke = false;
+    for (int j = a.jold; j <= a.m; ++j) {
+        const double *u1 = j >= 2 ? a.V + (size_t)(j - 2) * a.ldv : nullptr;
+        double *dst = a.V + (size_t)j * a.ldv;
+        const double nrm = sqrt(S);
+        if (tid == 0) {
+            a.sq[j] = S;
+            if (j > a.jold) Hd[(size_t)(j - 2) * kMH + (j - 1)] = nrm;     // H(j,j-1)
+        }
+        if (j > a.jold && !(nrm > a.break_tol)) {      // happy breakdown :249 (S is the same in every lane)
+            broke = true;
+            break;
+        }
+        const double s2 = 1.0 / nrm;
+        double y[kSmallTrips], v1[kSmallTrips];
+        double pa = 0.0, pb = 0.0;
+#pragma unroll
+        for (int t = 0; t < kSmallTrips; ++t) {
+            const int64_t r = small_row<DIA>(t);
+            y[t] = 0.0;
+            v1[t] = 0.0;
+            if (r < a.nact) {
+                if (u1) v1[t] = u1[r];
+                y[t] = s2 * small_product_row<DIA>(a, xs, r, offs[t], wid[t]);
+                pa += v1[t] * y[t];
+                pb += xs[r] * y[t];
+            }
+        }
+        small_reduce2(pa, pb, red);
+        double c1 = 0.0, h2;
+        if (u1) {
+            const double h1 = pa * s1;
+            c1 = h1 * s1;
+            h2 = (pb - c1 * g) * s2;
+            if (tid == 0) {
+                Hd[(size_t)(j - 1) * kMH + (j - 2)] = h1;                  // H(j-1,j)
+                a.gfin[j] = g;
+            }
+        } else {
+            h2 = pb * s2;
+        }
+        if (tid == 0) Hd[(size_t)(j - 1) * kMH + (j - 1)] = h2;            // H(j,j)
+        const double c2 = h2 * s2;
+        double asq = 0.0, ag = 0.0;
+#pragma unroll
+        for (int t = 0; t < kSmallTrips; ++t) {
+            const int64_t r = small_row<DIA>(t);
+            if (r < a.nact) {
+                const double v2 = xs[r];
+                const double w = y[t] - c1 * v1[t] - c2 * v2;
+                y[t] = w;
+                dst[r] = w;
+                asq += w * w;
+                ag += w * v2;
+            }
+        }
+        small_reduce2(asq, ag, red);     // every lane is past its reads of xs after these barriers
+        S = asq;
+        g = ag;
+        s1 = s2;
+#pragma unroll
+        for (int t = 0; t < kSmallTrips; ++t) {
+            const int64_t r = small_row<DIA>(t);
+            if (r < a.nact) xs[r] = y[t];
+        }
+        __syncthreads();
+    }
+    if (broke) {
+        if (tid == 0) *a.brk_flag = 1;
+        return;
+    }
+    // the extra product for AVNORM (:261-263); from column jold when the loop did not run
+    const bool looped = a.jold <= a.m;
+    const int jl = looped ? a.m + 1 : a.jold;
+    double *dst = a.V + (size_t)jl * a.ldv;
+    const double nrm = sqrt(S);
+    if (tid == 0) {
+        a.sq[jl] = S;
+        if (looped) {
+            Hd[(size_t)(a.m - 1) * kMH + a.m] = nrm;                       // H(m+1,m)
+            a.gfin[a.m + 1] = g;
+        }
+    }
+    if (looped && !(nrm > a.break_tol)) {
+        if (tid == 0) *a.brk_flag = 1;
+        return;
+    }
+    const double s2 = 1.0 / nrm;
+    double av = 0.0, dummy = 0.0;
+#pragma unroll
+    for (int t = 0; t < kSmallTrips; ++t) {
+        const int64_t r = small_row<DIA>(t);
+        if (r < a.nact) {
+            const double yv = s2 * small_product_row<DIA>(a, xs, r, offs[t], wid[t]);
+            dst[r] = yv;
+            av += yv * yv;
+        }
+    }
+    small_reduce2(av, dummy, red);
+    if (tid == 0) {
+        Hd[(size_t)kMH * kMH] = av;
+        Hd[(size_t)kMH * kMH + 1] = sqrt(av);
+    }
+}
+
+void launch_arnoldi_small(const SmallArnoldiArgs &a, bool dia, hipStream_t st)
+{
+    if (dia) hipLaunchKernelGGL((k_arnoldi_small<true>), dim3(1), dim3(kSmallBlock), 0, st, a);
+    else hipLaunchKernelGGL((k_arnoldi_small<false>), dim3(1), dim3(kSmallBlock), 0, st, a);
+}
+
 // ------------------------------------------------------------------ combine
 // w = beta * sum_j y_j s_j u_j ; clamp ; partial = sum |w|
 __global__ __launch_bounds__(kBlock) void k_combine(CombineArgs a)

@@ -120,3 +120,40 @@ def test_growing_and_shrinking_fsp_reuses_the_context(ctx, oracle, golden_dir):
         wref, wsref = oracle.expv_fixed(A, w, m, 1e-3, 2)
         assert np.abs(ctx.get_vector() - wref).sum() < 1e-11
         assert np.abs(ws - wsref).max() < 1e-12
+
+
+@pytest.mark.parametrize("fixture", ["solve_toggle_input.npz", "solve_ring6.npz", "assembly_goutsias_k10.npz"])
+def test_one_launch_arnoldi_equals_multi_launch(oracle, golden_dir, fixture):
+    """State spaces of <= 4096 rows run a whole IOP(2) pass in one launch of one
+    workgroup (k_arnoldi_small); it must reproduce the multi-launch pass -
+    Hessenberg, basis, AVNORM, restart and breakdown behaviour - to rounding."""
+    import os
+    from krylovfspssa_amd import KfspContext
+    g = np.load(os.path.join(golden_dir, fixture))
+    n = int(g["n"])
+    w = np.random.default_rng(21).random(n)
+    A = oracle.EllMatrix(g["adj"], g["offdiag"], g["diag"])
+    out = {}
+    for small in (1, 0):
+        with KfspContext(0) as c:
+            c.set_option("small_kernel", small)
+            c.set_matrix_ell(g["adj"], g["offdiag"], g["diag"])
+            c.set_vector(w)
+            beta = c.begin_step()
+            H, mb, k1, av = c.arnoldi(40)
+            H2 = np.zeros((52, 52), order="F")
+            H2[:41, :40] = H[:41, :40]
+            H2, mb2, k12, av2 = c.arnoldi(50, jold=40, H=H2)              # dimension change restart
+            v51 = c.get_basis(51)
+            H3 = np.zeros((22, 22), order="F")
+            _, mb3, k13, av3 = c.arnoldi(20, jold=50, H=H3)               # shrink below jold: column 51 := A v_50
+            out[small] = (H.copy(), av, H2.copy(), av2, av3, v51, (mb, k1, mb2, k12, mb3, k13))
+    V, Href, _, _, avr = oracle.arnoldi(A, w / np.sqrt(w @ w), 50)
+    for small in (1, 0):
+        H, av, H2, av2, av3, v51, flags = out[small]
+        assert flags == (40, 2, 50, 2, 20, 2)
+        assert np.abs(H2 - Href).max() <= 1e-11 * np.abs(Href).max()
+        assert av2 == pytest.approx(avr, rel=1e-10)
+        assert np.abs(v51 - V[:, 50]).max() < 1e-10
+    assert np.abs(out[1][0] - out[0][0]).max() <= 1e-12 * np.abs(Href).max()
+    assert out[1][4] == pytest.approx(out[0][4], rel=1e-12)

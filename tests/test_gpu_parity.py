@@ -404,6 +404,7 @@ def test_one_rank_communicator_runs_the_collective_path(oracle):
     out = []
     for use_comm in (False, True):
         with KfspContext(0) as c:
+            c.set_option("small_kernel", 0)
             if use_comm:
                 c.comm_init(1, 0, KfspContext.unique_id())
             assert c.row_block(mdl.n) == (0, mdl.n)
@@ -418,6 +419,8 @@ def test_one_rank_communicator_runs_the_collective_path(oracle):
     assert out[0][0] == out[1][0] and out[0][2] == out[1][2]
     assert np.array_equal(out[0][1], out[1][1])
     assert np.array_equal(out[0][3], out[1][3]) and np.array_equal(out[0][4], out[1][4])
+    # (13 547 rows: small enough for the one-launch pass, which is switched off above so that
+    # both runs use the same multi-launch kernels and differ only in the collectives)
     adj, off, diag = mdl.ell()
     wref, _ = oracle.expv_fixed(oracle.EllMatrix(adj, off, diag), p0, 20, 0.01, 3)
     assert np.abs(out[1][4] - wref).sum() < 1e-10
