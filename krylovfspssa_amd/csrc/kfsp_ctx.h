@@ -7,6 +7,7 @@
 
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -22,6 +23,10 @@ struct DevBuf {
     hipError_t reserve(size_t n, bool zero)
     {
         if (n <= cap) return hipSuccess;
+        // The FSP grows a little at every expansion: take half as much again, so
+        // that hipFree/hipMalloc (both synchronise the device, and fresh memory
+        // costs the first kernel that touches it) happen O(log n) times.
+        if (cap > 0) n = std::max(n, cap + cap / 2);
         if (p) (void)hipFree(p);
         p = nullptr;
         cap = 0;

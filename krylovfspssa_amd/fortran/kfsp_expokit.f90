@@ -37,10 +37,11 @@ SUBROUTINE DGPADMNORM(IDEG, M, T, H, LDH, WSP, LWSP, IPIV, IEXPH, NS, IFLAG, HNO
   IEXPH = 1
 END SUBROUTINE DGPADMNORM
 
-! CPU seconds of this process
+! wall-clock seconds (the reference's clock.f offers etime and, for threaded
+! runs, omp_get_wtime; the host threads of STATESPACE make CPU time meaningless)
 DOUBLE PRECISION FUNCTION CLOCK()
   IMPLICIT NONE
-  REAL :: TNOW
-  CALL CPU_TIME(TNOW)
-  CLOCK = DBLE(TNOW)
+  INTEGER(8) :: C, R
+  CALL SYSTEM_CLOCK(C, R)
+  CLOCK = DBLE(C) / DBLE(R)
 END FUNCTION CLOCK

@@ -121,6 +121,9 @@ CONTAINS
             LAST_SOLVE_STATS%N_EXPAND, ' DROP_CALLS =', LAST_SOLVE_STATS%N_DROP_CALLS
        PRINT '(A,4(1X,A,F10.1))', ' KFSP HOST STATE-SPACE MS:', 'DROP_STATES', 1.0D3 * HOST_SEC(1), &
             'SSA_EXTENDER', 1.0D3 * HOST_SEC(2), 'ONESTEP_EXTENDER', 1.0D3 * HOST_SEC(3), 'UPLOADS', 1.0D3 * HOST_SEC(4)
+       ! the passes inside them (process totals): ONESTEP scan/append/link,
+       ! SSA walk/link, DROP flags/compact/renumber/table
+       PRINT '(A,9F9.1)', ' KFSP HOST PASSES MS:', 1.0D3 * STATESPACE_SEC
     ENDIF
   END SUBROUTINE DGEXPV_FSP
 

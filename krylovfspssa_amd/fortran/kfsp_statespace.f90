@@ -13,8 +13,20 @@
 ! comparison of the stored state) instead of 140-byte big-integer keys with
 ! Brent's rehashing (HashTable.f90:61-236, big_integer_module.f90); only
 ! found / not-found and the stored index are observable, the table layout is not.
+!
+! Host parallelism.  A look-up is two or three dependent cache misses, and
+! linking one new state needs 2*NREACTIONS of them, so the extenders are bound
+! by memory latency.  They therefore split each sweep into (1) a sequential part
+! that fixes the ORDER of the new states exactly as the reference's one-at-a-time
+! ADD_STATE does (and calls the propensity functions in the same order), and
+! (2) the linking of all new states afterwards, which only reads the table and
+! runs under OpenMP.  Since every pair of listed states ends up linked either
+! way, ADJ after the sweep is identical to the reference's.  KFSP_HOST_THREADS
+! sets the thread count (default: all available, at most 16).
 MODULE STATESPACE
   USE MODELMODULE
+  USE, INTRINSIC :: ISO_C_BINDING, ONLY: C_INT, C_CHAR, C_NULL_CHAR
+  !$ USE OMP_LIB
   IMPLICIT NONE
 
   ! capacity of a default-created FSP (prime in the reference; kept for the
@@ -40,7 +52,9 @@ MODULE STATESPACE
      TYPE(FSP_MATRIX) :: MATRIX
      DOUBLE PRECISION, ALLOCATABLE :: VECTOR(:)
      INTEGER, PRIVATE :: KTLEN = 0
-     ! open-addressing table: KEYTAB = hash of the entry, KVTAB = state index (0 = free)
+     ! open-addressing table, one 8-byte word per slot: state index in the low
+     ! half, 32 hash bits in the high half, 0 = free; it grows with the list
+     ! (load factor <= 1/2).  KVTAB is kept as a name only (unused, length 1).
      INTEGER(8), ALLOCATABLE :: KEYTAB(:)
      INTEGER, ALLOCATABLE :: KVTAB(:)
    CONTAINS
@@ -51,7 +65,30 @@ MODULE STATESPACE
      PROCEDURE :: INDEX => INDEX_STATE
   END TYPE FINITE_STATE_PROJECTION
 
-  PRIVATE :: STATE_HASH, LOOKUP, TABLE_INSERT, REBUILD_TABLE, LEGAL
+  PRIVATE :: TICK, STATE_HASH, LOOKUP, PROBE, TABLE_INSERT, REBUILD_TABLE, LEGAL, RESERVE_TABLE, APPEND_STATE, &
+       LINK_ONE, LINK_NEW, HOST_THREADS
+
+  INTEGER(8), PARAMETER, PRIVATE :: LOW32 = 4294967295_8
+
+  INTERFACE
+     ! setenv(3) of the C library
+     INTEGER(C_INT) FUNCTION C_SETENV(NAME, VAL, OVERWRITE) BIND(C, NAME='setenv')
+       IMPORT :: C_INT, C_CHAR
+       CHARACTER(KIND=C_CHAR), INTENT(IN) :: NAME(*), VAL(*)
+       INTEGER(C_INT), VALUE :: OVERWRITE
+     END FUNCTION C_SETENV
+  END INTERFACE
+  PRIVATE :: C_SETENV
+  INTEGER(8), PARAMETER, PRIVATE :: LCG_A = 48271_8, LCG_M = 2147483647_8, LCG_LOW = 1073741823_8
+  DOUBLE PRECISION, PARAMETER, PRIVATE :: LCG_SCALE = 2.0D0**(-54)
+  PRIVATE :: LCG_RECOGNISED
+
+  ! wall seconds spent in the passes of the sweeps (profiles/statespace_bench.f90):
+  ! 1-3 ONESTEP_EXTENDER scan / append / link, 4-5 SSA_EXTENDER walk / link,
+  ! 6-9 DROP_STATES threshold+flags / compaction / renumbering / table
+  DOUBLE PRECISION, SAVE :: STATESPACE_SEC(9) = 0.0D0
+  INTEGER, PRIVATE, SAVE :: NTHREADS_CACHED = 0, PARALLEL_MIN = -1
+  INTEGER, PRIVATE, SAVE :: TOUCH_SINK = 0        ! keeps the early loads of SSA_EXTENDER alive
 
 CONTAINS
 
@@ -59,22 +96,18 @@ CONTAINS
     CLASS(FINITE_STATE_PROJECTION), INTENT(INOUT) :: FSP
     TYPE(CME_MODEL), INTENT(IN) :: MODEL
     INTEGER, OPTIONAL, INTENT(IN) :: MAX_SIZE_CUSTOM
-    INTEGER :: N, M, P
+    INTEGER :: N, M
     N = MODEL%NSPECIES
     M = MODEL%NREACTIONS
     IF (PRESENT(MAX_SIZE_CUSTOM)) FSP%MAX_SIZE = MAX_SIZE_CUSTOM
     IF (ALLOCATED(FSP%STATE)) CALL CLEAR_FSP(FSP)
-    ! table length: power of two, load factor <= 1/2
-    P = 16
-    DO WHILE (P < 2 * FSP%MAX_SIZE)
-       P = 2 * P
-    ENDDO
-    FSP%KTLEN = P
+    FSP%KTLEN = 1024
     ALLOCATE(FSP%STATE(N, FSP%MAX_SIZE), FSP%KEY(FSP%MAX_SIZE), &
          FSP%MATRIX%DIAG(FSP%MAX_SIZE), FSP%MATRIX%OFFDIAG(M, FSP%MAX_SIZE), FSP%MATRIX%ADJ(M, FSP%MAX_SIZE), &
-         FSP%KEYTAB(P), FSP%KVTAB(P), FSP%VECTOR(FSP%MAX_SIZE))
+         FSP%KEYTAB(FSP%KTLEN), FSP%KVTAB(1), FSP%VECTOR(FSP%MAX_SIZE))
     FSP%SIZE = 0
     FSP%MATRIX%SIZE = 0
+    FSP%KEYTAB = 0_8
     FSP%KVTAB = 0
   END SUBROUTINE CREATE_FSP
 
@@ -84,7 +117,61 @@ CONTAINS
          FSP%MATRIX%ADJ, FSP%KEYTAB, FSP%KVTAB, FSP%VECTOR)
     FSP%SIZE = 0
     FSP%MATRIX%SIZE = 0
+    FSP%KTLEN = 0
   END SUBROUTINE CLEAR_FSP
+
+  ! adds the wall time since T0 to STATESPACE_SEC(SLOT) and restarts T0
+  SUBROUTINE TICK(SLOT, T0)
+    INTEGER, INTENT(IN) :: SLOT
+    INTEGER(8), INTENT(INOUT) :: T0
+    INTEGER(8) :: C, R
+    CALL SYSTEM_CLOCK(C, R)
+    IF (SLOT > 0) STATESPACE_SEC(SLOT) = STATESPACE_SEC(SLOT) + DBLE(C - T0) / DBLE(R)
+    T0 = C
+  END SUBROUTINE TICK
+
+  ! threads for a sweep over WORK items that pays off from MINWORK items on
+  ! (KFSP_HOST_PARALLEL_MIN replaces every MINWORK: the tests use it to run the
+  ! threaded code on small cases)
+  INTEGER FUNCTION HOST_THREADS(WORK, MINWORK)
+    INTEGER, INTENT(IN) :: WORK, MINWORK
+    CHARACTER(LEN=16) :: BUF
+    INTEGER :: L, ST, V
+    INTEGER(C_INT) :: RC
+    IF (NTHREADS_CACHED == 0) THEN
+       NTHREADS_CACHED = 1
+       ! Keep the team on neighbouring cores of the caller's socket: what the
+       ! sweeps write is read by the sequential parts right afterwards, and on a
+       ! two-socket host an unbound team makes those reads remote.  The runtime
+       ! reads its environment on first use, i.e. just below; values the user set
+       ! are left alone.
+       !$ RC = C_SETENV('OMP_PROC_BIND' // C_NULL_CHAR, 'close' // C_NULL_CHAR, 0_C_INT)
+       !$ RC = C_SETENV('OMP_PLACES' // C_NULL_CHAR, 'cores' // C_NULL_CHAR, 0_C_INT)
+       !$ NTHREADS_CACHED = MIN(OMP_GET_MAX_THREADS(), 16)
+       ! the sweeps are milliseconds long and far apart: idle workers sleep
+       ! instead of spinning (LLVM OpenMP runtime entry point)
+       V = 0
+       CALL GET_ENVIRONMENT_VARIABLE('KFSP_HOST_BLOCKTIME_MS', BUF, L, ST)
+       IF (ST == 0 .AND. L > 0) READ(BUF(1:L), *, IOSTAT=ST) V
+       !$ CALL KMP_SET_BLOCKTIME(MAX(V, 0))
+       CALL GET_ENVIRONMENT_VARIABLE('KFSP_HOST_THREADS', BUF, L, ST)
+       IF (ST == 0 .AND. L > 0) THEN
+          READ(BUF(1:L), *, IOSTAT=ST) V
+          IF (ST == 0 .AND. V >= 1) NTHREADS_CACHED = MIN(V, 256)
+       ENDIF
+       CALL GET_ENVIRONMENT_VARIABLE('KFSP_HOST_PARALLEL_MIN', BUF, L, ST)
+       IF (ST == 0 .AND. L > 0) THEN
+          READ(BUF(1:L), *, IOSTAT=ST) V
+          IF (ST == 0 .AND. V >= 0) PARALLEL_MIN = V
+       ENDIF
+    ENDIF
+    HOST_THREADS = 1
+    IF (PARALLEL_MIN >= 0) THEN
+       IF (WORK >= PARALLEL_MIN) HOST_THREADS = NTHREADS_CACHED
+    ELSE
+       IF (WORK >= MINWORK) HOST_THREADS = NTHREADS_CACHED
+    ENDIF
+  END FUNCTION HOST_THREADS
 
   ! ---------------------------------------------------------------- lookup
 
@@ -109,25 +196,37 @@ CONTAINS
     STATE_HASH = H
   END FUNCTION STATE_HASH
 
-  ! index of state X in the FSP (0 = absent); H = its hash, SLOT = where it is
-  ! or where it would be inserted
-  SUBROUTINE LOOKUP(FSP, X, IDX, H, SLOT)
+  ! index of state X in the FSP (0 = absent) and its hash H.  The slot comes from
+  ! the low bits of H, the tag kept beside the index from bits 8..39.
+  SUBROUTINE LOOKUP(FSP, X, IDX, H)
     CLASS(FINITE_STATE_PROJECTION), INTENT(IN) :: FSP
     INTEGER, INTENT(IN) :: X(:)
-    INTEGER, INTENT(OUT) :: IDX, SLOT
+    INTEGER, INTENT(OUT) :: IDX
     INTEGER(8), INTENT(OUT) :: H
-    INTEGER :: MASK, J, K
-    LOGICAL :: SAME
     H = STATE_HASH(X)
+    CALL PROBE(FSP, X, H, IDX)
+  END SUBROUTINE LOOKUP
+
+  ! the same with the hash already known
+  SUBROUTINE PROBE(FSP, X, H, IDX)
+    CLASS(FINITE_STATE_PROJECTION), INTENT(IN) :: FSP
+    INTEGER, INTENT(IN) :: X(:)
+    INTEGER(8), INTENT(IN) :: H
+    INTEGER, INTENT(OUT) :: IDX
+    INTEGER :: MASK, SLOT, J, K
+    INTEGER(8) :: E, TAG
+    LOGICAL :: SAME
     MASK = FSP%KTLEN - 1
     SLOT = INT(IAND(H, INT(MASK, 8))) + 1
+    TAG = ISHFT(H, -8)
     DO
-       J = FSP%KVTAB(SLOT)
-       IF (J == 0) THEN
+       E = FSP%KEYTAB(SLOT)
+       IF (E == 0_8) THEN
           IDX = 0
           RETURN
        ENDIF
-       IF (FSP%KEYTAB(SLOT) == H) THEN
+       IF (IAND(ISHFT(E, -32), LOW32) == TAG) THEN
+          J = INT(IAND(E, LOW32))
           SAME = .TRUE.
           DO K = 1, SIZE(X)
              IF (FSP%STATE(K, J) /= X(K)) THEN
@@ -142,29 +241,104 @@ CONTAINS
        ENDIF
        SLOT = IAND(SLOT, MASK) + 1
     ENDDO
-  END SUBROUTINE LOOKUP
+  END SUBROUTINE PROBE
 
-  SUBROUTINE TABLE_INSERT(FSP, H, SLOT, IDX)
+  ! enter (hash H -> index IDX) into the first free slot of its probe sequence
+  SUBROUTINE TABLE_INSERT(FSP, H, IDX)
     CLASS(FINITE_STATE_PROJECTION), INTENT(INOUT) :: FSP
     INTEGER(8), INTENT(IN) :: H
-    INTEGER, INTENT(IN) :: SLOT, IDX
-    FSP%KEYTAB(SLOT) = H
-    FSP%KVTAB(SLOT) = IDX
+    INTEGER, INTENT(IN) :: IDX
+    INTEGER :: MASK, SLOT
+    MASK = FSP%KTLEN - 1
+    SLOT = INT(IAND(H, INT(MASK, 8))) + 1
+    DO WHILE (FSP%KEYTAB(SLOT) /= 0_8)
+       SLOT = IAND(SLOT, MASK) + 1
+    ENDDO
+    FSP%KEYTAB(SLOT) = IOR(ISHFT(ISHFT(H, -8), 32), INT(IDX, 8))
   END SUBROUTINE TABLE_INSERT
 
+  ! enter all listed states into the (already sized) table.  Threaded: every
+  ! thread owns a contiguous range of slots and enters the states whose probe
+  ! sequence starts AND ends inside it (it reads all keys, writes only its own
+  ! slots); the few sequences that would leave a range are entered afterwards.
+  ! Which slot a state gets differs from the one-by-one order, what LOOKUP
+  ! returns does not.
   SUBROUTINE REBUILD_TABLE(FSP)
     CLASS(FINITE_STATE_PROJECTION), INTENT(INOUT) :: FSP
-    INTEGER :: I, SLOT, MASK
-    FSP%KVTAB = 0
+    INTEGER, PARAMETER :: AHEAD = 16, MAXLATE = 65536
+    INTEGER :: I, MASK, NT, NTH, TID, SLOT, NLATE, P
+    INTEGER(8) :: TOUCH, LO, HI
+    INTEGER, ALLOCATABLE :: LATE(:)
     MASK = FSP%KTLEN - 1
-    DO I = 1, FSP%SIZE
-       SLOT = INT(IAND(FSP%KEY(I), INT(MASK, 8))) + 1
-       DO WHILE (FSP%KVTAB(SLOT) /= 0)
-          SLOT = IAND(SLOT, MASK) + 1
+    NT = HOST_THREADS(FSP%SIZE, 65536)
+    IF (NT > 1) THEN
+       ALLOCATE(LATE(MAXLATE))
+       NLATE = 0
+       NTH = 1
+       !$OMP PARALLEL NUM_THREADS(NT) PRIVATE(TID, LO, HI, I, SLOT, P)
+       TID = 0
+       !$ TID = OMP_GET_THREAD_NUM()
+       !$OMP SINGLE
+       !$ NTH = OMP_GET_NUM_THREADS()
+       !$OMP END SINGLE
+       LO = 1 + INT(TID, 8) * FSP%KTLEN / NTH
+       HI = INT(TID + 1, 8) * FSP%KTLEN / NTH
+       FSP%KEYTAB(LO:HI) = 0_8
+       DO I = 1, FSP%SIZE
+          SLOT = INT(IAND(FSP%KEY(I), INT(MASK, 8))) + 1
+          IF (SLOT < LO .OR. SLOT > HI) CYCLE
+          DO WHILE (SLOT <= HI)
+             IF (FSP%KEYTAB(SLOT) == 0_8) EXIT
+             SLOT = SLOT + 1
+          ENDDO
+          IF (SLOT <= HI) THEN
+             FSP%KEYTAB(SLOT) = IOR(ISHFT(ISHFT(FSP%KEY(I), -8), 32), INT(I, 8))
+          ELSE
+             !$OMP ATOMIC CAPTURE
+             NLATE = NLATE + 1
+             P = NLATE
+             !$OMP END ATOMIC
+             IF (P <= MAXLATE) LATE(P) = I
+          ENDIF
        ENDDO
-       CALL TABLE_INSERT(FSP, FSP%KEY(I), SLOT, I)
+       !$OMP END PARALLEL
+       IF (NLATE <= MAXLATE) THEN
+          DO P = 1, NLATE
+             CALL TABLE_INSERT(FSP, FSP%KEY(LATE(P)), LATE(P))
+          ENDDO
+          RETURN
+       ENDIF
+       ! (not reached at load factor 1/2; start over one by one)
+    ENDIF
+    FSP%KEYTAB = 0_8
+    TOUCH = 0
+    DO I = 1, FSP%SIZE
+       ! the slot of a later entry is requested now, so that it has arrived when
+       ! its turn comes
+       IF (I + AHEAD <= FSP%SIZE) TOUCH = TOUCH + FSP%KEYTAB(INT(IAND(FSP%KEY(I + AHEAD), INT(MASK, 8))) + 1)
+       CALL TABLE_INSERT(FSP, FSP%KEY(I), I)
     ENDDO
+    TOUCH_SINK = INT(IAND(TOUCH, 1_8))
   END SUBROUTINE REBUILD_TABLE
+
+  ! make room for NEED listed states at load factor <= 1/2 (the table of the
+  ! states listed so far is rebuilt when it has to grow)
+  SUBROUTINE RESERVE_TABLE(FSP, NEED)
+    CLASS(FINITE_STATE_PROJECTION), INTENT(INOUT) :: FSP
+    INTEGER, INTENT(IN) :: NEED
+    INTEGER :: P
+    IF (2_8 * NEED <= FSP%KTLEN .AND. ALLOCATED(FSP%KEYTAB)) RETURN
+    P = MAX(FSP%KTLEN, 1024)
+    DO WHILE (P < 2_8 * NEED)
+       P = 2 * P
+    ENDDO
+    ! load factor <= 1/4 right after growing keeps rebuilds rare
+    IF (P < 4_8 * NEED) P = 2 * P
+    IF (ALLOCATED(FSP%KEYTAB)) DEALLOCATE(FSP%KEYTAB)
+    ALLOCATE(FSP%KEYTAB(P))
+    FSP%KTLEN = P
+    CALL REBUILD_TABLE(FSP)
+  END SUBROUTINE RESERVE_TABLE
 
   DOUBLE PRECISION FUNCTION POINTWISE_FSP(FSP, X)
     CLASS(FINITE_STATE_PROJECTION), INTENT(IN) :: FSP
@@ -181,47 +355,87 @@ CONTAINS
   INTEGER FUNCTION INDEX_STATE(FSP, X)
     CLASS(FINITE_STATE_PROJECTION), INTENT(IN) :: FSP
     INTEGER, INTENT(IN) :: X(:)
-    INTEGER :: SLOT
     INTEGER(8) :: H
     INDEX_STATE = 0
     IF (.NOT. LEGAL(X)) RETURN
-    CALL LOOKUP(FSP, X, INDEX_STATE, H, SLOT)
+    CALL LOOKUP(FSP, X, INDEX_STATE, H)
   END FUNCTION INDEX_STATE
 
   ! -------------------------------------------------------------- assembly
 
-  ! column of the generator for state number I (already in the list and in the
-  ! table): propensities, forward links to successors already present, and the
-  ! back links of predecessors already present (StateSpace.f90:204-244)
-  SUBROUTINE LINK_STATE(FSP, MODEL, I)
+  ! put state Y (known to be absent, hash H) at the end of the list: table entry,
+  ! zero probability, its propensities (StateSpace.f90:204-212) and an unlinked
+  ! generator column
+  SUBROUTINE APPEND_STATE(FSP, MODEL, Y, H)
     CLASS(FINITE_STATE_PROJECTION), INTENT(INOUT) :: FSP
     TYPE(CME_MODEL), INTENT(IN) :: MODEL
-    INTEGER, INTENT(IN) :: I
-    INTEGER :: K, J, SLOT, X(MODEL%NSPECIES), Y(MODEL%NSPECIES)
-    INTEGER(8) :: H
+    INTEGER, INTENT(IN) :: Y(:)
+    INTEGER(8), INTENT(IN) :: H
+    INTEGER :: L, K
     DOUBLE PRECISION :: A
-    X = FSP%STATE(1:MODEL%NSPECIES, I)
-    FSP%MATRIX%DIAG(I) = 0.0D0
+    L = FSP%SIZE + 1
+    IF (2_8 * L > FSP%KTLEN) CALL RESERVE_TABLE(FSP, L)
+    FSP%SIZE = L
+    FSP%MATRIX%SIZE = L
+    FSP%STATE(1:MODEL%NSPECIES, L) = Y(1:MODEL%NSPECIES)
+    FSP%KEY(L) = H
+    FSP%VECTOR(L) = 0.0D0
+    CALL TABLE_INSERT(FSP, H, L)
+    FSP%MATRIX%DIAG(L) = 0.0D0
     DO K = 1, MODEL%NREACTIONS
-       A = MODEL%PROPENSITY(X, K)
-       FSP%MATRIX%DIAG(I) = FSP%MATRIX%DIAG(I) + A
-       FSP%MATRIX%OFFDIAG(K, I) = A
+       A = MODEL%PROPENSITY(Y, K)
+       FSP%MATRIX%DIAG(L) = FSP%MATRIX%DIAG(L) + A
+       FSP%MATRIX%OFFDIAG(K, L) = A
+       FSP%MATRIX%ADJ(K, L) = 0
+    ENDDO
+  END SUBROUTINE APPEND_STATE
+
+  ! links of state number I (StateSpace.f90:213-244): its own column (successors
+  ! present, -1 for a negative population) and, if BACK, the entries of the
+  ! predecessors listed BEFORE ALO that now find it.  Reads the table only; the
+  ! entries written belong to I alone (each (k, j) has a single successor).
+  SUBROUTINE LINK_ONE(FSP, MODEL, I, ALO, BACK)
+    CLASS(FINITE_STATE_PROJECTION), INTENT(INOUT) :: FSP
+    TYPE(CME_MODEL), INTENT(IN) :: MODEL
+    INTEGER, INTENT(IN) :: I, ALO
+    LOGICAL, INTENT(IN) :: BACK
+    INTEGER :: K, J, X(MODEL%NSPECIES), Y(MODEL%NSPECIES)
+    INTEGER(8) :: H
+    X = FSP%STATE(1:MODEL%NSPECIES, I)
+    DO K = 1, MODEL%NREACTIONS
        Y = X + MODEL%STOICHIOMETRY(:, K)
        IF (ANY(Y < 0)) THEN
           FSP%MATRIX%ADJ(K, I) = -1
        ELSE
           J = 0
-          IF (LEGAL(Y)) CALL LOOKUP(FSP, Y, J, H, SLOT)
+          IF (LEGAL(Y)) CALL LOOKUP(FSP, Y, J, H)
           FSP%MATRIX%ADJ(K, I) = J
        ENDIF
     ENDDO
+    IF (.NOT. BACK) RETURN
     DO K = 1, MODEL%NREACTIONS
        Y = X - MODEL%STOICHIOMETRY(:, K)
        IF (.NOT. LEGAL(Y)) CYCLE
-       CALL LOOKUP(FSP, Y, J, H, SLOT)
-       IF (J > 0) FSP%MATRIX%ADJ(K, J) = I
+       CALL LOOKUP(FSP, Y, J, H)
+       IF (J > 0 .AND. J < ALO) FSP%MATRIX%ADJ(K, J) = I
     ENDDO
-  END SUBROUTINE LINK_STATE
+  END SUBROUTINE LINK_ONE
+
+  ! link the states ALO..AHI, all appended since the states before ALO were last
+  ! fully linked
+  SUBROUTINE LINK_NEW(FSP, MODEL, ALO, AHI, BACK)
+    CLASS(FINITE_STATE_PROJECTION), INTENT(INOUT) :: FSP
+    TYPE(CME_MODEL), INTENT(IN) :: MODEL
+    INTEGER, INTENT(IN) :: ALO, AHI
+    LOGICAL, INTENT(IN) :: BACK
+    INTEGER :: I, NT
+    NT = HOST_THREADS(AHI - ALO + 1, 1024)
+    !$OMP PARALLEL DO NUM_THREADS(NT) SCHEDULE(STATIC) IF(NT > 1)
+    DO I = ALO, AHI
+       CALL LINK_ONE(FSP, MODEL, I, ALO, BACK)
+    ENDDO
+    !$OMP END PARALLEL DO
+  END SUBROUTINE LINK_NEW
 
   ! append one state (if it is new) and connect it.  KEYIN is accepted for
   ! source compatibility (the reference passes a precomputed key) and ignored.
@@ -230,69 +444,178 @@ CONTAINS
     TYPE(CME_MODEL), INTENT(IN) :: MODEL
     INTEGER :: STATE(:)
     INTEGER(8), INTENT(IN), OPTIONAL :: KEYIN
-    INTEGER :: IDX, SLOT, L
+    INTEGER :: IDX
     INTEGER(8) :: H
     IF (.NOT. LEGAL(STATE(1:MODEL%NSPECIES))) RETURN
     IF (FSP%SIZE >= FSP%MAX_SIZE) RETURN
-    CALL LOOKUP(FSP, STATE(1:MODEL%NSPECIES), IDX, H, SLOT)
+    CALL LOOKUP(FSP, STATE(1:MODEL%NSPECIES), IDX, H)
     IF (IDX > 0) RETURN
-    FSP%SIZE = FSP%SIZE + 1
-    L = FSP%SIZE
-    FSP%STATE(1:MODEL%NSPECIES, L) = STATE(1:MODEL%NSPECIES)
-    FSP%KEY(L) = H
-    FSP%VECTOR(L) = 0.0D0
-    FSP%MATRIX%SIZE = L
-    CALL TABLE_INSERT(FSP, H, SLOT, L)
-    CALL LINK_STATE(FSP, MODEL, L)
+    CALL APPEND_STATE(FSP, MODEL, STATE(1:MODEL%NSPECIES), H)
+    CALL LINK_ONE(FSP, MODEL, FSP%SIZE, FSP%SIZE, .TRUE.)
   END SUBROUTINE ADD_STATE
 
   ! build table and generator for the seed list FSP%STATE(:,1:FSP%SIZE)
   SUBROUTINE MATRIX_STARTER(FSP, MODEL)
     TYPE(CME_MODEL), INTENT(IN) :: MODEL
     TYPE(FINITE_STATE_PROJECTION) :: FSP
-    INTEGER :: I, IDX, SLOT
+    INTEGER :: I, K, IDX, N
     INTEGER(8) :: H
-    FSP%KVTAB = 0
-    FSP%MATRIX%SIZE = FSP%SIZE
-    DO I = 1, FSP%SIZE
-       CALL LOOKUP(FSP, FSP%STATE(1:MODEL%NSPECIES, I), IDX, H, SLOT)
+    DOUBLE PRECISION :: A
+    N = FSP%SIZE
+    FSP%SIZE = 0                       ! nothing to carry over into a regrown table
+    CALL RESERVE_TABLE(FSP, MAX(N, 1))
+    FSP%KEYTAB = 0_8
+    FSP%SIZE = N
+    FSP%MATRIX%SIZE = N
+    DO I = 1, N
+       CALL LOOKUP(FSP, FSP%STATE(1:MODEL%NSPECIES, I), IDX, H)
        FSP%KEY(I) = H
-       IF (IDX == 0) CALL TABLE_INSERT(FSP, H, SLOT, I)
-       CALL LINK_STATE(FSP, MODEL, I)
+       IF (IDX == 0) CALL TABLE_INSERT(FSP, H, I)
+       FSP%MATRIX%DIAG(I) = 0.0D0
+       DO K = 1, MODEL%NREACTIONS
+          A = MODEL%PROPENSITY(FSP%STATE(1:MODEL%NSPECIES, I), K)
+          FSP%MATRIX%DIAG(I) = FSP%MATRIX%DIAG(I) + A
+          FSP%MATRIX%OFFDIAG(K, I) = A
+       ENDDO
     ENDDO
+    CALL LINK_NEW(FSP, MODEL, 1, N, .FALSE.)
   END SUBROUTINE MATRIX_STARTER
 
   ! add every state one reaction away from the current list (in list order,
-  ! reaction order; new states are appended and NOT revisited in this sweep)
+  ! reaction order; new states are appended and NOT revisited in this sweep).
+  ! Pass 1 (parallel) resolves the open links whose target is already listed and
+  ! collects the others per block of states; pass 2 (sequential, same (j, k)
+  ! order as the reference's double loop) appends the targets still absent;
+  ! pass 3 (parallel) links the appended states.
   SUBROUTINE ONESTEP_EXTENDER(FSP, MODEL)
     TYPE(FINITE_STATE_PROJECTION) :: FSP
     TYPE(CME_MODEL), INTENT(IN) :: MODEL
-    INTEGER :: J, K, N0, IDX, SLOT, Y(MODEL%NSPECIES)
-    INTEGER(8) :: H
+    INTEGER :: J, K, N0, IDX, SD, PD, NT, NTH, TID, T, C, Y(MODEL%NSPECIES)
+    INTEGER(8) :: H, LO, HI, TOTAL, TCLK
+    INTEGER(8), ALLOCATABLE :: OFFS(:)
+    INTEGER, ALLOCATABLE :: NC(:), CJ(:), CK(:)
+    INTEGER(8), ALLOCATABLE :: CH(:)
+    INTEGER, PARAMETER :: AHEAD = 12
+    INTEGER(8) :: TOUCH
+    SD = MODEL%NSPECIES
+    PD = MODEL%NREACTIONS
     N0 = FSP%SIZE
-    DO J = 1, N0
-       DO K = 1, MODEL%NREACTIONS
+    CALL TICK(0, TCLK)
+    NT = HOST_THREADS(N0, 4096)
+    ALLOCATE(OFFS(0:NT), NC(0:NT))
+    OFFS = 0
+    NC = 0
+    NTH = 1
+    !$OMP PARALLEL NUM_THREADS(NT) IF(NT > 1) PRIVATE(TID, LO, HI, J, K, C, Y, IDX, H)
+    TID = 0
+    !$ TID = OMP_GET_THREAD_NUM()
+    !$OMP SINGLE
+    !$ NTH = OMP_GET_NUM_THREADS()
+    !$OMP END SINGLE
+    LO = 1 + INT(TID, 8) * N0 / NTH
+    HI = INT(TID + 1, 8) * N0 / NTH
+    C = 0
+    DO J = INT(LO), INT(HI)
+       DO K = 1, PD
+          IF (FSP%MATRIX%ADJ(K, J) == 0) C = C + 1
+       ENDDO
+    ENDDO
+    OFFS(TID + 1) = C
+    !$OMP BARRIER
+    !$OMP SINGLE
+    DO T = 1, NTH
+       OFFS(T) = OFFS(T) + OFFS(T - 1)
+    ENDDO
+    TOTAL = OFFS(NTH)
+    ALLOCATE(CJ(MAX(TOTAL, 1_8)), CK(MAX(TOTAL, 1_8)), CH(MAX(TOTAL, 1_8)))
+    !$OMP END SINGLE
+    C = 0
+    DO J = INT(LO), INT(HI)
+       DO K = 1, PD
           IF (FSP%MATRIX%ADJ(K, J) /= 0) CYCLE
-          Y = FSP%STATE(1:MODEL%NSPECIES, J) + MODEL%STOICHIOMETRY(:, K)
+          Y = FSP%STATE(1:SD, J) + MODEL%STOICHIOMETRY(:, K)
           IF (.NOT. LEGAL(Y)) CYCLE
-          CALL LOOKUP(FSP, Y, IDX, H, SLOT)
+          CALL LOOKUP(FSP, Y, IDX, H)
           IF (IDX > 0) THEN
              FSP%MATRIX%ADJ(K, J) = IDX
           ELSE
-             CALL ADD_STATE(FSP, MODEL, Y)
-             IF (FSP%SIZE >= FSP%MAX_SIZE) STOP 'OVERFLOW ERROR: FSP SIZE EXCEEDS MEMORY LIMIT.'
+             C = C + 1
+             CJ(OFFS(TID) + C) = J
+             CK(OFFS(TID) + C) = K
+             CH(OFFS(TID) + C) = H
           ENDIF
        ENDDO
     ENDDO
+    NC(TID) = C
+    !$OMP END PARALLEL
+    CALL TICK(1, TCLK)
+
+    ! the candidates of all blocks, in order, as one list
+    TOTAL = 0
+    DO T = 0, NTH - 1
+       IF (OFFS(T) /= TOTAL) THEN
+          CJ(TOTAL + 1:TOTAL + NC(T)) = CJ(OFFS(T) + 1:OFFS(T) + NC(T))
+          CK(TOTAL + 1:TOTAL + NC(T)) = CK(OFFS(T) + 1:OFFS(T) + NC(T))
+          CH(TOTAL + 1:TOTAL + NC(T)) = CH(OFFS(T) + 1:OFFS(T) + NC(T))
+       ENDIF
+       TOTAL = TOTAL + NC(T)
+    ENDDO
+    TOUCH = 0
+    DO C = 1, INT(TOTAL)
+       ! request the table slot of a later candidate now (it is a cache miss)
+       IF (C + AHEAD <= TOTAL) TOUCH = TOUCH + FSP%KEYTAB(INT(IAND(CH(C + AHEAD), INT(FSP%KTLEN - 1, 8))) + 1)
+       J = CJ(C)
+       K = CK(C)
+       Y = FSP%STATE(1:SD, J) + MODEL%STOICHIOMETRY(:, K)
+       H = CH(C)
+       CALL PROBE(FSP, Y, H, IDX)
+       IF (IDX == 0) THEN
+          IF (FSP%SIZE >= FSP%MAX_SIZE) STOP 'OVERFLOW ERROR: FSP SIZE EXCEEDS MEMORY LIMIT.'
+          CALL APPEND_STATE(FSP, MODEL, Y, H)
+          IDX = FSP%SIZE
+          IF (FSP%SIZE >= FSP%MAX_SIZE) STOP 'OVERFLOW ERROR: FSP SIZE EXCEEDS MEMORY LIMIT.'
+       ENDIF
+       FSP%MATRIX%ADJ(K, J) = IDX
+    ENDDO
+    TOUCH_SINK = INT(IAND(TOUCH, 1_8))
+    CALL TICK(2, TCLK)
+    IF (FSP%SIZE > N0) CALL LINK_NEW(FSP, MODEL, N0 + 1, FSP%SIZE, .FALSE.)
+    CALL TICK(3, TCLK)
   END SUBROUTINE ONESTEP_EXTENDER
 
   ! largest power-of-ten threshold whose sub-threshold mass stays below DSUM
+  ! (StateSpace.f90:398-429).  The reference sweeps W once per threshold; here the
+  ! sums of the first NLEV thresholds are accumulated in one sweep, each of them
+  ! over the same entries in the same order, hence to the same bits.
   SUBROUTINE FIND_DROPTOL(SD, LSIZE, W, DROPTOL, DSUM)
     INTEGER :: SD, LSIZE
     DOUBLE PRECISION :: W(:), DROPTOL, DSUM
-    DOUBLE PRECISION :: S
-    INTEGER :: I
-    DROPTOL = 1.0D-08
+    INTEGER, PARAMETER :: NLEV = 24
+    DOUBLE PRECISION :: S, TOLS(NLEV), SL(NLEV), WI
+    INTEGER :: I, T
+    TOLS(1) = 1.0D-08
+    DO T = 2, NLEV
+       TOLS(T) = TOLS(T - 1) / 10.0D0
+    ENDDO
+    SL = 0.0D0
+    DO I = 1, LSIZE
+       WI = W(I)
+       IF (WI < TOLS(1) .AND. WI > 0) THEN
+          T = 1
+          DO WHILE (WI < TOLS(T))
+             SL(T) = SL(T) + WI
+             T = T + 1
+             IF (T > NLEV) EXIT
+          ENDDO
+       ENDIF
+    ENDDO
+    DO T = 1, NLEV
+       IF (SL(T) < DSUM) THEN
+          DROPTOL = TOLS(T)
+          RETURN
+       ENDIF
+    ENDDO
+    DROPTOL = TOLS(NLEV) / 10.0D0
     DO
        S = 0.0D0
        DO I = 1, LSIZE
@@ -314,56 +637,110 @@ CONTAINS
     DOUBLE PRECISION, INTENT(IN) :: AW(:)
     LOGICAL, INTENT(OUT) :: CHANGED
     LOGICAL, ALLOCATABLE :: DROP(:)
+    LOGICAL :: MARK
     INTEGER, ALLOCATABLE :: NEWIDX(:)
     DOUBLE PRECISION :: DROPTOL
-    INTEGER :: I, J, K, Q, N, CNT, SD, PD
+    INTEGER :: I, J, K, Q, N, CNT, SD, PD, NT, JF, NMOVE
+    INTEGER(8) :: TCLK
+    DOUBLE PRECISION, ALLOCATABLE :: SCRD(:, :)
+    INTEGER, ALLOCATABLE :: SCRI(:, :)
+    INTEGER(8), ALLOCATABLE :: SCRK(:)
     SD = MODEL%NSPECIES
     PD = MODEL%NREACTIONS
     N = FSP%SIZE
     CHANGED = .FALSE.
+    CALL TICK(0, TCLK)
     CALL FIND_DROPTOL(SD, N, W, DROPTOL, DSUM)
     ALLOCATE(DROP(N))
+    NT = HOST_THREADS(N, 65536)
     CNT = 0
+    !$OMP PARALLEL DO NUM_THREADS(NT) SCHEDULE(STATIC) IF(NT > 1) REDUCTION(+:CNT) PRIVATE(MARK)
     DO I = 1, N
-       DROP(I) = W(I) < DROPTOL
-       IF (DROP(I)) CNT = CNT + 1
-    ENDDO
-    DO I = 1, N
+       MARK = W(I) < DROPTOL
+       IF (MARK) CNT = CNT + 1
        IF (AW(I) > 1.0D-8) THEN
-          DROP(I) = .FALSE.
+          MARK = .FALSE.
           CNT = CNT - 1          ! decremented whether or not it was marked (:490-495)
        ENDIF
+       DROP(I) = MARK
     ENDDO
+    !$OMP END PARALLEL DO
+    CALL TICK(6, TCLK)
     IF (CNT * 1.0D0 / (N * 1.0D0) <= 0.1D0) RETURN
 
+    ! new numbers of the states that stay (list order is kept, :500-546)
     ALLOCATE(NEWIDX(N))
     Q = 0
+    JF = 0                             ! first state that moves
     DO J = 1, N
        IF (DROP(J)) THEN
           NEWIDX(J) = 0
+          IF (JF == 0) JF = J
        ELSE
           Q = Q + 1
           NEWIDX(J) = Q
-          IF (Q /= J) THEN
-             W(Q) = W(J)
-             FSP%STATE(1:SD, Q) = FSP%STATE(1:SD, J)
-             FSP%KEY(Q) = FSP%KEY(J)
-             FSP%MATRIX%DIAG(Q) = FSP%MATRIX%DIAG(J)
-             FSP%MATRIX%OFFDIAG(1:PD, Q) = FSP%MATRIX%OFFDIAG(1:PD, J)
-             FSP%MATRIX%ADJ(1:PD, Q) = FSP%MATRIX%ADJ(1:PD, J)
-          ENDIF
        ENDIF
     ENDDO
+    NT = HOST_THREADS(N, 65536)
+    ! every array is gathered into scratch storage and copied back, both in
+    ! parallel: the sweep is bound by memory bandwidth, which one thread cannot use
+    NMOVE = Q - JF + 1                 ! states JF..N that stay go to JF..Q
+    IF (JF == 0) NMOVE = 0
+    IF (NMOVE > 0) THEN
+       ALLOCATE(SCRD(MAX(PD, 2), NMOVE), SCRI(MAX(PD, SD), NMOVE), SCRK(NMOVE))
+       !$OMP PARALLEL NUM_THREADS(NT) IF(NT > 1) PRIVATE(J, I)
+       !$OMP DO SCHEDULE(STATIC)
+       DO J = JF, N
+          I = NEWIDX(J) - JF + 1
+          IF (I > 0) THEN
+             SCRD(1:PD, I) = FSP%MATRIX%OFFDIAG(1:PD, J)
+             SCRI(1:PD, I) = FSP%MATRIX%ADJ(1:PD, J)
+             SCRK(I) = FSP%KEY(J)
+          ENDIF
+       ENDDO
+       !$OMP END DO
+       !$OMP DO SCHEDULE(STATIC)
+       DO I = 1, NMOVE
+          FSP%MATRIX%OFFDIAG(1:PD, JF + I - 1) = SCRD(1:PD, I)
+          FSP%MATRIX%ADJ(1:PD, JF + I - 1) = SCRI(1:PD, I)
+          FSP%KEY(JF + I - 1) = SCRK(I)
+       ENDDO
+       !$OMP END DO
+       !$OMP DO SCHEDULE(STATIC)
+       DO J = JF, N
+          I = NEWIDX(J) - JF + 1
+          IF (I > 0) THEN
+             SCRD(1, I) = FSP%MATRIX%DIAG(J)
+             SCRD(2, I) = W(J)
+             SCRI(1:SD, I) = FSP%STATE(1:SD, J)
+          ENDIF
+       ENDDO
+       !$OMP END DO
+       !$OMP DO SCHEDULE(STATIC)
+       DO I = 1, NMOVE
+          FSP%MATRIX%DIAG(JF + I - 1) = SCRD(1, I)
+          W(JF + I - 1) = SCRD(2, I)
+          FSP%STATE(1:SD, JF + I - 1) = SCRI(1:SD, I)
+       ENDDO
+       !$OMP END DO
+       !$OMP END PARALLEL
+       DEALLOCATE(SCRD, SCRI, SCRK)
+    ENDIF
     W(Q + 1:N) = 0.0D0
     FSP%SIZE = Q
     FSP%MATRIX%SIZE = Q
+    CALL TICK(7, TCLK)
+    !$OMP PARALLEL DO NUM_THREADS(NT) SCHEDULE(STATIC) IF(NT > 1) PRIVATE(K, I)
     DO J = 1, Q
        DO K = 1, PD
           I = FSP%MATRIX%ADJ(K, J)
           IF (I > 0) FSP%MATRIX%ADJ(K, J) = NEWIDX(I)
        ENDDO
     ENDDO
+    !$OMP END PARALLEL DO
+    CALL TICK(8, TCLK)
     CALL REBUILD_TABLE(FSP)
+    CALL TICK(9, TCLK)
     CHANGED = .TRUE.
   END SUBROUTINE DROP_STATES_CORE
 
@@ -381,26 +758,113 @@ CONTAINS
     CALL DROP_STATES_CORE(W, FSP, MODEL, DSUM, AW, CHANGED)
   END SUBROUTINE DROP_STATES
 
+  ! Is the processor's RANDOM_NUMBER the generator of LLVM flang's runtime - the
+  ! minimal-standard congruential sequence s <- 48271 s mod (2**31 - 1) with
+  ! RANDOM_SEED(GET/PUT) exchanging s itself, one double from two consecutive
+  ! terms?  Decided by experiment at every call: the next four numbers and the
+  ! seed after them must agree, and PUT must be read back by GET; the generator
+  ! is left as it was found.  OK = .FALSE. leaves everything to RANDOM_NUMBER.
+  SUBROUTINE LCG_RECOGNISED(OK, S)
+    LOGICAL, INTENT(OUT) :: OK
+    INTEGER(8), INTENT(OUT) :: S
+    INTEGER :: NSEED, I
+    INTEGER :: SEED(1), SEED1(1)
+    INTEGER(8) :: G1, G2, Q
+    DOUBLE PRECISION :: X(4), Y
+    OK = .FALSE.
+    S = 0
+    CALL RANDOM_SEED(SIZE=NSEED)
+    IF (NSEED /= 1) RETURN
+    CALL RANDOM_SEED(GET=SEED)
+    IF (SEED(1) < 1 .OR. SEED(1) >= LCG_M) RETURN
+    CALL RANDOM_NUMBER(X)
+    CALL RANDOM_SEED(GET=SEED1)
+    Q = SEED(1)
+    OK = .TRUE.
+    DO I = 1, 4
+       G1 = Q
+       Q = MOD(Q * LCG_A, LCG_M)
+       G2 = Q
+       Q = MOD(Q * LCG_A, LCG_M)
+       Y = DBLE(ISHFT(IOR(ISHFT(G1, 30), IAND(G2 - 1_8, LCG_LOW)), -7)) * LCG_SCALE
+       IF (Y /= X(I)) OK = .FALSE.
+    ENDDO
+    IF (Q /= SEED1(1)) OK = .FALSE.
+    CALL RANDOM_SEED(PUT=SEED)
+    CALL RANDOM_SEED(GET=SEED1)
+    IF (SEED1(1) /= SEED(1)) THEN
+       ! PUT does not restore what GET gave: give the four numbers up for lost
+       OK = .FALSE.
+       RETURN
+    ENDIF
+    S = SEED(1)
+  END SUBROUTINE LCG_RECOGNISED
+
   ! grow the FSP along one Gillespie path per listed state, each of duration
   ! TIMESTEP at most (StateSpace.f90:550-630); two uniform numbers per jump, in
-  ! the reference's order, so that the same generator gives the same paths
+  ! the reference's order, so that the same generator gives the same paths.
+  ! The walk is sequential (the paths share one random stream and see the states
+  ! added by earlier paths); a state met for the first time is appended with its
+  ! propensities only, an open link (0) is resolved through the table as the
+  ! reference does for its own open links, and the columns of all appended
+  ! states are linked together afterwards.
   SUBROUTINE SSA_EXTENDER(TIMESTEP, FSP, MODEL)
     DOUBLE PRECISION :: TIMESTEP
     TYPE(FINITE_STATE_PROJECTION) :: FSP
     TYPE(CME_MODEL), INTENT(IN) :: MODEL
-    INTEGER :: SD, PD, J, J0, K, N0, IDX, SLOT, X(MODEL%NSPECIES), Y(MODEL%NSPECIES)
+    INTEGER :: SD, PD, J, J0, K, N0, IDX, TOUCH, X(MODEL%NSPECIES), Y(MODEL%NSPECIES)
     INTEGER(8) :: H
     DOUBLE PRECISION :: T, R1, R2, R2A, ACC
+    ! the uniform numbers are drawn NRB at a time (one runtime call instead of
+    ! NRB); what is left of the last block is given back at the end, so the
+    ! generator is left exactly where one call per number would leave it
+    INTEGER, PARAMETER :: NRB = 2048
+    DOUBLE PRECISION :: RB(NRB)
+    INTEGER :: RP, NSEED
+    INTEGER, ALLOCATABLE :: SEED0(:)
+    INTEGER(8) :: TCLK
+    ! Where RANDOM_NUMBER is recognised (LCG_RECOGNISED) its numbers are computed
+    ! here instead, and the generator is set to where it would stand at the end.
+    LOGICAL :: FAST
+    INTEGER(8) :: RS, G1, G2
     SD = MODEL%NSPECIES
     PD = MODEL%NREACTIONS
     N0 = FSP%SIZE
-    DO J0 = 1, N0
+    CALL RANDOM_SEED(SIZE=NSEED)
+    ALLOCATE(SEED0(NSEED))
+    RP = NRB
+    CALL LCG_RECOGNISED(FAST, RS)
+    TOUCH = 0
+    CALL TICK(0, TCLK)
+    PATHS: DO J0 = 1, N0
        J = J0
        X = FSP%STATE(1:SD, J)
        T = 0.0D0
        DO
-          CALL RANDOM_NUMBER(R1)
-          CALL RANDOM_NUMBER(R2)
+          ! start fetching the links of J now: which one is needed is known only
+          ! after the propensities have arrived
+          TOUCH = TOUCH + FSP%MATRIX%ADJ(1, J) + FSP%MATRIX%ADJ(PD, J)
+          IF (FAST) THEN
+             G1 = RS
+             RS = MOD(RS * LCG_A, LCG_M)
+             G2 = RS
+             RS = MOD(RS * LCG_A, LCG_M)
+             R1 = DBLE(ISHFT(IOR(ISHFT(G1, 30), IAND(G2 - 1_8, LCG_LOW)), -7)) * LCG_SCALE
+             G1 = RS
+             RS = MOD(RS * LCG_A, LCG_M)
+             G2 = RS
+             RS = MOD(RS * LCG_A, LCG_M)
+             R2 = DBLE(ISHFT(IOR(ISHFT(G1, 30), IAND(G2 - 1_8, LCG_LOW)), -7)) * LCG_SCALE
+          ELSE
+             IF (RP == NRB) THEN
+                CALL RANDOM_SEED(GET=SEED0)
+                CALL RANDOM_NUMBER(RB)
+                RP = 0
+             ENDIF
+             R1 = RB(RP + 1)
+             R2 = RB(RP + 2)
+             RP = RP + 2
+          ENDIF
           T = MIN(TIMESTEP, T + (-LOG(R1) / FSP%MATRIX%DIAG(J)))
           ! pick the reaction whose cumulative propensity first reaches r2*a0
           ACC = FSP%MATRIX%OFFDIAG(1, J)
@@ -417,23 +881,38 @@ CONTAINS
           ENDIF
           IF (FSP%MATRIX%ADJ(K, J) == 0) THEN
              IDX = 0
-             IF (LEGAL(Y)) CALL LOOKUP(FSP, Y, IDX, H, SLOT)
+             IF (LEGAL(Y)) CALL LOOKUP(FSP, Y, IDX, H)
              IF (IDX > 0) THEN
+                ! (a link the final linking would set to the same value: later
+                ! paths through J need no look-up)
+                FSP%MATRIX%ADJ(K, J) = IDX
                 J = IDX
              ELSE
-                IF (FSP%SIZE >= FSP%MAX_SIZE) RETURN
+                IF (FSP%SIZE >= FSP%MAX_SIZE) EXIT PATHS
                 IF (.NOT. LEGAL(Y)) EXIT
-                CALL ADD_STATE(FSP, MODEL, Y)
+                CALL APPEND_STATE(FSP, MODEL, Y, H)
+                FSP%MATRIX%ADJ(K, J) = FSP%SIZE
                 J = FSP%SIZE
              ENDIF
           ELSE
              J = FSP%MATRIX%ADJ(K, J)
           ENDIF
-          X = FSP%STATE(1:SD, J)
+          X = Y                      ! = FSP%STATE(1:SD, J)
           ! a path ends at the horizon or when it falls back onto an earlier seed
           IF (.NOT. (T < TIMESTEP .AND. J >= J0)) EXIT
        ENDDO
-    ENDDO
+    ENDDO PATHS
+    IF (FAST) THEN
+       SEED0(1) = INT(RS)
+       CALL RANDOM_SEED(PUT=SEED0)
+    ELSE IF (RP < NRB) THEN
+       CALL RANDOM_SEED(PUT=SEED0)
+       IF (RP > 0) CALL RANDOM_NUMBER(RB(1:RP))
+    ENDIF
+    CALL TICK(4, TCLK)
+    IF (FSP%SIZE > N0) CALL LINK_NEW(FSP, MODEL, N0 + 1, FSP%SIZE, .TRUE.)
+    CALL TICK(5, TCLK)
+    TOUCH_SINK = TOUCH
   END SUBROUTINE SSA_EXTENDER
 
 END MODULE STATESPACE

@@ -103,11 +103,60 @@ ASSEMBLY_CASES = [("toggle", 5), ("toggle", 10), ("toggle", 20),
                   ("goutsias", 5), ("goutsias", 10), ("goutsias", 16)]
 
 
+# (model, rounds of SSA_EXTENDER + ONESTEP_EXTENDER, path duration)
+SSA_CASES = [("toggle", 10, 0.1), ("repressilator", 8, 0.05), ("goutsias", 12, 2.0)]
+
+
+def ssa_fixture_name(name, k, dt):
+    return f"ssa_{name}_k{k}_dt{dt:g}.npz"
+
+
+def make_ssa(tmp):
+    # G1b: SSA paths + one-step reachability on the default random stream
+    # (StateSpace.f90:347-396, :550-630); integer arrays bit-exact
+    for name, k, dt in SSA_CASES:
+        p = os.path.join(tmp, f"ssa_{name}_{k}.bin")
+        run_dump(["ssa", name, str(k), repr(dt), p])
+        d = read_fsp(p)
+        np.savez_compressed(os.path.join(GOLDEN, ssa_fixture_name(name, k, dt)), k=np.int32(k), dt=dt,
+                            ns=d["ns"], nr=d["nr"], n=d["n"], state=d["state"], adj=d["adj"], diag=d["diag"],
+                            next_uniform=d["vector"][0])
+        print(f"ssa {name} k={k} dt={dt}: N={d['n']}")
+
+
+# (model, one-step sweeps before the drop, mass bound DSUM)
+DROP_CASES = [("toggle", 20, 1e-6), ("goutsias", 12, 1e-7), ("goutsias", 16, 1e-12), ("repressilator", 10, 1e-4)]
+
+
+def drop_fixture_name(name, k, dsum):
+    return f"drop_{name}_k{k}_dsum{dsum:g}.npz"
+
+
+def make_drop(tmp):
+    # G1c: DROP_STATES + the sweep that follows it (StateSpace.f90:398-548), and
+    # FIND_DROPTOL alone over ten mass bounds
+    for name, k, dsum in DROP_CASES:
+        p = os.path.join(tmp, f"drop_{name}_{k}.bin")
+        run_dump(["drop", name, str(k), repr(dsum), p])
+        d = read_fsp(p)
+        np.savez_compressed(os.path.join(GOLDEN, drop_fixture_name(name, k, dsum)), k=np.int32(k), dsum=dsum, **d)
+        print(f"drop {name} k={k} dsum={dsum}: N={d['n']}")
+    p = os.path.join(tmp, "droptol.bin")
+    run_dump(["droptol", p])
+    a = np.fromfile(p).reshape(2, -1)
+    np.savez_compressed(os.path.join(GOLDEN, "droptol.npz"), dsum=a[0], droptol=a[1])
+    print("droptol", a[1])
+
+
 def main():
     if not os.path.exists(os.path.join(REF_DIR, "ref_dump")):
         sys.exit("oracle/_ref/ref_dump missing: run `make -C oracle` where /root/reference exists")
     os.makedirs(GOLDEN, exist_ok=True)
     tmp = tempfile.mkdtemp(prefix="kfsp_golden_")
+    make_ssa(tmp)
+    make_drop(tmp)
+    if sys.argv[1:] == ["statespace"]:
+        return
 
     # G1: assembly (integer arrays bit-exact, StateSpace.f90:248-396)
     for name, k in ASSEMBLY_CASES:

@@ -9,11 +9,15 @@
 !   MODELMODULE  : CME_MODEL%LOAD/CREATE/RESET_PARAMETERS/PROPENSITY, CUSTOMPROP
 !                  (src/model/ModelModule.f90:14-42)
 !   STATESPACE   : FINITE_STATE_PROJECTION%CREATE, MATRIX_STARTER,
-!                  ONESTEP_EXTENDER (src/state_space/StateSpace.f90:19-45,248,347)
+!                  ONESTEP_EXTENDER, SSA_EXTENDER, FIND_DROPTOL, DROP_STATES
+!                  (src/state_space/StateSpace.f90:19-45,248,347,398,431,550)
 !   KRYLOVSOLVER : CME_SOLVE (src/fsp/KrylovSolver.f90:7)
 !   DGPADM       : src/expokit/dgpadm.f:2
 !
 ! usage:  ref_dump assembly <toggle|repressilator|goutsias> <k> <out.bin>
+!         ref_dump ssa      <toggle|repressilator|goutsias> <k> <dt> <out.bin>
+!         ref_dump drop     <toggle|repressilator|goutsias> <k> <dsum> <out.bin>
+!         ref_dump droptol  <out.bin>
 !         ref_dump solve    <case> <out.bin> [T]    (log goes to stdout)
 !         ref_dump padm     <out.bin>
 !         ref_dump proptable <out.bin>
@@ -43,23 +47,54 @@ CONTAINS
 
 END MODULE REF_DUMP_RING
 
+MODULE REF_DUMP_MATVEC
+  ! y = A x in the scatter form of the column layout (what the solver hands to
+  ! DROP_STATES as its FMATVEC argument, KrylovSolver.f90:511,577-607)
+  USE STATESPACE
+  IMPLICIT NONE
+CONTAINS
+  SUBROUTINE DUMP_MATVEC(X, Y, MATRIX)
+    DOUBLE PRECISION :: X(*), Y(*)
+    TYPE(FSP_MATRIX) :: MATRIX
+    INTEGER :: I, K, J
+    DO I = 1, MATRIX%SIZE
+       Y(I) = 0.0D0
+    ENDDO
+    DO I = 1, MATRIX%SIZE
+       Y(I) = Y(I) - MATRIX%DIAG(I) * X(I)
+       DO K = 1, SIZE(MATRIX%ADJ, 1)
+          J = MATRIX%ADJ(K, I)
+          IF (J > 0) Y(J) = Y(J) + MATRIX%OFFDIAG(K, I) * X(I)
+       ENDDO
+    ENDDO
+  END SUBROUTINE DUMP_MATVEC
+END MODULE REF_DUMP_MATVEC
+
 PROGRAM REF_DUMP
   USE REF_DUMP_RING
+  USE REF_DUMP_MATVEC
   USE STATESPACE
   USE KRYLOVSOLVER
   IMPLICIT NONE
 
-  CHARACTER(LEN=256) :: MODE, ARG2, ARG3, ARG4
+  CHARACTER(LEN=256) :: MODE, ARG2, ARG3, ARG4, ARG5
   INTEGER, PARAMETER :: TABLEN = 100009   ! prime, see StateSpace.f90:9
 
   CALL GET_COMMAND_ARGUMENT(1, MODE)
   CALL GET_COMMAND_ARGUMENT(2, ARG2)
   CALL GET_COMMAND_ARGUMENT(3, ARG3)
   CALL GET_COMMAND_ARGUMENT(4, ARG4)
+  CALL GET_COMMAND_ARGUMENT(5, ARG5)
 
   SELECT CASE (TRIM(MODE))
   CASE ('assembly')
      CALL DO_ASSEMBLY(TRIM(ARG2), TRIM(ARG3), TRIM(ARG4))
+  CASE ('ssa')
+     CALL DO_SSA(TRIM(ARG2), TRIM(ARG3), TRIM(ARG4), TRIM(ARG5))
+  CASE ('drop')
+     CALL DO_DROP(TRIM(ARG2), TRIM(ARG3), TRIM(ARG4), TRIM(ARG5))
+  CASE ('droptol')
+     CALL DO_DROPTOL(TRIM(ARG2))
   CASE ('solve')
      CALL DO_SOLVE(TRIM(ARG2), TRIM(ARG3))
   CASE ('padm')
@@ -139,6 +174,111 @@ CONTAINS
     CALL WRITE_FSP(FNAME, MODEL, FSP)
     PRINT *, 'ASSEMBLY ', NAME, ' K=', K, ' N=', FSP%SIZE
   END SUBROUTINE DO_ASSEMBLY
+
+  !---------------------------------------------------------------- G1b
+  ! k rounds of SSA_EXTENDER(dt) + ONESTEP_EXTENDER, as the solver issues them
+  ! (KrylovSolver.f90:528-529), on the default random stream.  One more uniform
+  ! number is drawn at the end and stored in VECTOR(1): it pins how many numbers
+  ! the paths consumed.
+  SUBROUTINE DO_SSA(NAME, KSTR, DTSTR, FNAME)
+    CHARACTER(LEN=*), INTENT(IN) :: NAME, KSTR, DTSTR, FNAME
+    TYPE(CME_MODEL) :: MODEL
+    TYPE(FINITE_STATE_PROJECTION) :: FSP
+    INTEGER, ALLOCATABLE :: X0(:)
+    INTEGER :: K, I
+    DOUBLE PRECISION :: DT, R
+    READ(KSTR, *) K
+    READ(DTSTR, *) DT
+    CALL LOAD_INPUT_MODEL(NAME, MODEL, X0)
+    CALL FSP%CREATE(MODEL, TABLEN)
+    FSP%SIZE = 1
+    FSP%STATE(:, 1) = X0
+    FSP%VECTOR = 0.0D0
+    CALL MATRIX_STARTER(FSP, MODEL)
+    DO I = 1, K
+       CALL SSA_EXTENDER(DT, FSP, MODEL)
+       CALL ONESTEP_EXTENDER(FSP, MODEL)
+    ENDDO
+    CALL RANDOM_NUMBER(R)
+    FSP%VECTOR(1) = R
+    CALL WRITE_FSP(FNAME, MODEL, FSP)
+    PRINT *, 'SSA ', NAME, ' K=', K, ' DT=', DT, ' N=', FSP%SIZE
+  END SUBROUTINE DO_SSA
+
+  !---------------------------------------------------------------- G1c
+  ! a deterministic positive vector spanning 1e-2 .. 1e-16 (golden-ratio sequence)
+  SUBROUTINE SPREAD_VECTOR(N, W)
+    INTEGER, INTENT(IN) :: N
+    DOUBLE PRECISION, INTENT(OUT) :: W(:)
+    INTEGER :: I
+    DOUBLE PRECISION :: U
+    DO I = 1, N
+       U = I * 0.6180339887498949D0
+       U = U - AINT(U)
+       W(I) = 10.0D0**(-2.0D0 - 14.0D0 * U)
+    ENDDO
+  END SUBROUTINE SPREAD_VECTOR
+
+  ! DROP_STATES (StateSpace.f90:431-548) on the FSP of the assembly case with a
+  ! decaying vector, then one ONESTEP_EXTENDER on what is left; the vector
+  ! after the drop is dumped in VECTOR
+  SUBROUTINE DO_DROP(NAME, KSTR, DSTR, FNAME)
+    CHARACTER(LEN=*), INTENT(IN) :: NAME, KSTR, DSTR, FNAME
+    TYPE(CME_MODEL) :: MODEL
+    TYPE(FINITE_STATE_PROJECTION) :: FSP
+    INTEGER, ALLOCATABLE :: X0(:)
+    DOUBLE PRECISION, ALLOCATABLE :: W(:)
+    INTEGER :: K, I, N1
+    DOUBLE PRECISION :: DSUM
+    READ(KSTR, *) K
+    READ(DSTR, *) DSUM
+    CALL LOAD_INPUT_MODEL(NAME, MODEL, X0)
+    CALL FSP%CREATE(MODEL, TABLEN)
+    FSP%SIZE = 1
+    FSP%STATE(:, 1) = X0
+    FSP%VECTOR = 0.0D0
+    CALL MATRIX_STARTER(FSP, MODEL)
+    DO I = 1, K
+       CALL ONESTEP_EXTENDER(FSP, MODEL)
+    ENDDO
+    ALLOCATE(W(TABLEN))
+    W = 0.0D0
+    ! decays over 18 decades along the list (breadth-first order: neighbours
+    ! have similar magnitudes, as in a solve), with every 7th entry raised so
+    ! that kept and dropped states interleave
+    N1 = FSP%SIZE
+    DO I = 1, N1
+       W(I) = 10.0D0**(-2.0D0 - 18.0D0 * DBLE(I - 1) / DBLE(MAX(N1 - 1, 1)))
+       IF (MOD(I, 7) == 0) W(I) = W(I) * 1.0D3
+    ENDDO
+    PRINT *, 'N BEFORE DROP=', N1
+    CALL DROP_STATES(W, FSP, MODEL, DSUM, DUMP_MATVEC)
+    N1 = FSP%SIZE
+    FSP%VECTOR(1:N1) = W(1:N1)
+    CALL ONESTEP_EXTENDER(FSP, MODEL)
+    CALL WRITE_FSP(FNAME, MODEL, FSP)
+    PRINT *, 'DROP ', NAME, ' K=', K, ' DSUM=', DSUM, ' N AFTER DROP=', N1, ' N=', FSP%SIZE
+  END SUBROUTINE DO_DROP
+
+  ! FIND_DROPTOL (StateSpace.f90:398-427) for a range of mass bounds
+  SUBROUTINE DO_DROPTOL(FNAME)
+    CHARACTER(LEN=*), INTENT(IN) :: FNAME
+    INTEGER, PARAMETER :: N = 50000, ND = 10
+    DOUBLE PRECISION :: W(N), TOL(ND), DS(ND)
+    INTEGER :: I, U
+    CALL SPREAD_VECTOR(N, W)
+    W(7:N:13) = 0.0D0
+    W(5:N:17) = -W(5:N:17)
+    W(3:N:11) = W(3:N:11) * 1.0D-12
+    DS = [1.0D-1, 1.0D-4, 1.0D-6, 1.0D-8, 1.0D-10, 1.0D-13, 1.0D-16, 1.0D-20, 1.0D-24, 1.0D-27]
+    DO I = 1, ND
+       CALL FIND_DROPTOL(6, N, W, TOL(I), DS(I))
+    ENDDO
+    OPEN(NEWUNIT=U, FILE=FNAME, ACCESS='STREAM', FORM='UNFORMATTED', STATUS='REPLACE')
+    WRITE(U) DS, TOL
+    CLOSE(U)
+    PRINT *, 'DROPTOL ', TOL
+  END SUBROUTINE DO_DROPTOL
 
   !---------------------------------------------------------------- G3 / G6
   SUBROUTINE DO_SOLVE(CASENAME, FNAME)

@@ -26,9 +26,9 @@ def dump():
     return DUMP
 
 
-def _run(dump, args, tmp_path):
+def _run(dump, args, tmp_path, env=None):
     out = subprocess.run([dump] + args, cwd=MODELS, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
-                         text=True, timeout=900)
+                         text=True, timeout=900, env=None if env is None else dict(os.environ, **env))
     assert out.returncode == 0, out.stdout[-2000:]
     return out.stdout
 
@@ -46,6 +46,58 @@ def test_assembly_is_bit_exact(dump, tmp_path, name, k):
     assert d["n"] == int(g["n"])
     for key in ("state", "adj", "offdiag", "diag"):
         assert np.array_equal(d[key], g[key]), key
+
+
+def _threads_env(threads):
+    # with more than one thread every sweep runs its threaded code, whatever the size
+    return {"KFSP_HOST_THREADS": str(threads)} | ({"KFSP_HOST_PARALLEL_MIN": "1"} if threads > 1 else {})
+
+
+@pytest.mark.parametrize("threads", [1, 4])
+@pytest.mark.parametrize("name,k,dt", MG.SSA_CASES)
+def test_ssa_and_onestep_growth_is_bit_exact(dump, tmp_path, name, k, dt, threads):
+    """k rounds of SSA_EXTENDER(dt) + ONESTEP_EXTENDER on the default random
+    stream (StateSpace.f90:347-396, :550-630): same state list, same adjacency,
+    same total propensities as the reference, for the sequential and for the
+    threaded linking sweeps, and the random stream is left where the reference
+    leaves it (the next uniform number is the same)."""
+    p = str(tmp_path / "g.bin")
+    _run(dump, ["ssa", name, str(k), repr(dt), p], tmp_path, env=_threads_env(threads))
+    d = MG.read_fsp(p)
+    g = np.load(os.path.join(GOLDEN, MG.ssa_fixture_name(name, k, dt)))
+    assert d["n"] == int(g["n"])
+    for key in ("state", "adj", "diag"):
+        assert np.array_equal(d[key], g[key]), key
+    assert d["vector"][0] == float(g["next_uniform"])
+
+
+@pytest.mark.parametrize("threads", [1, 4])
+@pytest.mark.parametrize("name,k,dsum", MG.DROP_CASES)
+def test_drop_states_is_bit_exact(dump, tmp_path, name, k, dsum, threads):
+    """DROP_STATES (threshold search, derivative guard, the 10 % rule, compaction
+    and renumbering, StateSpace.f90:398-548) followed by one ONESTEP_EXTENDER on
+    the compacted FSP: list, links, propensities and the compacted vector as the
+    reference leaves them.  The product A*w it needs comes from the driver's own
+    scatter loop here (the GPU tests cover the device product)."""
+    p = str(tmp_path / "d.bin")
+    _run(dump, ["drop", name, str(k), repr(dsum), p], tmp_path, env=_threads_env(threads))
+    d = MG.read_fsp(p)
+    g = np.load(os.path.join(GOLDEN, MG.drop_fixture_name(name, k, dsum)))
+    assert d["n"] == int(g["n"])
+    for key in ("state", "adj", "offdiag", "diag", "vector"):
+        assert np.array_equal(d[key], g[key]), key
+
+
+def test_find_droptol_matches_reference(dump, tmp_path):
+    """FIND_DROPTOL over ten mass bounds on a vector with zeros, negative and
+    tiny entries (StateSpace.f90:398-427): the one-sweep search returns the
+    thresholds of the reference's sweep-per-threshold loop."""
+    p = str(tmp_path / "t.bin")
+    _run(dump, ["droptol", p], tmp_path)
+    a = np.fromfile(p).reshape(2, -1)
+    g = np.load(os.path.join(GOLDEN, "droptol.npz"))
+    assert np.array_equal(a[0], g["dsum"])
+    assert np.array_equal(a[1], g["droptol"])
 
 
 def test_parsed_propensities_match_reference_parser(dump, tmp_path):
