@@ -812,7 +812,9 @@ CONTAINS
     DOUBLE PRECISION :: TIMESTEP
     TYPE(FINITE_STATE_PROJECTION) :: FSP
     TYPE(CME_MODEL), INTENT(IN) :: MODEL
-    INTEGER :: SD, PD, J, J0, K, N0, IDX, TOUCH, X(MODEL%NSPECIES), Y(MODEL%NSPECIES)
+    INTEGER :: SD, PD, J, J0, K, S, N0, IDX, TOUCH, X(MODEL%NSPECIES), Y(MODEL%NSPECIES)
+    INTEGER :: NU(MODEL%NSPECIES, MODEL%NREACTIONS)
+    LOGICAL :: NEG
     INTEGER(8) :: H
     DOUBLE PRECISION :: T, R1, R2, R2A, ACC
     ! the uniform numbers are drawn NRB at a time (one runtime call instead of
@@ -834,6 +836,7 @@ CONTAINS
     ALLOCATE(SEED0(NSEED))
     RP = NRB
     CALL LCG_RECOGNISED(FAST, RS)
+    NU = MODEL%STOICHIOMETRY(1:SD, 1:PD)
     TOUCH = 0
     CALL TICK(0, TCLK)
     PATHS: DO J0 = 1, N0
@@ -874,8 +877,12 @@ CONTAINS
              K = K + 1
              ACC = ACC + FSP%MATRIX%OFFDIAG(K, J)
           ENDDO
-          Y = X + MODEL%STOICHIOMETRY(:, K)
-          IF (ANY(Y < 0)) THEN
+          NEG = .FALSE.
+          DO S = 1, SD
+             Y(S) = X(S) + NU(S, K)
+             NEG = NEG .OR. Y(S) < 0
+          ENDDO
+          IF (NEG) THEN
              FSP%MATRIX%ADJ(K, J) = -1
              EXIT
           ENDIF
