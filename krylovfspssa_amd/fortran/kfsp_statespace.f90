@@ -65,7 +65,7 @@ MODULE STATESPACE
      PROCEDURE :: INDEX => INDEX_STATE
   END TYPE FINITE_STATE_PROJECTION
 
-  PRIVATE :: TICK, STATE_HASH, LOOKUP, PROBE, TABLE_INSERT, REBUILD_TABLE, LEGAL, RESERVE_TABLE, APPEND_STATE, &
+  PRIVATE :: TICK, STATE_HASH, LOOKUP, PROBE, INSERT_RANGE, APPEND_CANDIDATES, TABLE_INSERT, REBUILD_TABLE, LEGAL, RESERVE_TABLE, APPEND_STATE, &
        LINK_ONE, LINK_NEW, HOST_THREADS
 
   INTEGER(8), PARAMETER, PRIVATE :: LOW32 = 4294967295_8
@@ -257,20 +257,22 @@ CONTAINS
     FSP%KEYTAB(SLOT) = IOR(ISHFT(ISHFT(H, -8), 32), INT(IDX, 8))
   END SUBROUTINE TABLE_INSERT
 
-  ! enter all listed states into the (already sized) table.  Threaded: every
-  ! thread owns a contiguous range of slots and enters the states whose probe
-  ! sequence starts AND ends inside it (it reads all keys, writes only its own
-  ! slots); the few sequences that would leave a range are entered afterwards.
-  ! Which slot a state gets differs from the one-by-one order, what LOOKUP
-  ! returns does not.
-  SUBROUTINE REBUILD_TABLE(FSP)
+  ! enter the listed states ILO..IHI (none of them in the table yet) into the
+  ! table.  Threaded: every thread owns a contiguous range of slots and enters the
+  ! states whose probe sequence starts AND ends inside it (it reads all keys,
+  ! writes only its own slots); the few sequences that would leave a range are
+  ! entered afterwards.  Which slot a state gets differs from the one-by-one
+  ! order, what LOOKUP returns does not.  CLEAR empties the table first.
+  SUBROUTINE INSERT_RANGE(FSP, ILO, IHI, CLEAR)
     CLASS(FINITE_STATE_PROJECTION), INTENT(INOUT) :: FSP
+    INTEGER, INTENT(IN) :: ILO, IHI
+    LOGICAL, INTENT(IN) :: CLEAR
     INTEGER, PARAMETER :: AHEAD = 16, MAXLATE = 65536
     INTEGER :: I, MASK, NT, NTH, TID, SLOT, NLATE, P
     INTEGER(8) :: TOUCH, LO, HI
     INTEGER, ALLOCATABLE :: LATE(:)
     MASK = FSP%KTLEN - 1
-    NT = HOST_THREADS(FSP%SIZE, 65536)
+    NT = HOST_THREADS(IHI - ILO + 1, 65536)
     IF (NT > 1) THEN
        ALLOCATE(LATE(MAXLATE))
        NLATE = 0
@@ -283,8 +285,8 @@ CONTAINS
        !$OMP END SINGLE
        LO = 1 + INT(TID, 8) * FSP%KTLEN / NTH
        HI = INT(TID + 1, 8) * FSP%KTLEN / NTH
-       FSP%KEYTAB(LO:HI) = 0_8
-       DO I = 1, FSP%SIZE
+       IF (CLEAR) FSP%KEYTAB(LO:HI) = 0_8
+       DO I = ILO, IHI
           SLOT = INT(IAND(FSP%KEY(I), INT(MASK, 8))) + 1
           IF (SLOT < LO .OR. SLOT > HI) CYCLE
           DO WHILE (SLOT <= HI)
@@ -302,23 +304,27 @@ CONTAINS
           ENDIF
        ENDDO
        !$OMP END PARALLEL
-       IF (NLATE <= MAXLATE) THEN
-          DO P = 1, NLATE
-             CALL TABLE_INSERT(FSP, FSP%KEY(LATE(P)), LATE(P))
-          ENDDO
-          RETURN
-       ENDIF
-       ! (not reached at load factor 1/2; start over one by one)
+       ! (more than MAXLATE leftovers cannot happen at load factor 1/2)
+       IF (NLATE > MAXLATE) STOP 'KFSP STATESPACE: TABLE RANGE OVERFLOW'
+       DO P = 1, NLATE
+          CALL TABLE_INSERT(FSP, FSP%KEY(LATE(P)), LATE(P))
+       ENDDO
+       RETURN
     ENDIF
-    FSP%KEYTAB = 0_8
+    IF (CLEAR) FSP%KEYTAB = 0_8
     TOUCH = 0
-    DO I = 1, FSP%SIZE
+    DO I = ILO, IHI
        ! the slot of a later entry is requested now, so that it has arrived when
        ! its turn comes
-       IF (I + AHEAD <= FSP%SIZE) TOUCH = TOUCH + FSP%KEYTAB(INT(IAND(FSP%KEY(I + AHEAD), INT(MASK, 8))) + 1)
+       IF (I + AHEAD <= IHI) TOUCH = TOUCH + FSP%KEYTAB(INT(IAND(FSP%KEY(I + AHEAD), INT(MASK, 8))) + 1)
        CALL TABLE_INSERT(FSP, FSP%KEY(I), I)
     ENDDO
     TOUCH_SINK = INT(IAND(TOUCH, 1_8))
+  END SUBROUTINE INSERT_RANGE
+
+  SUBROUTINE REBUILD_TABLE(FSP)
+    CLASS(FINITE_STATE_PROJECTION), INTENT(INOUT) :: FSP
+    CALL INSERT_RANGE(FSP, 1, FSP%SIZE, .TRUE.)
   END SUBROUTINE REBUILD_TABLE
 
   ! make room for NEED listed states at load factor <= 1/2 (the table of the
@@ -481,6 +487,127 @@ CONTAINS
     CALL LINK_NEW(FSP, MODEL, 1, N, .FALSE.)
   END SUBROUTINE MATRIX_STARTER
 
+  ! Pass 2 of ONESTEP_EXTENDER for a long candidate list.  Candidate C is the open
+  ! link (CJ(C), CK(C)) whose target, hash CH(C), is not listed.  The reference
+  ! appends each target when its first candidate comes up; so the new states are
+  ! the DISTINCT targets in order of first appearance.  Threads split the
+  ! candidates by hash (equal targets meet in the same thread), find for each the
+  ! first candidate with the same target (REP), a sweep over REP numbers the new
+  ! states, and the rest - state, key, table entry, the links of all candidates -
+  ! is filled in in parallel.  Propensity functions are called afterwards in the
+  ! reference's order (state by state) from this thread, unless the model is a
+  ! parsed one, whose evaluator is known to be re-entrant.
+  SUBROUTINE APPEND_CANDIDATES(FSP, MODEL, TOTAL, CJ, CK, CH)
+    TYPE(FINITE_STATE_PROJECTION) :: FSP
+    TYPE(CME_MODEL), INTENT(IN) :: MODEL
+    INTEGER, INTENT(IN) :: TOTAL, CJ(:), CK(:)
+    INTEGER(8), INTENT(IN) :: CH(:)
+    INTEGER, ALLOCATABLE :: REP(:), NEWOF(:), LT(:)
+    INTEGER :: SD, PD, NT, NTH, TID, C, R, S, K, L, N0, NNEW, MINE, LTLEN, SLOT
+    INTEGER :: NU(MODEL%NSPECIES, MODEL%NREACTIONS)
+    LOGICAL :: SAME, PARPROP
+    DOUBLE PRECISION :: A
+    SD = MODEL%NSPECIES
+    PD = MODEL%NREACTIONS
+    N0 = FSP%SIZE
+    NU = MODEL%STOICHIOMETRY(1:SD, 1:PD)
+    NT = HOST_THREADS(TOTAL, 1)
+    ALLOCATE(REP(TOTAL), NEWOF(TOTAL))
+    NTH = 1
+    !$OMP PARALLEL NUM_THREADS(NT) PRIVATE(TID, C, R, S, MINE, LTLEN, LT, SLOT, SAME)
+    TID = 0
+    !$ TID = OMP_GET_THREAD_NUM()
+    !$OMP SINGLE
+    !$ NTH = OMP_GET_NUM_THREADS()
+    !$OMP END SINGLE
+    MINE = 0
+    DO C = 1, TOTAL
+       IF (MOD(ISHFT(CH(C), -16), INT(NTH, 8)) == TID) MINE = MINE + 1
+    ENDDO
+    LTLEN = 64
+    DO WHILE (LTLEN < 2 * MINE)
+       LTLEN = 2 * LTLEN
+    ENDDO
+    ALLOCATE(LT(LTLEN))
+    LT = 0
+    DO C = 1, TOTAL
+       IF (MOD(ISHFT(CH(C), -16), INT(NTH, 8)) /= TID) CYCLE
+       SLOT = INT(IAND(ISHFT(CH(C), -4), INT(LTLEN - 1, 8))) + 1
+       DO
+          R = LT(SLOT)
+          IF (R == 0) THEN
+             LT(SLOT) = C
+             REP(C) = C
+             EXIT
+          ENDIF
+          IF (CH(R) == CH(C)) THEN
+             SAME = .TRUE.
+             DO S = 1, SD
+                IF (FSP%STATE(S, CJ(R)) + NU(S, CK(R)) /= FSP%STATE(S, CJ(C)) + NU(S, CK(C))) SAME = .FALSE.
+             ENDDO
+             IF (SAME) THEN
+                REP(C) = R
+                EXIT
+             ENDIF
+          ENDIF
+          SLOT = IAND(SLOT, LTLEN - 1) + 1
+       ENDDO
+    ENDDO
+    DEALLOCATE(LT)
+    !$OMP END PARALLEL
+
+    NNEW = 0
+    DO C = 1, TOTAL
+       IF (REP(C) == C) THEN
+          NNEW = NNEW + 1
+          NEWOF(C) = N0 + NNEW
+       ENDIF
+    ENDDO
+    IF (N0 + NNEW >= FSP%MAX_SIZE) STOP 'OVERFLOW ERROR: FSP SIZE EXCEEDS MEMORY LIMIT.'
+    FSP%SIZE = N0                       ! (what a regrown table is rebuilt from)
+    CALL RESERVE_TABLE(FSP, N0 + NNEW)
+
+    PARPROP = .NOT. ASSOCIATED(MODEL%CUSTOMPROP)
+    !$OMP PARALLEL DO NUM_THREADS(NT) SCHEDULE(STATIC) PRIVATE(L, S, K, A)
+    DO C = 1, TOTAL
+       IF (REP(C) /= C) CYCLE
+       L = NEWOF(C)
+       DO S = 1, SD
+          FSP%STATE(S, L) = FSP%STATE(S, CJ(C)) + NU(S, CK(C))
+       ENDDO
+       FSP%KEY(L) = CH(C)
+       FSP%VECTOR(L) = 0.0D0
+       FSP%MATRIX%ADJ(1:PD, L) = 0
+       IF (PARPROP) THEN
+          FSP%MATRIX%DIAG(L) = 0.0D0
+          DO K = 1, PD
+             A = MODEL%PROPENSITY(FSP%STATE(1:SD, L), K)
+             FSP%MATRIX%DIAG(L) = FSP%MATRIX%DIAG(L) + A
+             FSP%MATRIX%OFFDIAG(K, L) = A
+          ENDDO
+       ENDIF
+    ENDDO
+    !$OMP END PARALLEL DO
+    IF (.NOT. PARPROP) THEN
+       DO L = N0 + 1, N0 + NNEW
+          FSP%MATRIX%DIAG(L) = 0.0D0
+          DO K = 1, PD
+             A = MODEL%PROPENSITY(FSP%STATE(1:SD, L), K)
+             FSP%MATRIX%DIAG(L) = FSP%MATRIX%DIAG(L) + A
+             FSP%MATRIX%OFFDIAG(K, L) = A
+          ENDDO
+       ENDDO
+    ENDIF
+    FSP%SIZE = N0 + NNEW
+    FSP%MATRIX%SIZE = FSP%SIZE
+    IF (NNEW > 0) CALL INSERT_RANGE(FSP, N0 + 1, N0 + NNEW, .FALSE.)
+    !$OMP PARALLEL DO NUM_THREADS(NT) SCHEDULE(STATIC)
+    DO C = 1, TOTAL
+       FSP%MATRIX%ADJ(CK(C), CJ(C)) = NEWOF(REP(C))
+    ENDDO
+    !$OMP END PARALLEL DO
+  END SUBROUTINE APPEND_CANDIDATES
+
   ! add every state one reaction away from the current list (in list order,
   ! reaction order; new states are appended and NOT revisited in this sweep).
   ! Pass 1 (parallel) resolves the open links whose target is already listed and
@@ -560,24 +687,28 @@ CONTAINS
        ENDIF
        TOTAL = TOTAL + NC(T)
     ENDDO
-    TOUCH = 0
-    DO C = 1, INT(TOTAL)
-       ! request the table slot of a later candidate now (it is a cache miss)
-       IF (C + AHEAD <= TOTAL) TOUCH = TOUCH + FSP%KEYTAB(INT(IAND(CH(C + AHEAD), INT(FSP%KTLEN - 1, 8))) + 1)
-       J = CJ(C)
-       K = CK(C)
-       Y = FSP%STATE(1:SD, J) + MODEL%STOICHIOMETRY(:, K)
-       H = CH(C)
-       CALL PROBE(FSP, Y, H, IDX)
-       IF (IDX == 0) THEN
-          IF (FSP%SIZE >= FSP%MAX_SIZE) STOP 'OVERFLOW ERROR: FSP SIZE EXCEEDS MEMORY LIMIT.'
-          CALL APPEND_STATE(FSP, MODEL, Y, H)
-          IDX = FSP%SIZE
-          IF (FSP%SIZE >= FSP%MAX_SIZE) STOP 'OVERFLOW ERROR: FSP SIZE EXCEEDS MEMORY LIMIT.'
-       ENDIF
-       FSP%MATRIX%ADJ(K, J) = IDX
-    ENDDO
-    TOUCH_SINK = INT(IAND(TOUCH, 1_8))
+    IF (HOST_THREADS(INT(TOTAL), 16384) > 1) THEN
+       CALL APPEND_CANDIDATES(FSP, MODEL, INT(TOTAL), CJ, CK, CH)
+    ELSE
+       TOUCH = 0
+       DO C = 1, INT(TOTAL)
+          ! request the table slot of a later candidate now (it is a cache miss)
+          IF (C + AHEAD <= TOTAL) TOUCH = TOUCH + FSP%KEYTAB(INT(IAND(CH(C + AHEAD), INT(FSP%KTLEN - 1, 8))) + 1)
+          J = CJ(C)
+          K = CK(C)
+          Y = FSP%STATE(1:SD, J) + MODEL%STOICHIOMETRY(:, K)
+          H = CH(C)
+          CALL PROBE(FSP, Y, H, IDX)
+          IF (IDX == 0) THEN
+             IF (FSP%SIZE >= FSP%MAX_SIZE) STOP 'OVERFLOW ERROR: FSP SIZE EXCEEDS MEMORY LIMIT.'
+             CALL APPEND_STATE(FSP, MODEL, Y, H)
+             IDX = FSP%SIZE
+             IF (FSP%SIZE >= FSP%MAX_SIZE) STOP 'OVERFLOW ERROR: FSP SIZE EXCEEDS MEMORY LIMIT.'
+          ENDIF
+          FSP%MATRIX%ADJ(K, J) = IDX
+       ENDDO
+       TOUCH_SINK = INT(IAND(TOUCH, 1_8))
+    ENDIF
     CALL TICK(2, TCLK)
     IF (FSP%SIZE > N0) CALL LINK_NEW(FSP, MODEL, N0 + 1, FSP%SIZE, .FALSE.)
     CALL TICK(3, TCLK)
