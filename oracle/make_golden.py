@@ -96,6 +96,13 @@ SOLVE_CASES = {
     "ring6_T40": ("ring6", 40.0, 1e-4, 1e-10),
     "ring6_long": ("ring6", 60.0, 1e-4, 1e-10),   # trajectory may fork late
     "ring4": ("ring4", 6.2, 1e-6, 1e-8),
+    # the other two shipped models through the whole adaptive loop (3 and 6
+    # species; parsed propensities, SSA + one-step growth, drops with compaction)
+    "repressilator_input_T03": ("repressilator_input", 0.3, 1e-4, 1e-10),
+    "repressilator_input_T1": ("repressilator_input", 1.0, 1e-4, 1e-10),
+    "goutsias_input_T4": ("goutsias_input", 4.0, 1e-6, 1e-8),
+    "goutsias_input_T15": ("goutsias_input", 15.0, 1e-6, 1e-8),
+    "goutsias_input_T40": ("goutsias_input", 40.0, 1e-6, 1e-8),
 }
 
 ASSEMBLY_CASES = [("toggle", 5), ("toggle", 10), ("toggle", 20),
@@ -153,13 +160,16 @@ def main():
         sys.exit("oracle/_ref/ref_dump missing: run `make -C oracle` where /root/reference exists")
     os.makedirs(GOLDEN, exist_ok=True)
     tmp = tempfile.mkdtemp(prefix="kfsp_golden_")
-    make_ssa(tmp)
-    make_drop(tmp)
+    # `make_golden.py statespace` / `make_golden.py solve <fixture> ...` refresh a subset
+    only = set(sys.argv[2:]) if sys.argv[1:2] == ["solve"] else None
+    if not only:
+        make_ssa(tmp)
+        make_drop(tmp)
     if sys.argv[1:] == ["statespace"]:
         return
 
     # G1: assembly (integer arrays bit-exact, StateSpace.f90:248-396)
-    for name, k in ASSEMBLY_CASES:
+    for name, k in ([] if only else ASSEMBLY_CASES):
         p = os.path.join(tmp, f"asm_{name}_{k}.bin")
         run_dump(["assembly", name, str(k), p])
         d = read_fsp(p)
@@ -169,6 +179,8 @@ def main():
 
     # G3/G6: CME_SOLVE end to end
     for name, (case, T, fsptol, krytol) in SOLVE_CASES.items():
+        if only and name not in only:
+            continue
         p = os.path.join(tmp, f"solve_{name}.bin")
         text = run_dump(["solve", case, p, repr(T)])
         din = read_fsp(p + ".in")
@@ -181,6 +193,8 @@ def main():
             n=dout["n"], state=dout["state"], adj=dout["adj"], offdiag=dout["offdiag"],
             diag=dout["diag"], vector=dout["vector"], **log)
         print(f"solve {name}: N={dout['n']} steps={len(log['step_no'])} sum={dout['vector'].sum()!r}")
+    if only:
+        return
 
     # G5: DGPADM
     p = os.path.join(tmp, "padm.bin")

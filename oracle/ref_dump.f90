@@ -307,6 +307,16 @@ CONTAINS
        T = 100.0D0; FSPTOL = 1.0D-4; KRYTOL = 1.0D-8
        X0 = [0, 0]
        CALL SEED_POINT(MODEL, FSP_IN, FSP, X0)
+    CASE ('repressilator_input')
+       ! models/repressilator_model.input with the tolerances of toggle_input
+       CALL LOAD_INPUT_MODEL('repressilator', MODEL, X0)
+       T = 10.0D0; FSPTOL = 1.0D-4; KRYTOL = 1.0D-10
+       CALL SEED_POINT(MODEL, FSP_IN, FSP, X0)
+    CASE ('goutsias_input')
+       ! models/goutsias_model.input with the tolerances of examples/transcr6d.f90:16
+       CALL LOAD_INPUT_MODEL('goutsias', MODEL, X0)
+       T = 300.0D0; FSPTOL = 1.0D-6; KRYTOL = 1.0D-8
+       CALL SEED_POINT(MODEL, FSP_IN, FSP, X0)
     CASE ('ring6')
        ! closed 6-species ring, 8 molecules: every state is seeded, nothing
        ! leaks and nothing is droppable, so the FSP never changes and the run

@@ -133,7 +133,10 @@ def test_cme_solve_closed_systems(dump, tmp_path, fixture, case):
 
 
 SHORT = [("toggle_input_T02", "toggle_input"), ("toggle_input_T05", "toggle_input"),
-         ("toggle_example_T05", "toggle_example")]
+         ("toggle_example_T05", "toggle_example"),
+         ("repressilator_input_T03", "repressilator_input"), ("repressilator_input_T1", "repressilator_input"),
+         ("goutsias_input_T4", "goutsias_input"), ("goutsias_input_T15", "goutsias_input"),
+         ("goutsias_input_T40", "goutsias_input")]
 LONG = [("toggle_input", "toggle_input"), ("toggle_example", "toggle_example"),
         ("toggle_input_T2", "toggle_input"), ("toggle_example_T2", "toggle_example")]
 
