@@ -65,7 +65,7 @@ MODULE STATESPACE
      PROCEDURE :: INDEX => INDEX_STATE
   END TYPE FINITE_STATE_PROJECTION
 
-  PRIVATE :: TICK, STATE_HASH, LOOKUP, PROBE, INSERT_RANGE, APPEND_CANDIDATES, TABLE_INSERT, REBUILD_TABLE, LEGAL, RESERVE_TABLE, APPEND_STATE, &
+  PRIVATE :: TICK, STATE_HASH, LOOKUP, PROBE, INSERT_RANGE, APPEND_CANDIDATES, CUSTOMPROP_IS_PURE, TABLE_INSERT, REBUILD_TABLE, LEGAL, RESERVE_TABLE, APPEND_STATE, &
        LINK_ONE, LINK_NEW, HOST_THREADS
 
   INTEGER(8), PARAMETER, PRIVATE :: LOW32 = 4294967295_8
@@ -487,6 +487,14 @@ CONTAINS
     CALL LINK_NEW(FSP, MODEL, 1, N, .FALSE.)
   END SUBROUTINE MATRIX_STARTER
 
+  LOGICAL FUNCTION CUSTOMPROP_IS_PURE()
+    CHARACTER(LEN=8) :: BUF
+    INTEGER :: L, ST
+    CALL GET_ENVIRONMENT_VARIABLE('KFSP_HOST_PARALLEL_PROPENSITY', BUF, L, ST)
+    CUSTOMPROP_IS_PURE = .FALSE.
+    IF (ST == 0 .AND. L > 0) CUSTOMPROP_IS_PURE = BUF(1:1) == '1'
+  END FUNCTION CUSTOMPROP_IS_PURE
+
   ! Pass 2 of ONESTEP_EXTENDER for a long candidate list.  Candidate C is the open
   ! link (CJ(C), CK(C)) whose target, hash CH(C), is not listed.  The reference
   ! appends each target when its first candidate comes up; so the new states are
@@ -567,7 +575,9 @@ CONTAINS
     FSP%SIZE = N0                       ! (what a regrown table is rebuilt from)
     CALL RESERVE_TABLE(FSP, N0 + NNEW)
 
-    PARPROP = .NOT. ASSOCIATED(MODEL%CUSTOMPROP)
+    ! a user's CUSTOMPROP is called from this thread only, unless
+    ! KFSP_HOST_PARALLEL_PROPENSITY=1 declares it free of side effects
+    PARPROP = .NOT. ASSOCIATED(MODEL%CUSTOMPROP) .OR. CUSTOMPROP_IS_PURE()
     !$OMP PARALLEL DO NUM_THREADS(NT) SCHEDULE(STATIC) PRIVATE(L, S, K, A)
     DO C = 1, TOTAL
        IF (REP(C) /= C) CYCLE
