@@ -73,6 +73,9 @@ CONTAINS
     INTEGER(8) :: C0, C1, CRATE
 
     IFLAG = 0
+    ! the device context comes first: the threads its runtime starts must not
+    ! inherit the one-core affinity the host sweeps give the calling thread
+    CALL ENSURE_CONTEXT()
     N0 = FSP%SIZE
     ALLOCATE(P0(N0))
     P0 = V(1:N0)                       ! DCOPY(FSP%SIZE, V, 1, W, 1)  :176
@@ -85,7 +88,6 @@ CONTAINS
     FSP%VECTOR(1:N0) = P0
     IF (FSP%SIZE > N0) FSP%VECTOR(N0 + 1:FSP%SIZE) = 0.0D0
 
-    CALL ENSURE_CONTEXT()
     CALL SYSTEM_CLOCK(C0, CRATE)
     RC = KFSP_GET_TIMERS(CTX, TMS, 1_C_INT)
     HOST_SEC = 0.0D0
