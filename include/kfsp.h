@@ -13,8 +13,10 @@
  *     its name ends in _dev.  The library copies on set_* and owns all device
  *     memory until kfsp_destroy.  No pointer is retained past a call.
  *   - return value: 0 ok; <0 = index of the bad argument (like IFLAG,
- *     KrylovSolver.f90:142-149); >0 = 1000+hipError_t or 2000+ncclResult_t.
- *     Never exits, never throws.  kfsp_last_error() gives the text.
+ *     KrylovSolver.f90:142-149); >0 = 1000+hipError_t, 2000+ncclResult_t,
+ *     3000+ host Pade failure, 4000 exception inside the library or a
+ *     callback, 4001 out of host memory.  Never exits, never throws (C++
+ *     exceptions are caught at the boundary).  kfsp_last_error() gives the text.
  *   - indices in reference-layout arrays are 1-based exactly as the reference
  *     stores them; CSR entry points are 0-based.
  *   - one host thread per context; calls return when their host-visible

@@ -36,6 +36,22 @@ int fail(kfsp_ctx *c, int code, const char *what)
     return code;
 }
 
+// C++ exceptions (host allocations) end at the C boundary as status codes
+template <class F>
+int no_throw(kfsp_ctx *c, F &&body)
+{
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        return fail(c, 4001, "out of host memory");
+    } catch (const std::exception &e) {
+        if (c) c->err = std::string("exception: ") + e.what();
+        return 4000;
+    } catch (...) {
+        return fail(c, 4000, "unknown exception");
+    }
+}
+
 int hip_fail(kfsp_ctx *c, hipError_t e, const char *where)
 {
     if (c) c->err = std::string(where) + ": " + hipGetErrorString(e);
@@ -491,6 +507,26 @@ int upload_csr_from_sell(kfsp_ctx *ctx, const HostSell &S, const std::vector<int
     return 0;
 }
 
+// stream, events and the fixed-size buffers of a fresh context
+int init_context(kfsp_ctx *ctx)
+{
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&ctx->ev0));
+    HIP_TRY(hipEventCreate(&ctx->ev1));
+    HIP_TRY(ctx->d_part.reserve((size_t)kNumPartial * kMaxGrid, true));
+    HIP_TRY(ctx->d_stage.reserve(kNumStage, true));
+    HIP_TRY(ctx->d_H.reserve((size_t)kMH * kMH + 2, true));
+    HIP_TRY(ctx->d_sq.reserve(kMH + 2, true));
+    HIP_TRY(ctx->d_g.reserve(kMH + 2, true));
+    HIP_TRY(ctx->d_y.reserve(kMH, true));
+    HIP_TRY(ctx->d_flag.reserve(4, true));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_H), ((size_t)kMH * kMH + 2) * sizeof(double), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_pin), (size_t)(kMH + 8) * sizeof(double), hipHostMallocDefault));
+    std::memset(ctx->h_H, 0, ((size_t)kMH * kMH + 2) * sizeof(double));
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -505,24 +541,15 @@ int kfsp_create(int device, kfsp_ctx **out)
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0) return 1000 + (int)(e == hipSuccess ? hipErrorNoDevice : e);
     if (device < 0 || device >= count) return -1;
-    std::unique_ptr<kfsp_ctx> c(new kfsp_ctx);
-    kfsp_ctx *ctx = c.get();
+    kfsp_ctx *ctx = new (std::nothrow) kfsp_ctx;
+    if (!ctx) return 4001;
     ctx->device = device;
-    HIP_TRY(hipSetDevice(device));
-    HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreate(&ctx->ev0));
-    HIP_TRY(hipEventCreate(&ctx->ev1));
-    HIP_TRY(ctx->d_part.reserve((size_t)kNumPartial * kMaxGrid, true));
-    HIP_TRY(ctx->d_stage.reserve(kNumStage, true));
-    HIP_TRY(ctx->d_H.reserve((size_t)kMH * kMH + 2, true));
-    HIP_TRY(ctx->d_sq.reserve(kMH + 2, true));
-    HIP_TRY(ctx->d_g.reserve(kMH + 2, true));
-    HIP_TRY(ctx->d_y.reserve(kMH, true));
-    HIP_TRY(ctx->d_flag.reserve(4, true));
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_H), ((size_t)kMH * kMH + 2) * sizeof(double), hipHostMallocDefault));
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_pin), (size_t)(kMH + 8) * sizeof(double), hipHostMallocDefault));
-    std::memset(ctx->h_H, 0, ((size_t)kMH * kMH + 2) * sizeof(double));
-    *out = c.release();
+    const int rc = init_context(ctx);
+    if (rc != 0) {
+        (void)kfsp_destroy(ctx);        // releases whatever init_context got as far as creating
+        return rc;
+    }
+    *out = ctx;
     return 0;
 }
 
@@ -621,124 +648,128 @@ int kfsp_row_block(const kfsp_ctx *ctx, int64_t n, int64_t *row0, int64_t *nrows
 int kfsp_set_matrix_ell(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, const int32_t *adj,
                         const double *offdiag, const double *diag)
 {
-    if (!ctx) return -1;
-    if (n < 1) return fail(ctx, -2, "n < 1");
-    if (bw < 1) return fail(ctx, -3, "bw < 1");
-    if (ld < bw) return fail(ctx, -4, "ld < bw");
-    if (!adj) return fail(ctx, -5, "null adj");
-    if (!offdiag) return fail(ctx, -6, "null offdiag");
-    if (!diag) return fail(ctx, -7, "null diag");
-    HIP_TRY(hipSetDevice(ctx->device));
-    auto t0 = std::chrono::steady_clock::now();
-    if (int rc = resize(ctx, n)) return rc;
-    const int64_t row0 = ctx->row0, nloc = ctx->nloc;
+    return no_throw(ctx, [&]() -> int {
+        if (!ctx) return -1;
+        if (n < 1) return fail(ctx, -2, "n < 1");
+        if (bw < 1) return fail(ctx, -3, "bw < 1");
+        if (ld < bw) return fail(ctx, -4, "ld < bw");
+        if (!adj) return fail(ctx, -5, "null adj");
+        if (!offdiag) return fail(ctx, -6, "null offdiag");
+        if (!diag) return fail(ctx, -7, "null diag");
+        HIP_TRY(hipSetDevice(ctx->device));
+        auto t0 = std::chrono::steady_clock::now();
+        if (int rc = resize(ctx, n)) return rc;
+        const int64_t row0 = ctx->row0, nloc = ctx->nloc;
 
-    if (!ctx->opt_host_build && !ctx->want_csr) {
-        // the arrays go to HBM verbatim and are transposed there (kfsp_build.hip)
-        int rc = build_from_ell_device(ctx, n, bw, ld, adj, offdiag, diag);
-        if (!rc) rc = setup_exchange(ctx);
-        ctx->have_csr = false;
-        ctx->t_ms[KFSP_T_UPLOAD] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        return rc;
-    }
+        if (!ctx->opt_host_build && !ctx->want_csr) {
+            // the arrays go to HBM verbatim and are transposed there (kfsp_build.hip)
+            int rc = build_from_ell_device(ctx, n, bw, ld, adj, offdiag, diag);
+            if (!rc) rc = setup_exchange(ctx);
+            ctx->have_csr = false;
+            ctx->t_ms[KFSP_T_UPLOAD] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            return rc;
+        }
 
-    // host transpose (kept for A/B checks of the device build and for the CSR copy)
-    // in-degree of every local row
-    std::vector<int32_t> cnt((size_t)std::max<int64_t>(nloc, 1), 0);
-    for (int64_t i = 0; i < n; ++i) {
-        const int32_t *a = adj + (size_t)i * ld;
-        for (int j = 0; j < bw; ++j) {
-            const int64_t k = a[j];
-            if (k > n) return fail(ctx, -5, "adj entry exceeds n");
-            if (k >= 1) {
-                const int64_t r = k - 1 - row0;
-                if (r >= 0 && r < nloc) ++cnt[(size_t)r];
+        // host transpose (kept for A/B checks of the device build and for the CSR copy)
+        // in-degree of every local row
+        std::vector<int32_t> cnt((size_t)std::max<int64_t>(nloc, 1), 0);
+        for (int64_t i = 0; i < n; ++i) {
+            const int32_t *a = adj + (size_t)i * ld;
+            for (int j = 0; j < bw; ++j) {
+                const int64_t k = a[j];
+                if (k > n) return fail(ctx, -5, "adj entry exceeds n");
+                if (k >= 1) {
+                    const int64_t r = k - 1 - row0;
+                    if (r >= 0 && r < nloc) ++cnt[(size_t)r];
+                }
             }
         }
-    }
-    HostSell S;
-    sell_layout(cnt, nloc, row0, S);
-    std::vector<int32_t> fill((size_t)std::max<int64_t>(nloc, 1), 0);
-    int64_t nnz = nloc;
-    // sources in increasing order: each row's entries end up sorted by column,
-    // the order in which FMATVEC (:598-604) accumulates them
-    for (int64_t i = 0; i < n; ++i) {
-        const int32_t *a = adj + (size_t)i * ld;
-        const double *o = offdiag + (size_t)i * ld;
-        for (int j = 0; j < bw; ++j) {
-            const int64_t k = a[j];
-            if (k < 1) continue;
-            const int64_t r = k - 1 - row0;
-            if (r < 0 || r >= nloc) continue;
-            const int64_t c = r / kChunk, l = r % kChunk;
-            const int64_t pos = S.off[(size_t)c] + (int64_t)fill[(size_t)r]++ * kChunk + l;
-            S.col[(size_t)pos] = (int32_t)i;
-            S.val[(size_t)pos] = o[j];
-            ++nnz;
+        HostSell S;
+        sell_layout(cnt, nloc, row0, S);
+        std::vector<int32_t> fill((size_t)std::max<int64_t>(nloc, 1), 0);
+        int64_t nnz = nloc;
+        // sources in increasing order: each row's entries end up sorted by column,
+        // the order in which FMATVEC (:598-604) accumulates them
+        for (int64_t i = 0; i < n; ++i) {
+            const int32_t *a = adj + (size_t)i * ld;
+            const double *o = offdiag + (size_t)i * ld;
+            for (int j = 0; j < bw; ++j) {
+                const int64_t k = a[j];
+                if (k < 1) continue;
+                const int64_t r = k - 1 - row0;
+                if (r < 0 || r >= nloc) continue;
+                const int64_t c = r / kChunk, l = r % kChunk;
+                const int64_t pos = S.off[(size_t)c] + (int64_t)fill[(size_t)r]++ * kChunk + l;
+                S.col[(size_t)pos] = (int32_t)i;
+                S.val[(size_t)pos] = o[j];
+                ++nnz;
+            }
         }
-    }
-    for (int64_t r = 0; r < nloc; ++r) S.diag[(size_t)r] = diag[(size_t)(row0 + r)];
-    S.nnz = nnz;
-    if (int rc = upload_sell(ctx, S)) return rc;
-    if (int rc = maybe_upload_dia(ctx, S, cnt)) return rc;
-    if (int rc = setup_exchange(ctx)) return rc;
-    ctx->have_csr = false;
-    if (ctx->want_csr)
-        if (int rc = upload_csr_from_sell(ctx, S, cnt)) return rc;
-    ctx->t_ms[KFSP_T_UPLOAD] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    return 0;
+        for (int64_t r = 0; r < nloc; ++r) S.diag[(size_t)r] = diag[(size_t)(row0 + r)];
+        S.nnz = nnz;
+        if (int rc = upload_sell(ctx, S)) return rc;
+        if (int rc = maybe_upload_dia(ctx, S, cnt)) return rc;
+        if (int rc = setup_exchange(ctx)) return rc;
+        ctx->have_csr = false;
+        if (ctx->want_csr)
+            if (int rc = upload_csr_from_sell(ctx, S, cnt)) return rc;
+        ctx->t_ms[KFSP_T_UPLOAD] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return 0;
+    });
 }
 
 int kfsp_set_matrix_csr(kfsp_ctx *ctx, int64_t n, int64_t row0, int64_t nrows, const int64_t *rowptr,
                         const int32_t *col, const double *val)
 {
-    if (!ctx) return -1;
-    if (n < 1 || n > 2147483647LL - 512) return fail(ctx, -2, "n out of range");
-    HIP_TRY(hipSetDevice(ctx->device));
-    if (int rc = resize(ctx, n)) return rc;
-    if (row0 != std::min(ctx->row0, n)) return fail(ctx, -3, "row0 is not this rank's block start (kfsp_row_block)");
-    if (nrows != ctx->nloc) return fail(ctx, -4, "nrows is not this rank's block size (kfsp_row_block)");
-    if (!rowptr) return fail(ctx, -5, "null rowptr");
-    if (nrows > 0 && (!col || !val)) return fail(ctx, -6, "null col/val");
-    if (rowptr[0] != 0) return fail(ctx, -5, "rowptr[0] != 0");
-    auto t0 = std::chrono::steady_clock::now();
-    const int64_t nloc = ctx->nloc;
-    std::vector<int32_t> cnt((size_t)std::max<int64_t>(nloc, 1), 0);
-    for (int64_t r = 0; r < nloc; ++r) {
-        if (rowptr[r + 1] < rowptr[r]) return fail(ctx, -5, "rowptr not monotone");
-        int c = 0;
-        for (int64_t p = rowptr[r]; p < rowptr[r + 1]; ++p) {
-            if (col[p] < 0 || col[p] >= n) return fail(ctx, -6, "column index out of range");
-            if (col[p] != row0 + r) ++c;
-        }
-        cnt[(size_t)r] = c;
-    }
-    HostSell S;
-    sell_layout(cnt, nloc, ctx->row0, S);
-    for (int64_t r = 0; r < nloc; ++r) {
-        const int64_t c = r / kChunk, l = r % kChunk;
-        int k = 0;
-        double d = 0.0;
-        for (int64_t p = rowptr[r]; p < rowptr[r + 1]; ++p) {
-            if (col[p] == row0 + r) {
-                d += val[p];
-            } else {
-                const int64_t pos = S.off[(size_t)c] + (int64_t)k++ * kChunk + l;
-                S.col[(size_t)pos] = col[p];
-                S.val[(size_t)pos] = val[p];
+    return no_throw(ctx, [&]() -> int {
+        if (!ctx) return -1;
+        if (n < 1 || n > 2147483647LL - 512) return fail(ctx, -2, "n out of range");
+        HIP_TRY(hipSetDevice(ctx->device));
+        if (int rc = resize(ctx, n)) return rc;
+        if (row0 != std::min(ctx->row0, n)) return fail(ctx, -3, "row0 is not this rank's block start (kfsp_row_block)");
+        if (nrows != ctx->nloc) return fail(ctx, -4, "nrows is not this rank's block size (kfsp_row_block)");
+        if (!rowptr) return fail(ctx, -5, "null rowptr");
+        if (nrows > 0 && (!col || !val)) return fail(ctx, -6, "null col/val");
+        if (rowptr[0] != 0) return fail(ctx, -5, "rowptr[0] != 0");
+        auto t0 = std::chrono::steady_clock::now();
+        const int64_t nloc = ctx->nloc;
+        std::vector<int32_t> cnt((size_t)std::max<int64_t>(nloc, 1), 0);
+        for (int64_t r = 0; r < nloc; ++r) {
+            if (rowptr[r + 1] < rowptr[r]) return fail(ctx, -5, "rowptr not monotone");
+            int c = 0;
+            for (int64_t p = rowptr[r]; p < rowptr[r + 1]; ++p) {
+                if (col[p] < 0 || col[p] >= n) return fail(ctx, -6, "column index out of range");
+                if (col[p] != row0 + r) ++c;
             }
+            cnt[(size_t)r] = c;
         }
-        S.diag[(size_t)r] = -d;   // kept positive like DIAG (StateSpace.f90:16)
-    }
-    S.nnz = rowptr[nloc];
-    if (int rc = upload_sell(ctx, S)) return rc;
-    if (int rc = maybe_upload_dia(ctx, S, cnt)) return rc;
-    if (int rc = setup_exchange(ctx)) return rc;
-    ctx->have_csr = false;
-    if (ctx->want_csr)
-        if (int rc = upload_csr_from_sell(ctx, S, cnt)) return rc;
-    ctx->t_ms[KFSP_T_UPLOAD] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    return 0;
+        HostSell S;
+        sell_layout(cnt, nloc, ctx->row0, S);
+        for (int64_t r = 0; r < nloc; ++r) {
+            const int64_t c = r / kChunk, l = r % kChunk;
+            int k = 0;
+            double d = 0.0;
+            for (int64_t p = rowptr[r]; p < rowptr[r + 1]; ++p) {
+                if (col[p] == row0 + r) {
+                    d += val[p];
+                } else {
+                    const int64_t pos = S.off[(size_t)c] + (int64_t)k++ * kChunk + l;
+                    S.col[(size_t)pos] = col[p];
+                    S.val[(size_t)pos] = val[p];
+                }
+            }
+            S.diag[(size_t)r] = -d;   // kept positive like DIAG (StateSpace.f90:16)
+        }
+        S.nnz = rowptr[nloc];
+        if (int rc = upload_sell(ctx, S)) return rc;
+        if (int rc = maybe_upload_dia(ctx, S, cnt)) return rc;
+        if (int rc = setup_exchange(ctx)) return rc;
+        ctx->have_csr = false;
+        if (ctx->want_csr)
+            if (int rc = upload_csr_from_sell(ctx, S, cnt)) return rc;
+        ctx->t_ms[KFSP_T_UPLOAD] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return 0;
+    });
 }
 
 int kfsp_matrix_info(const kfsp_ctx *ctx, int64_t *nrows, int64_t *slots, int64_t *nnz)
@@ -1114,28 +1145,30 @@ int kfsp_get_basis(kfsp_ctx *ctx, int j, int64_t nlocal, double *v)
 
 int kfsp_expv_fixed(kfsp_ctx *ctx, int m, double tau, int nsteps, double *wsums)
 {
-    if (!ctx) return -1;
-    if (ctx->ldv == 0) return fail(ctx, -1, "no matrix set");
-    if (m < 1 || m > kMMax || (int64_t)m >= ctx->n) return fail(ctx, -2, "bad m");
-    if (nsteps < 0) return fail(ctx, -4, "bad nsteps");
-    const int mh = m + 2;
-    std::vector<double> H((size_t)mh * mh), E((size_t)mh * mh);
-    for (int s = 0; s < nsteps; ++s) {
-        double beta = 0.0, avn = 0.0, hn = 0.0;
-        int mb = m, k1 = 2, ns = 0;
-        if (int rc = kfsp_begin_step(ctx, &beta)) return rc;
-        std::fill(H.begin(), H.end(), 0.0);
-        if (int rc = kfsp_arnoldi(ctx, m, 1, 2, 1.0e-7, H.data(), mh, &mb, &k1, &avn)) return rc;
-        int mx = mb + k1;
-        auto t0 = std::chrono::steady_clock::now();
-        if (int rc = kfsp_padm(6, mx, tau, H.data(), mh, E.data(), &ns, &hn)) return fail(ctx, rc, "kfsp_padm failed");
-        ctx->t_ms[KFSP_T_HOST_PADE] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        mx = mb + std::max(0, k1 - 1);
-        double ws = 0.0;
-        if (int rc = kfsp_combine(ctx, mx, beta, E.data(), &ws)) return rc;
-        if (wsums) wsums[s] = ws;
-    }
-    return 0;
+    return no_throw(ctx, [&]() -> int {
+        if (!ctx) return -1;
+        if (ctx->ldv == 0) return fail(ctx, -1, "no matrix set");
+        if (m < 1 || m > kMMax || (int64_t)m >= ctx->n) return fail(ctx, -2, "bad m");
+        if (nsteps < 0) return fail(ctx, -4, "bad nsteps");
+        const int mh = m + 2;
+        std::vector<double> H((size_t)mh * mh), E((size_t)mh * mh);
+        for (int s = 0; s < nsteps; ++s) {
+            double beta = 0.0, avn = 0.0, hn = 0.0;
+            int mb = m, k1 = 2, ns = 0;
+            if (int rc = kfsp_begin_step(ctx, &beta)) return rc;
+            std::fill(H.begin(), H.end(), 0.0);
+            if (int rc = kfsp_arnoldi(ctx, m, 1, 2, 1.0e-7, H.data(), mh, &mb, &k1, &avn)) return rc;
+            int mx = mb + k1;
+            auto t0 = std::chrono::steady_clock::now();
+            if (int rc = kfsp_padm(6, mx, tau, H.data(), mh, E.data(), &ns, &hn)) return fail(ctx, rc, "kfsp_padm failed");
+            ctx->t_ms[KFSP_T_HOST_PADE] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            mx = mb + std::max(0, k1 - 1);
+            double ws = 0.0;
+            if (int rc = kfsp_combine(ctx, mx, beta, E.data(), &ws)) return rc;
+            if (wsums) wsums[s] = ws;
+        }
+        return 0;
+    });
 }
 
 int kfsp_spmv_bench(kfsp_ctx *ctx, int reps, int variant, float *ms_total)

@@ -204,7 +204,7 @@ bool solve_in_place(Dense &Q, Dense &X)
 }  // namespace
 
 extern "C" int kfsp_padm(int ideg, int m, double t, const double *H, int ldh, double *E, int *ns_out, double *hnorm_out)
-{
+try {
     if (ideg < 1 || ideg > 20) return -1;
     if (m < 1) return -2;
     if (!H) return -4;
@@ -274,5 +274,6 @@ extern "C" int kfsp_padm(int ideg, int m, double t, const double *H, int ldh, do
     }
     std::memcpy(E, P.a.data(), P.a.size() * sizeof(double));
     return 0;
+} catch (...) {
+    return 4001;   // out of host memory
 }
-

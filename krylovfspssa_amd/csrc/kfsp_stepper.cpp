@@ -93,7 +93,7 @@ struct Stepper {
 
 extern "C" int kfsp_dgexpv(kfsp_ctx *ctx, double t, double fsptol, double krytol, int n_reactions,
                            const kfsp_fsp_ops *ops, kfsp_stats *stats)
-{
+try {
     if (!ctx) return -1;
     if (!(t != 0.0) || !std::isfinite(t)) return -2;
     if (!(fsptol > 0.0)) return -3;
@@ -370,4 +370,6 @@ extern "C" int kfsp_dgexpv(kfsp_ctx *ctx, double t, double fsptol, double krytol
     st.hump = st.hump / vnorm;
     if (stats) *stats = st;
     return 0;
+} catch (...) {
+    return 4000;   // host allocation failure or an exception out of a callback: never across the C boundary
 }
