@@ -1,0 +1,40 @@
+"""Generator SpMV on an FSP in the reference's OWN state order (SSA / one-step
+discovery order, not a lexicographic box): the matrix dumped by
+profiles/statespace_bench.f90 goes through kfsp_set_matrix_ell (device build ->
+SELL-64) and is timed like bench.py times c3.
+    /tmp/ssb 2.0 38 /tmp/fsp.bin && python profiles/fsp_spmv_timing.py /tmp/fsp.bin"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from krylovfspssa_amd import KfspContext, synth  # noqa: E402
+
+with open(sys.argv[1], "rb") as f:
+    ns, nr, n = (int(v) for v in np.fromfile(f, dtype=np.int32, count=3))
+    adj = np.fromfile(f, dtype=np.int32, count=nr * n).reshape(n, nr)
+    off = np.fromfile(f, dtype=np.float64, count=nr * n).reshape(n, nr)
+    diag = np.fromfile(f, dtype=np.float64, count=n)
+nnz = int((adj > 0).sum()) + n
+ctx = KfspContext(0)
+ctx.set_matrix_ell(adj, off, diag)
+info = ctx.matrix_info()
+x = np.random.default_rng(12345).random(n)
+ctx.set_vector(x)
+ctx.begin_step()
+# spot check against numpy (scatter form on a sample of columns is awkward: use the gather rows)
+y = ctx.spmv_w()
+ref = -diag * x
+src = np.repeat(np.arange(n), nr)[(adj > 0).ravel()]
+dst = adj[adj > 0] - 1
+np.add.at(ref, dst, off[adj > 0] * x[src])
+print(f"N={n} nnz={nnz} stored slots={info['slots']} max |err| = {np.abs(y - ref).max():.3e}")
+ctx.spmv_bench(20)
+reps = 200
+ms = ctx.spmv_bench(reps) / reps
+b_alg = synth.spmv_alg_bytes(nnz, n)
+b_real = 12 * info["slots"] + 24 * n
+span = np.abs(dst - src)
+print(f"SpMV {ms * 1e3:.1f} us/launch: algorithmic {b_alg / ms / 1e6:.0f} GB/s, stored bytes (12/slot + 24/row) "
+      f"{b_real / ms / 1e6:.0f} GB/s; |col-row| median {int(np.median(span))}, 90% {int(np.quantile(span, 0.9))}, max {int(span.max())}")

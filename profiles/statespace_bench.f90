@@ -3,7 +3,11 @@
 ! adaptive loop issues them, with a checksum of the resulting FSP.
 !   B=krylovfspssa_amd/fortran/_build
 !   flang -O3 -fopenmp -I$B profiles/statespace_bench.f90 $B/libkfsp_fortran.a -o /tmp/ssb
-!   KFSP_HOST_THREADS=<t> /tmp/ssb <path duration> <rounds>
+!   KFSP_HOST_THREADS=<t> /tmp/ssb <path duration> <rounds> [<dump file>]
+! With a dump file the final generator is written as
+!   int32 ns, nr, n ; int32 ADJ(nr,n) ; f64 OFFDIAG(nr,n) ; f64 DIAG(n)
+! for profiles/fsp_spmv_timing.py (SpMV rate on an FSP in the reference's own
+! state order).
 MODULE SSB_MODEL
   IMPLICIT NONE
 CONTAINS
@@ -39,6 +43,8 @@ PROGRAM SSB
   INTEGER(8) :: C0, C1, CR, CHK
   INTEGER :: I, K
   CHARACTER(32) :: ARG
+  CHARACTER(256) :: DUMPFILE
+  INTEGER :: U
   PAR = (/0.043D0, 0.0007D0, 0.0715D0, 0.0039D0, 0.0199264663575241D0, 0.4791D0, &
           0.000199264663575241D0, 0.8765D-11, 0.0830269431563506104D0, 0.5D0/)
   NU = 0
@@ -55,6 +61,8 @@ PROGRAM SSB
   IF (COMMAND_ARGUMENT_COUNT() >= 2) THEN
      CALL GET_COMMAND_ARGUMENT(2, ARG); READ(ARG, *) NR
   ENDIF
+  DUMPFILE = ''
+  IF (COMMAND_ARGUMENT_COUNT() >= 3) CALL GET_COMMAND_ARGUMENT(3, DUMPFILE)
   CALL MODEL%CREATE(6, 10, 10)
   MODEL%STOICHIOMETRY = NU
   MODEL%CUSTOMPROP => GPROP
@@ -105,4 +113,12 @@ PROGRAM SSB
   ENDDO
   WRITE(*, '(A,F9.3,A,F9.3,A,F9.3,A,I10,A,I22)') 'ssa ', TS, ' onestep ', TO, ' drop ', TD, ' n ', FSP%SIZE, ' chk ', CHK
   WRITE(*, '(A,9F8.3)') 'passes: onestep scan/append/link, ssa walk/link, drop flags/compact/renumber/table', STATESPACE_SEC
+  IF (LEN_TRIM(DUMPFILE) > 0) THEN
+     OPEN(NEWUNIT=U, FILE=TRIM(DUMPFILE), ACCESS='STREAM', FORM='UNFORMATTED', STATUS='REPLACE')
+     WRITE(U) 6, 10, FSP%SIZE
+     WRITE(U) FSP%MATRIX%ADJ(1:10, 1:FSP%SIZE)
+     WRITE(U) FSP%MATRIX%OFFDIAG(1:10, 1:FSP%SIZE)
+     WRITE(U) FSP%MATRIX%DIAG(1:FSP%SIZE)
+     CLOSE(U)
+  ENDIF
 END PROGRAM SSB
