@@ -66,6 +66,25 @@ int kfsp_partition(int64_t n, int nranks, int rank, int64_t *row0, int64_t *nrow
  * 511, 528-529). */
 int kfsp_set_matrix_ell(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld,
                         const int32_t *adj, const double *offdiag, const double *diag);
+/* Optional, before kfsp_set_matrix_ell: the species counts of the n states of
+ * that generator, FSP%STATE(1:ns, 1:n) (StateSpace.f90:22), leading dimension
+ * ld >= ns.  The reference lists states in the order SSA_EXTENDER /
+ * ONESTEP_EXTENDER discovered them (:347-396, :550-630), which scatters the
+ * neighbours of a state over the whole vector; with the coordinates the library
+ * can keep generator and vectors in lexicographic state order INTERNALLY
+ * (species 1 fastest), so that the gathers of a product coalesce (2x on the
+ * product at 10^6 discovery-ordered states).  Nothing changes at the boundary:
+ * every array handed in or out stays in the caller's order.
+ * OFF unless option state_order = 1: rows are then summed in the internal
+ * column order instead of FMATVEC's (KrylovSolver.f90:598-604), i.e. results
+ * differ from the default path at rounding level.  When on it applies to the
+ * next kfsp_set_matrix_ell with the same n only, and not below option
+ * state_order_min states, with a communicator, or while generators are
+ * short-lived (the one being replaced saw fewer than option
+ * state_order_products products: reordering costs about 130 of them). */
+int kfsp_set_state_coords(kfsp_ctx *ctx, int32_t n, int32_t ns, int32_t ld, const int32_t *state);
+/* 1 if the generator last set is held in the internal state order */
+int kfsp_state_order_active(const kfsp_ctx *ctx, int *active);
 /* Synthetic / pre-transposed input: gather rows [row0, row0+nrows) of an
  * n x n generator in CSR, 0-based GLOBAL column indices, the diagonal stored
  * as an ordinary (negative) entry.  rowptr has nrows+1 entries starting at 0. */
@@ -198,8 +217,12 @@ int kfsp_get_timers(kfsp_ctx *ctx, double *ms /* [KFSP_T_COUNT] */, int reset);
 /* add ms to a phase (used by kfsp_dgexpv, which is a client of this ABI) */
 int kfsp_add_timer(kfsp_ctx *ctx, int phase, double ms);
 
-/* tuning knobs (name/value); unknown name -> -2.  "grid_blocks", "nt_loads",
- * "deterministic" ... see DESIGN.md */
+/* tuning knobs (name/value); unknown name -> -2: "grid_blocks",
+ * "vec_grid_blocks", "nt_loads", "build_csr", "format", "fused_ortho",
+ * "host_build", "halo", "overlap", "small_kernel", "state_order" (1: use
+ * kfsp_set_state_coords; default 0), "state_order_min" (smallest generator that is
+ * reordered, default 32768), "state_order_products" (products the previous
+ * generator must have seen, default 128) ... see DESIGN.md */
 int kfsp_set_option(kfsp_ctx *ctx, const char *name, int64_t value);
 
 #ifdef __cplusplus

@@ -177,6 +177,7 @@ int run_product(kfsp_ctx *ctx, int mode, SpmvArgs a, const double *src, bool src
                 bool force_sell = false)
 {
     hipStream_t st = ctx->stream;
+    ++ctx->prod_count;
     const bool dia = ctx->use_dia && !force_sell;
     const bool nt = use_nt(ctx);
     const int64_t trips = dia ? (ctx->nchunks + 1) / 2 : ctx->nchunks;
@@ -507,6 +508,34 @@ int upload_csr_from_sell(kfsp_ctx *ctx, const HostSell &S, const std::vector<int
     return 0;
 }
 
+// Host array (caller's state order) -> device vector (internal order) and back.
+// Without an internal order these are plain copies.
+int upload_states(kfsp_ctx *ctx, const double *host, double *dev, int64_t count)
+{
+    if (count <= 0) return 0;
+    if (!ctx->perm_on) {
+        HIP_TRY(hipMemcpyAsync(dev, host, (size_t)count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        return 0;
+    }
+    HIP_TRY(ctx->d_pstage.reserve((size_t)count, false));
+    HIP_TRY(hipMemcpyAsync(ctx->d_pstage.p, host, (size_t)count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    kfsp::launch_gather_index(count, ctx->d_perm.p, ctx->d_pstage.p, dev, ctx->stream);
+    return 0;
+}
+
+int download_states(kfsp_ctx *ctx, const double *dev, double *host, int64_t count)
+{
+    if (count <= 0) return 0;
+    if (!ctx->perm_on) {
+        HIP_TRY(hipMemcpyAsync(host, dev, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        return 0;
+    }
+    HIP_TRY(ctx->d_pstage.reserve((size_t)count, false));
+    kfsp::launch_gather_index(count, ctx->d_iperm.p, dev, ctx->d_pstage.p, ctx->stream);
+    HIP_TRY(hipMemcpyAsync(host, ctx->d_pstage.p, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    return 0;
+}
+
 // stream, events and the fixed-size buffers of a fresh context
 int init_context(kfsp_ctx *ctx)
 {
@@ -570,6 +599,9 @@ int kfsp_destroy(kfsp_ctx *ctx)
     ctx->d_y.release(); ctx->d_flag.release(); ctx->d_g.release(); ctx->d_dia.release();
     ctx->d_ell_adj.release(); ctx->d_ell_off.release(); ctx->d_ell_diag.release(); ctx->d_cnt.release();
     ctx->d_ticket.release(); ctx->d_slot.release(); ctx->d_scan.release(); ctx->d_strip.release();
+    ctx->d_perm.release(); ctx->d_iperm.release(); ctx->d_coords.release(); ctx->d_ell_adj2.release();
+    ctx->d_ell_off2.release(); ctx->d_ell_diag2.release(); ctx->d_pstage.release(); ctx->d_keys.release();
+    ctx->d_sortidx.release(); ctx->d_sorttmp.release();
     if (ctx->h_H) (void)hipHostFree(ctx->h_H);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -660,6 +692,11 @@ int kfsp_set_matrix_ell(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, const 
         auto t0 = std::chrono::steady_clock::now();
         if (int rc = resize(ctx, n)) return rc;
         const int64_t row0 = ctx->row0, nloc = ctx->nloc;
+        // coordinates handed over for exactly this generator switch the internal order on
+        ctx->perm_on = ctx->perm_pending_n == n && !ctx->use_comm && !ctx->opt_host_build && !ctx->want_csr;
+        ctx->perm_pending_n = 0;
+        ctx->prod_last = ctx->prod_count;
+        ctx->prod_count = 0;
 
         if (!ctx->opt_host_build && !ctx->want_csr) {
             // the arrays go to HBM verbatim and are transposed there (kfsp_build.hip)
@@ -725,6 +762,10 @@ int kfsp_set_matrix_csr(kfsp_ctx *ctx, int64_t n, int64_t row0, int64_t nrows, c
         if (!ctx) return -1;
         if (n < 1 || n > 2147483647LL - 512) return fail(ctx, -2, "n out of range");
         HIP_TRY(hipSetDevice(ctx->device));
+        ctx->perm_on = false;
+        ctx->perm_pending_n = 0;
+        ctx->prod_last = ctx->prod_count;
+        ctx->prod_count = 0;
         if (int rc = resize(ctx, n)) return rc;
         if (row0 != std::min(ctx->row0, n)) return fail(ctx, -3, "row0 is not this rank's block start (kfsp_row_block)");
         if (nrows != ctx->nloc) return fail(ctx, -4, "nrows is not this rank's block size (kfsp_row_block)");
@@ -772,6 +813,39 @@ int kfsp_set_matrix_csr(kfsp_ctx *ctx, int64_t n, int64_t row0, int64_t nrows, c
     });
 }
 
+int kfsp_set_state_coords(kfsp_ctx *ctx, int32_t n, int32_t ns, int32_t ld, const int32_t *state)
+{
+    return no_throw(ctx, [&]() -> int {
+        if (!ctx) return -1;
+        if (n < 1) return fail(ctx, -2, "n < 1");
+        if (ns < 1) return fail(ctx, -3, "ns < 1");
+        if (ld < ns) return fail(ctx, -4, "ld < ns");
+        if (!state) return fail(ctx, -5, "null state");
+        ctx->perm_pending_n = 0;
+        if (!ctx->opt_state_order || n < ctx->opt_state_order_min || ctx->use_comm) return 0;
+        // Sorting, relabelling and the extra upload cost about as much as 130 products
+        // save: worth it only while generators live that long.  The generator being
+        // replaced is the best predictor there is.
+        if (ctx->prod_count < ctx->opt_state_order_products) return 0;
+        HIP_TRY(hipSetDevice(ctx->device));
+        auto t0 = std::chrono::steady_clock::now();
+        bool ok = false;
+        const int rc = kfsp::state_order_from_coords(ctx, n, ns, ld, state, &ok);
+        ctx->t_ms[KFSP_T_UPLOAD] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (rc) return rc;
+        if (ok) ctx->perm_pending_n = n;
+        return 0;
+    });
+}
+
+int kfsp_state_order_active(const kfsp_ctx *ctx, int *active)
+{
+    if (!ctx) return -1;
+    if (!active) return -2;
+    *active = ctx->perm_on ? 1 : 0;
+    return 0;
+}
+
 int kfsp_matrix_info(const kfsp_ctx *ctx, int64_t *nrows, int64_t *slots, int64_t *nnz)
 {
     if (!ctx) return -1;
@@ -797,8 +871,7 @@ int kfsp_set_vector(kfsp_ctx *ctx, int64_t nlocal, const double *w)
     if (!w && nlocal > 0) return fail(ctx, -3, "null w");
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipMemsetAsync(ctx->d_w.p, 0, (size_t)ctx->ldv * sizeof(double), ctx->stream));
-    if (nlocal > 0)
-        HIP_TRY(hipMemcpyAsync(ctx->d_w.p, w, (size_t)nlocal * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if (int rc = upload_states(ctx, w, ctx->d_w.p, nlocal)) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return 0;
 }
@@ -809,8 +882,7 @@ int kfsp_get_vector(kfsp_ctx *ctx, int64_t nlocal, double *w)
     if (nlocal != ctx->nloc) return fail(ctx, -2, "nlocal is not this rank's block size");
     if (!w && nlocal > 0) return fail(ctx, -3, "null w");
     HIP_TRY(hipSetDevice(ctx->device));
-    if (nlocal > 0)
-        HIP_TRY(hipMemcpyAsync(w, ctx->d_w.p, (size_t)nlocal * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (int rc = download_states(ctx, ctx->d_w.p, w, nlocal)) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return 0;
 }
@@ -1067,7 +1139,7 @@ int kfsp_spmv(kfsp_ctx *ctx, const double *x, double *y)
     hipStream_t st = ctx->stream;
     HIP_TRY(hipMemsetAsync(ctx->d_xg.p, 0, ctx->d_xg.cap * sizeof(double), st));
     if (ctx->nranks == 1) {
-        HIP_TRY(hipMemcpyAsync(ctx->d_xg.p, x, (size_t)ctx->n * sizeof(double), hipMemcpyHostToDevice, st));
+        if (int rc = upload_states(ctx, x, ctx->d_xg.p, ctx->n)) return rc;
     } else {
         // global index of row k of rank p is p*L + k
         for (int p = 0; p < ctx->nranks; ++p) {
@@ -1077,8 +1149,7 @@ int kfsp_spmv(kfsp_ctx *ctx, const double *x, double *y)
         }
     }
     if (int rc = spmv_plain(ctx, ctx->d_xg.p, true, ctx->d_tmp.p)) return rc;
-    if (ctx->nloc > 0)
-        HIP_TRY(hipMemcpyAsync(y, ctx->d_tmp.p, (size_t)ctx->nloc * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (int rc = download_states(ctx, ctx->d_tmp.p, y, ctx->nloc)) return rc;
     HIP_TRY(hipStreamSynchronize(st));
     return 0;
 }
@@ -1097,8 +1168,7 @@ int kfsp_spmv_w(kfsp_ctx *ctx, double *y)
         src = scratch;
     }
     if (int rc = spmv_plain(ctx, src, false, ctx->d_tmp.p)) return rc;
-    if (ctx->nloc > 0)
-        HIP_TRY(hipMemcpyAsync(y, ctx->d_tmp.p, (size_t)ctx->nloc * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (int rc = download_states(ctx, ctx->d_tmp.p, y, ctx->nloc)) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return 0;
 }
@@ -1134,9 +1204,7 @@ int kfsp_get_basis(kfsp_ctx *ctx, int j, int64_t nlocal, double *v)
     HIP_TRY(hipSetDevice(ctx->device));
     double sq = 0.0;
     HIP_TRY(hipMemcpyAsync(&sq, ctx->d_sq.p + j, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    if (nlocal > 0)
-        HIP_TRY(hipMemcpyAsync(v, vcol(ctx, j - 1), (size_t)nlocal * sizeof(double),
-                               hipMemcpyDeviceToHost, ctx->stream));
+    if (int rc = download_states(ctx, vcol(ctx, j - 1), v, nlocal)) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     const double s = 1.0 / std::sqrt(sq);
     for (int64_t i = 0; i < nlocal; ++i) v[i] *= s;
@@ -1252,6 +1320,9 @@ int kfsp_set_option(kfsp_ctx *ctx, const char *name, int64_t value)
     else if (k == "format") ctx->opt_format = value;
     else if (k == "fused_ortho") ctx->opt_fused = value;
     else if (k == "host_build") ctx->opt_host_build = value;
+    else if (k == "state_order") ctx->opt_state_order = value;
+    else if (k == "state_order_min") ctx->opt_state_order_min = value;
+    else if (k == "state_order_products") ctx->opt_state_order_products = value;
     else if (k == "halo") ctx->opt_halo = value;
     else if (k == "overlap") ctx->opt_overlap = value;
     else if (k == "small_kernel") ctx->opt_small = value;

@@ -13,6 +13,8 @@
 // order in which FMATVEC accumulates (KrylovSolver.f90:598-604).
 #include "kfsp_ctx.h"
 
+#include <hipcub/hipcub.hpp>
+
 #include <algorithm>
 #include <chrono>
 #include <climits>
@@ -73,6 +75,80 @@ __global__ __launch_bounds__(kBlock) void k_ell_scan(int64_t n, int bw, int ld, 
             }
         }
     }
+}
+
+// ---- internal state order ------------------------------------------------------
+// column i' of the relabelled arrays is the caller's column perm[i'], its links
+// renumbered by iperm (entries <= 0 and out-of-range ones pass through: the scan
+// reports the latter)
+__global__ __launch_bounds__(kBlock) void k_ell_relabel(int64_t n, int bw, int ld, const int32_t *__restrict__ perm,
+                                                        const int32_t *__restrict__ iperm,
+                                                        const int32_t *__restrict__ adj, const double *__restrict__ off,
+                                                        const double *__restrict__ diag, int32_t *__restrict__ adj2,
+                                                        double *__restrict__ off2, double *__restrict__ diag2)
+{
+    const int64_t i2 = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i2 >= n) return;
+    const int64_t i = perm[i2];
+    diag2[i2] = diag[i];
+    for (int j = 0; j < bw; ++j) {
+        const int k = adj[i * ld + j];
+        adj2[i2 * ld + j] = (k >= 1 && k <= n) ? iperm[k - 1] + 1 : k;
+        off2[i2 * ld + j] = off[i * ld + j];
+    }
+    for (int j = bw; j < ld; ++j) {
+        adj2[i2 * ld + j] = 0;
+        off2[i2 * ld + j] = 0.0;
+    }
+}
+
+// smallest and largest count of every species (mm[2k], mm[2k+1])
+__global__ __launch_bounds__(kBlock) void k_coord_minmax(int64_t n, int ns, int ld, const int32_t *__restrict__ state,
+                                                         int *__restrict__ mm)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    for (int k = 0; k < ns; ++k) {
+        const int v = i < n ? state[i * ld + k] : 0;
+        const int lo = wave_min_i(i < n ? v : INT_MAX);
+        const int hi = wave_max_i(i < n ? v : INT_MIN);
+        if ((threadIdx.x & 63) == 0 && lo != INT_MAX) {
+            atomicMin(&mm[2 * k], lo);
+            atomicMax(&mm[2 * k + 1], hi);
+        }
+    }
+}
+
+struct KeyLayout {
+    int ns;
+    int lo[16];
+    int shift[16];
+};
+
+// species 1 in the lowest bits: ascending keys = lexicographic order with the
+// first species running fastest (the order of the benchmark boxes)
+__global__ __launch_bounds__(kBlock) void k_pack_keys(int64_t n, int ld, const int32_t *__restrict__ state, KeyLayout L,
+                                                      unsigned long long *__restrict__ keys, int32_t *__restrict__ idx)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    unsigned long long key = 0;
+    for (int k = 0; k < L.ns; ++k) key |= (unsigned long long)(unsigned)(state[i * ld + k] - L.lo[k]) << L.shift[k];
+    keys[i] = key;
+    idx[i] = (int32_t)i;
+}
+
+__global__ __launch_bounds__(kBlock) void k_invert_perm(int64_t n, const int32_t *__restrict__ perm,
+                                                        int32_t *__restrict__ iperm)
+{
+    const int64_t i2 = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i2 < n) iperm[perm[i2]] = (int32_t)i2;
+}
+
+__global__ __launch_bounds__(kBlock) void k_gather_index(int64_t n, const int32_t *__restrict__ index,
+                                                         const double *__restrict__ src, double *__restrict__ dst)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) dst[i] = src[index[i]];
 }
 
 // banded form: diagonal d is slot slot_of[d]; row r reads source r - shift
@@ -238,6 +314,21 @@ int build_from_ell_device(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, cons
     HIP_TRY_B(hipMemcpyAsync(ctx->d_ell_adj.p, adj, nent * sizeof(int32_t), hipMemcpyHostToDevice, st));
     HIP_TRY_B(hipMemcpyAsync(ctx->d_ell_off.p, offdiag, nent * sizeof(double), hipMemcpyHostToDevice, st));
     HIP_TRY_B(hipMemcpyAsync(ctx->d_ell_diag.p, diag, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
+    const int32_t *ell_adj = ctx->d_ell_adj.p;
+    const double *ell_off = ctx->d_ell_off.p, *ell_diag = ctx->d_ell_diag.p;
+    if (ctx->perm_on) {
+        // columns renumbered and reordered to the internal state order; the
+        // transpose below then never knows about the caller's order
+        HIP_TRY_B(ctx->d_ell_adj2.reserve(nent, false));
+        HIP_TRY_B(ctx->d_ell_off2.reserve(nent, false));
+        HIP_TRY_B(ctx->d_ell_diag2.reserve((size_t)n, false));
+        hipLaunchKernelGGL(k_ell_relabel, dim3((int)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, (int64_t)n,
+                           (int)bw, (int)ld, ctx->d_perm.p, ctx->d_iperm.p, ctx->d_ell_adj.p, ctx->d_ell_off.p,
+                           ctx->d_ell_diag.p, ctx->d_ell_adj2.p, ctx->d_ell_off2.p, ctx->d_ell_diag2.p);
+        ell_adj = ctx->d_ell_adj2.p;
+        ell_off = ctx->d_ell_off2.p;
+        ell_diag = ctx->d_ell_diag2.p;
+    }
 
     HIP_TRY_B(ctx->d_cnt.reserve((size_t)std::max<int64_t>(nact, 64), false));
     HIP_TRY_B(ctx->d_scan.reserve(sizeof(ScanOut), false));
@@ -253,7 +344,7 @@ int build_from_ell_device(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, cons
     HIP_TRY_B(hipMemcpyAsync(ctx->d_scan.p, &init, sizeof(init), hipMemcpyHostToDevice, st));
     ScanOut *dscan = reinterpret_cast<ScanOut *>(ctx->d_scan.p);
     const int gsrc = (int)((n + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(k_ell_scan, dim3(gsrc), dim3(kBlock), 0, st, (int64_t)n, (int)bw, (int)ld, ctx->d_ell_adj.p,
+    hipLaunchKernelGGL(k_ell_scan, dim3(gsrc), dim3(kBlock), 0, st, (int64_t)n, (int)bw, (int)ld, ell_adj,
                        row0, nloc, ctx->d_cnt.p, dscan);
     ScanOut res;
     HIP_TRY_B(hipMemcpyAsync(&res, dscan, sizeof(res), hipMemcpyDeviceToHost, st));
@@ -300,7 +391,7 @@ int build_from_ell_device(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, cons
         HIP_TRY_B(ctx->d_slot.reserve(kMaxDiag, false));
         HIP_TRY_B(hipMemcpyAsync(ctx->d_slot.p, slot_of, sizeof(int) * (size_t)nd, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(k_ell_to_dia, dim3((int)((nact2 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, (int64_t)n,
-                           (int)ld, ctx->d_ell_adj.p, ctx->d_ell_off.p, ctx->d_ell_diag.p, row0, nloc, nd, D,
+                           (int)ld, ell_adj, ell_off, ell_diag, row0, nloc, nd, D,
                            ctx->d_slot.p, ctx->d_dia.p, ctx->d_diag.p);
         HIP_TRY_B(hipStreamSynchronize(st));
         ctx->nd = nd;
@@ -329,14 +420,74 @@ int build_from_ell_device(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, cons
     HIP_TRY_B(hipMemsetAsync(ctx->d_ticket.p, 0, (size_t)std::max<int64_t>(nact, 64) * sizeof(int32_t), st));
     if (nchunks > 0) {
         hipLaunchKernelGGL(k_sell_init, dim3((int)((nchunks + 3) / 4)), dim3(kBlock), 0, st, nchunks, nloc, row0,
-                           ctx->d_off.p, ctx->d_col.p, ctx->d_val.p, ctx->d_ell_diag.p, ctx->d_diag.p);
-        hipLaunchKernelGGL(k_sell_fill, dim3(gsrc), dim3(kBlock), 0, st, (int64_t)n, (int)bw, (int)ld, ctx->d_ell_adj.p,
-                           ctx->d_ell_off.p, row0, nloc, ctx->d_off.p, ctx->d_ticket.p, ctx->d_col.p, ctx->d_val.p);
+                           ctx->d_off.p, ctx->d_col.p, ctx->d_val.p, ell_diag, ctx->d_diag.p);
+        hipLaunchKernelGGL(k_sell_fill, dim3(gsrc), dim3(kBlock), 0, st, (int64_t)n, (int)bw, (int)ld, ell_adj,
+                           ell_off, row0, nloc, ctx->d_off.p, ctx->d_ticket.p, ctx->d_col.p, ctx->d_val.p);
         hipLaunchKernelGGL(k_sell_sort_rows, dim3((int)((nloc + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, nloc,
                            ctx->d_cnt.p, ctx->d_off.p, ctx->d_col.p, ctx->d_val.p);
     }
     HIP_TRY_B(hipStreamSynchronize(st));
     ctx->have_sell = true;
+    return 0;
+}
+
+void launch_gather_index(int64_t n, const int32_t *index, const double *src, double *dst, hipStream_t st)
+{
+    if (n > 0)
+        hipLaunchKernelGGL(k_gather_index, dim3((int)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, n, index, src,
+                           dst);
+}
+
+int state_order_from_coords(kfsp_ctx *ctx, int32_t n, int32_t ns, int32_t ld, const int32_t *state, bool *ok)
+{
+    *ok = false;
+    if (ns > 16) return 0;                                 // more species than the key layout holds
+    hipStream_t st = ctx->stream;
+    const size_t nent = (size_t)n * (size_t)ld;
+    HIP_TRY_B(ctx->d_coords.reserve(nent + 64, false));
+    HIP_TRY_B(hipMemcpyAsync(ctx->d_coords.p, state, nent * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    int mm[32];
+    for (int k = 0; k < ns; ++k) {
+        mm[2 * k] = INT_MAX;
+        mm[2 * k + 1] = INT_MIN;
+    }
+    int *dmm = reinterpret_cast<int *>(ctx->d_coords.p + nent);
+    HIP_TRY_B(hipMemcpyAsync(dmm, mm, sizeof(int) * 2 * (size_t)ns, hipMemcpyHostToDevice, st));
+    const int grid = (int)(((int64_t)n + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_coord_minmax, dim3(grid), dim3(kBlock), 0, st, (int64_t)n, (int)ns, (int)ld, ctx->d_coords.p,
+                       dmm);
+    HIP_TRY_B(hipMemcpyAsync(mm, dmm, sizeof(int) * 2 * (size_t)ns, hipMemcpyDeviceToHost, st));
+    HIP_TRY_B(hipStreamSynchronize(st));
+    KeyLayout L;
+    L.ns = ns;
+    int bits = 0;
+    for (int k = 0; k < ns; ++k) {
+        const long long range = (long long)mm[2 * k + 1] - (long long)mm[2 * k];
+        if (range < 0) return 0;                           // no states
+        int b = 0;
+        while ((1LL << b) <= range) ++b;
+        L.lo[k] = mm[2 * k];
+        L.shift[k] = bits;
+        bits += b;
+    }
+    if (bits > 64) return 0;                               // does not pack: keep the caller's order
+    if (bits == 0) bits = 1;
+    HIP_TRY_B(ctx->d_keys.reserve(2 * (size_t)n, false));
+    HIP_TRY_B(ctx->d_sortidx.reserve((size_t)n, false));
+    HIP_TRY_B(ctx->d_perm.reserve((size_t)n, false));
+    HIP_TRY_B(ctx->d_iperm.reserve((size_t)n, false));
+    unsigned long long *kin = ctx->d_keys.p, *kout = ctx->d_keys.p + n;
+    hipLaunchKernelGGL(k_pack_keys, dim3(grid), dim3(kBlock), 0, st, (int64_t)n, (int)ld, ctx->d_coords.p, L, kin,
+                       ctx->d_sortidx.p);
+    size_t tmp_bytes = 0;
+    HIP_TRY_B(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, kin, kout, ctx->d_sortidx.p, ctx->d_perm.p, (int)n,
+                                                 0, bits, st));
+    HIP_TRY_B(ctx->d_sorttmp.reserve(tmp_bytes + 256, false));
+    HIP_TRY_B(hipcub::DeviceRadixSort::SortPairs(ctx->d_sorttmp.p, tmp_bytes, kin, kout, ctx->d_sortidx.p, ctx->d_perm.p,
+                                                 (int)n, 0, bits, st));
+    hipLaunchKernelGGL(k_invert_perm, dim3(grid), dim3(kBlock), 0, st, (int64_t)n, ctx->d_perm.p, ctx->d_iperm.p);
+    HIP_TRY_B(hipStreamSynchronize(st));
+    *ok = true;
     return 0;
 }
 

@@ -97,6 +97,17 @@ struct kfsp_ctx {
     DevBuf<double> d_ell_off, d_ell_diag;
     DevBuf<int> d_slot;
     DevBuf<char> d_scan;
+    // Internal state order (kfsp_set_state_coords): the device keeps generator and
+    // vectors in lexicographic order of the state coordinates, the host sees its
+    // own order.  perm[new] = old, iperm[old] = new (0-based).
+    DevBuf<int32_t> d_perm, d_iperm, d_coords, d_ell_adj2;
+    DevBuf<double> d_ell_off2, d_ell_diag2, d_pstage;
+    DevBuf<unsigned long long> d_keys;     // 2 n sort keys (in, out)
+    DevBuf<int32_t> d_sortidx;             // n identity indices (sort values in)
+    DevBuf<char> d_sorttmp;
+    int64_t perm_pending_n = 0;            // coordinates received for a generator of this size
+    bool perm_on = false;                  // the current generator and vectors are permuted
+    int64_t prod_count = 0, prod_last = 0; // products on the current / the previous generator
     // optional CSR copy for the CSR-stream kernel variant
     DevBuf<int64_t> d_rowptr;
     DevBuf<int32_t> d_ccol, d_tile;
@@ -133,6 +144,9 @@ struct kfsp_ctx {
     int64_t opt_small = 1;        // 1: one-launch Arnoldi pass for <= 16384 rows
     int64_t opt_overlap = 1;      // 0: exchange and product strictly one after the other
     int64_t opt_host_build = 0;   // 1: transpose reference-layout input on the host (A/B testing)
+    int64_t opt_state_order = 0;          // 1: use kfsp_set_state_coords (off: sums stay in the reference's order)
+    int64_t opt_state_order_min = 32768;  // smallest generator that is reordered
+    int64_t opt_state_order_products = 128;  // ... and only if its predecessor saw this many products
     double t_ms[KFSP_T_COUNT] = {0, 0, 0, 0, 0, 0};
 };
 
@@ -140,4 +154,9 @@ namespace kfsp {
 // generator build on the device from the reference layout (kfsp_build.hip)
 int build_from_ell_device(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, const int32_t *adj,
                           const double *offdiag, const double *diag);
+// lexicographic order of n states given as ns coordinates each (host array, leading
+// dimension ld): fills d_perm / d_iperm; *ok = false when the packed key needs > 64 bits
+int state_order_from_coords(kfsp_ctx *ctx, int32_t n, int32_t ns, int32_t ld, const int32_t *state, bool *ok);
+// dst[i'] = src[perm[i']] (host order -> device order) and dst[i] = src[iperm[i]] (back)
+void launch_gather_index(int64_t n, const int32_t *index, const double *src, double *dst, hipStream_t st);
 }  // namespace kfsp

@@ -140,6 +140,7 @@ CONTAINS
   SUBROUTINE ENSURE_CONTEXT()
     CHARACTER(LEN=16) :: ENV
     INTEGER :: DEV, L, STAT, RC
+    INTEGER(C_INT64_T) :: V8
     IF (C_ASSOCIATED(CTX)) RETURN
     DEV = 0
     CALL GET_ENVIRONMENT_VARIABLE('KFSP_DEVICE', ENV, L, STAT)
@@ -148,6 +149,25 @@ CONTAINS
     IF (RC /= 0) THEN
        PRINT *, 'KFSP: NO USABLE HIP DEVICE (kfsp_create returned', RC, '); THE SOLVER HAS NO CPU PATH.'
        STOP 2
+    ENDIF
+    ! KFSP_STATE_ORDER=1 lets the device keep large, long-lived FSPs in its own state
+    ! order (off by default: it changes the order of the sums); KFSP_STATE_ORDER_MIN:
+    ! smallest FSP that is reordered (library default 32768), KFSP_STATE_ORDER_PRODUCTS:
+    ! products the previous generator must have seen (default 128)
+    CALL GET_ENVIRONMENT_VARIABLE('KFSP_STATE_ORDER_MIN', ENV, L, STAT)
+    IF (STAT == 0 .AND. L > 0) THEN
+       READ(ENV(1:L), *, IOSTAT=STAT) V8
+       IF (STAT == 0) RC = KFSP_SET_OPTION(CTX, 'state_order_min' // C_NULL_CHAR, V8)
+    ENDIF
+    CALL GET_ENVIRONMENT_VARIABLE('KFSP_STATE_ORDER_PRODUCTS', ENV, L, STAT)
+    IF (STAT == 0 .AND. L > 0) THEN
+       READ(ENV(1:L), *, IOSTAT=STAT) V8
+       IF (STAT == 0) RC = KFSP_SET_OPTION(CTX, 'state_order_products' // C_NULL_CHAR, V8)
+    ENDIF
+    CALL GET_ENVIRONMENT_VARIABLE('KFSP_STATE_ORDER', ENV, L, STAT)
+    IF (STAT == 0 .AND. L > 0) THEN
+       READ(ENV(1:L), *, IOSTAT=STAT) V8
+       IF (STAT == 0) RC = KFSP_SET_OPTION(CTX, 'state_order' // C_NULL_CHAR, V8)
     ENDIF
   END SUBROUTINE ENSURE_CONTEXT
 
@@ -164,6 +184,11 @@ CONTAINS
     TYPE(FINITE_STATE_PROJECTION), INTENT(IN) :: FSP
     TYPE(CME_MODEL), INTENT(IN) :: MODEL
     INTEGER(C_INT) :: RC
+    ! the species counts let the device keep its own, locality-preserving state
+    ! order if that was asked for (nothing changes on this side of the boundary)
+    RC = KFSP_SET_STATE_COORDS(CTX, INT(FSP%SIZE, C_INT32_T), INT(MODEL%NSPECIES, C_INT32_T), &
+         INT(SIZE(FSP%STATE, 1), C_INT32_T), FSP%STATE)
+    CALL CHECK(RC, 'kfsp_set_state_coords')
     RC = KFSP_SET_MATRIX_ELL(CTX, INT(FSP%SIZE, C_INT32_T), INT(MODEL%NREACTIONS, C_INT32_T), &
          INT(SIZE(FSP%MATRIX%ADJ, 1), C_INT32_T), FSP%MATRIX%ADJ, FSP%MATRIX%OFFDIAG, FSP%MATRIX%DIAG)
     CALL CHECK(RC, 'kfsp_set_matrix_ell')

@@ -48,6 +48,8 @@ def load_library():
         "kfsp_partition": [i64, C.c_int, C.c_int, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)],
         "kfsp_set_matrix_ell": [vp, i32, i32, i32, vp, vp, vp],
         "kfsp_set_matrix_csr": [vp, i64, i64, i64, vp, vp, vp],
+        "kfsp_set_state_coords": [vp, i32, i32, i32, vp],
+        "kfsp_state_order_active": [vp, C.POINTER(C.c_int)],
         "kfsp_matrix_info": [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)],
         "kfsp_num_states": [vp, C.POINTER(i64)],
         "kfsp_dgexpv": [vp, dbl, dbl, dbl, C.c_int, vp, vp],
@@ -195,6 +197,18 @@ class KfspContext:
                   "kfsp_set_matrix_ell")
         self.n = n
         self.row0, self.nloc = self.row_block(n)
+
+    def set_state_coords(self, state):
+        """FSP%STATE as a [state][species] array, for the next set_matrix_ell of the
+        same size (internal lexicographic state order, include/kfsp.h)."""
+        state = np.ascontiguousarray(state, dtype=np.int32)
+        n, ns = state.shape
+        self._chk(self._lib.kfsp_set_state_coords(self._h, n, ns, ns, _p(state)), "kfsp_set_state_coords")
+
+    def state_order_active(self):
+        a = C.c_int(0)
+        self._chk(self._lib.kfsp_state_order_active(self._h, C.byref(a)), "kfsp_state_order_active")
+        return bool(a.value)
 
     def set_matrix_csr(self, n, rowptr, col, val, row0=None):
         rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)

@@ -16,6 +16,7 @@ with open(sys.argv[1], "rb") as f:
     adj = np.fromfile(f, dtype=np.int32, count=nr * n).reshape(n, nr)
     off = np.fromfile(f, dtype=np.float64, count=nr * n).reshape(n, nr)
     diag = np.fromfile(f, dtype=np.float64, count=n)
+    state = np.fromfile(f, dtype=np.int32, count=ns * n).reshape(n, ns)
 nnz = int((adj > 0).sum()) + n
 ctx = KfspContext(0)
 ctx.set_matrix_ell(adj, off, diag)
@@ -38,3 +39,31 @@ b_real = 12 * info["slots"] + 24 * n
 span = np.abs(dst - src)
 print(f"SpMV {ms * 1e3:.1f} us/launch: algorithmic {b_alg / ms / 1e6:.0f} GB/s, stored bytes (12/slot + 24/row) "
       f"{b_real / ms / 1e6:.0f} GB/s; |col-row| median {int(np.median(span))}, 90% {int(np.quantile(span, 0.9))}, max {int(span.max())}")
+
+# the same call sequence with the coordinates handed over first: the library keeps
+# generator and vectors in lexicographic state order internally
+ctx.set_option("state_order", 1)               # opt-in
+ctx.set_option("state_order_products", 0)      # (the default waits for long-lived generators)
+ctx.set_state_coords(state)
+ctx.set_matrix_ell(adj, off, diag)
+assert ctx.state_order_active()
+info2 = ctx.matrix_info()
+ctx.set_vector(x)
+ctx.begin_step()
+y2 = ctx.spmv_w()
+print(f"with kfsp_set_state_coords: stored slots={info2['slots']} max |err| vs numpy = {np.abs(y2 - ref).max():.3e}")
+ctx.spmv_bench(20)
+ms2 = ctx.spmv_bench(reps) / reps
+print(f"SpMV {ms2 * 1e3:.1f} us/launch: algorithmic {b_alg / ms2 / 1e6:.0f} GB/s, stored bytes "
+      f"{(12 * info2['slots'] + 24 * n) / ms2 / 1e6:.0f} GB/s")
+t = ctx.timers(reset=True)
+import time
+t0 = time.perf_counter()
+for _ in range(10):
+    ctx.set_state_coords(state)
+    ctx.set_matrix_ell(adj, off, diag)
+t1 = time.perf_counter()
+for _ in range(10):
+    ctx.set_matrix_ell(adj, off, diag)
+t2 = time.perf_counter()
+print(f"upload + device build: {(t1 - t0) * 100:.2f} ms with the state order, {(t2 - t1) * 100:.2f} ms without")

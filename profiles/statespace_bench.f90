@@ -5,7 +5,7 @@
 !   flang -O3 -fopenmp -I$B profiles/statespace_bench.f90 $B/libkfsp_fortran.a -o /tmp/ssb
 !   KFSP_HOST_THREADS=<t> /tmp/ssb <path duration> <rounds> [<dump file>]
 ! With a dump file the final generator is written as
-!   int32 ns, nr, n ; int32 ADJ(nr,n) ; f64 OFFDIAG(nr,n) ; f64 DIAG(n)
+!   int32 ns, nr, n ; int32 ADJ(nr,n) ; f64 OFFDIAG(nr,n) ; f64 DIAG(n) ; int32 STATE(ns,n)
 ! for profiles/fsp_spmv_timing.py (SpMV rate on an FSP in the reference's own
 ! state order).
 MODULE SSB_MODEL
@@ -119,6 +119,7 @@ PROGRAM SSB
      WRITE(U) FSP%MATRIX%ADJ(1:10, 1:FSP%SIZE)
      WRITE(U) FSP%MATRIX%OFFDIAG(1:10, 1:FSP%SIZE)
      WRITE(U) FSP%MATRIX%DIAG(1:FSP%SIZE)
+     WRITE(U) FSP%STATE(1:6, 1:FSP%SIZE)
      CLOSE(U)
   ENDIF
 END PROGRAM SSB

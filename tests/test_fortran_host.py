@@ -113,10 +113,10 @@ def test_parsed_propensities_match_reference_parser(dump, tmp_path):
     assert np.abs(P - closed).max() <= 1e-12 * np.abs(closed).max()
 
 
-def _solve(dump, tmp_path, fixture, case):
+def _solve(dump, tmp_path, fixture, case, env=None):
     g = np.load(os.path.join(GOLDEN, f"solve_{fixture}.npz"))
     p = str(tmp_path / "s.bin")
-    text = _run(dump, ["solve", case, p, repr(float(g["T"]))], tmp_path)
+    text = _run(dump, ["solve", case, p, repr(float(g["T"]))], tmp_path, env=env)
     return g, MG.read_fsp(p), MG.parse_log(text)
 
 
@@ -155,6 +155,23 @@ def test_cme_solve_adaptive_fsp_exact_on_short_horizons(dump, tmp_path, fixture,
     assert d["n"] == int(g["n"])
     assert np.array_equal(d["state"], g["state"])
     assert np.array_equal(d["adj"], g["adj"])
+    assert np.abs(log["wsum"] - g["wsum"]).max() < 1e-10
+    assert np.abs(d["vector"] - g["vector"]).sum() < 1e-10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fixture,case", [("toggle_input_T05", "toggle_input"),
+                                          ("repressilator_input_T1", "repressilator_input"),
+                                          ("goutsias_input_T40", "goutsias_input")])
+def test_cme_solve_with_internal_state_order(dump, tmp_path, fixture, case):
+    """The same adaptive runs with the device keeping every FSP in its own
+    lexicographic state order (opt-in KFSP_STATE_ORDER=1; KFSP_STATE_ORDER_MIN=1, KFSP_STATE_ORDER_PRODUCTS=0 force it at these sizes):
+    sums run in another order on the device, everything the host sees - step log,
+    state list, links, probabilities by state - is as before."""
+    g, d, log = _solve(dump, tmp_path, fixture, case, env={"KFSP_STATE_ORDER": "1", "KFSP_STATE_ORDER_MIN": "1", "KFSP_STATE_ORDER_PRODUCTS": "0"})
+    assert np.array_equal(log["step_n"], g["step_n"])
+    assert np.array_equal(log["step_tau"], g["step_tau"]) and np.array_equal(log["step_m"], g["step_m"])
+    assert np.array_equal(d["state"], g["state"]) and np.array_equal(d["adj"], g["adj"])
     assert np.abs(log["wsum"] - g["wsum"]).max() < 1e-10
     assert np.abs(d["vector"] - g["vector"]).sum() < 1e-10
 
