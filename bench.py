@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c3x", "tiny"])
+    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c3x", "c4", "tiny"])
     ap.add_argument("--variant", type=int, default=0, help="SpMV kernel variant (0 auto: DIA/SELL, 1 CSR-stream, 2 SELL)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-expv", action="store_true")
@@ -60,6 +60,10 @@ def spmv_model(workload, nranks):
         return synth.repressilator(dims=(171, 171, 171 * nranks)), "repressilator_model.input propensities, box 171x171x(171*ranks)"
     if workload == "c3x":
         return synth.repressilator(dims=(216, 216, 216 * nranks)), "repressilator_model.input propensities, box 216x216x(216*ranks) (10^7 states/GPU)"
+    if workload == "c4":
+        # the conserved-DNA state set of BASELINE config 4 (2.025e7 states per GPU); ranks stack along RNA
+        return (synth.GoutsiasConserved(150, 150, 150) if nranks == 1 else None,
+                "goutsias_model.input propensities, M,D,RNA in [0,150)^3 x 6 DNA configurations (single GPU only)")
     if workload == "c2":
         return synth.toggle(1000, 1000 * nranks), "toggle_model.input propensities, box 1000x(1000*ranks)"
     return synth.repressilator(dims=(40, 40, 40 * nranks)), "tiny repressilator box 40x40x(40*ranks)"
@@ -119,6 +123,8 @@ def main():
 
     # ---------------------------------------------------------------- SpMV
     mdl, desc = spmv_model(args.workload, world)
+    if mdl is None:
+        sys.exit(f"workload {args.workload} is defined for one GPU")
     row0, nrows = ctx.row_block(mdl.n)
     t0 = time.time()
     rowptr, col, val = mdl.csr_rows(row0, nrows)

@@ -446,7 +446,9 @@ int maybe_upload_dia(kfsp_ctx *ctx, const HostSell &S, const std::vector<int32_t
             ++nnz_off;
         }
     }
-    if (nd == 0 || (double)nd * (double)nloc > 1.25 * (double)nnz_off + 1024.0) return 0;
+    // a stored diagonal entry costs 8 bytes whether it is zero or not, a SELL slot 12: the
+    // banded form moves fewer bytes as long as nd * rows < 1.5 * (off-diagonal entries)
+    if (nd == 0 || (double)nd * (double)nloc > 1.5 * (double)nnz_off + 1024.0) return 0;
     std::sort(delta, delta + nd);
     const int64_t ld = round_up(ctx->nchunks * kChunk, 2 * kChunk);   // the banded kernel works on 128-row groups
     std::vector<double> val((size_t)nd * (size_t)ld, 0.0);

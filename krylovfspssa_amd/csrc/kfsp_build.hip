@@ -368,7 +368,8 @@ int build_from_ell_device(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, cons
         else dl[nd++] = {-res.dmin[j], j};
     }
     if (nd == 0 || nd > kMaxDiag) banded = false;
-    if (banded && (double)nd * (double)nloc > 1.25 * (double)res.nnz_off + 1024.0) banded = false;
+    // (8 bytes per stored diagonal entry against 12 per SELL slot, cf. maybe_upload_dia)
+    if (banded && (double)nd * (double)nloc > 1.5 * (double)res.nnz_off + 1024.0) banded = false;
 
     ctx->use_dia = false;
     ctx->nd = 0;

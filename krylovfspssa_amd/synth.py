@@ -201,6 +201,115 @@ def goutsias_box(dims, params=GOUTSIAS_PARAMS):
     return BoxModel("goutsias", dims, st, prop)
 
 
+class GoutsiasConserved:
+    """BASELINE config 4: the Goutsias model on M, D, RNA in [0, nM) x [0, nD) x [0, nRNA)
+    times the six ways two DNA copies split into (DNA, DNA.D, DNA.2D) - the state
+    set a run from (2, 6, 0, 2, 0, 0) lives on (examples/transcr6d.f90:50), 150^3 x 6 =
+    2.025e7 states at full size.  Index = M + nM (D + nD (RNA + nRNA cfg)).  Same
+    interface as BoxModel (ell / csr_rows / nnz); species order of the reference's
+    model file: M, D, RNA, DNA, DNA.D, DNA.2D."""
+
+    CFG = np.array([(2, 0, 0), (1, 1, 0), (1, 0, 1), (0, 2, 0), (0, 1, 1), (0, 0, 2)], dtype=np.int64)
+    # (dM, dD, dRNA) and the successor configuration of every reaction (-1: a DNA form would go negative)
+    _SAME = (0, 1, 2, 3, 4, 5)
+    REACTIONS = [((1, 0, 0), _SAME), ((-1, 0, 0), _SAME), ((0, 0, 1), _SAME), ((0, 0, -1), _SAME),
+                 ((0, -1, 0), (1, 3, 4, -1, -1, -1)), ((0, 1, 0), (-1, 0, -1, 1, 2, -1)),
+                 ((0, -1, 0), (-1, 2, -1, 4, 5, -1)), ((0, 1, 0), (-1, -1, 1, -1, 3, 4)),
+                 ((-2, 1, 0), _SAME), ((2, -1, 0), _SAME)]
+
+    def __init__(self, nM=150, nD=150, nRNA=150, params=None):
+        self.name = "goutsias_conserved"
+        self.box = (int(nM), int(nD), int(nRNA))
+        self.dims = self.box + (6,)
+        self.c = GOUTSIAS_PARAMS if params is None else params
+        self.strides = np.array([1, nM, nM * nD, nM * nD * nRNA], dtype=np.int64)
+        self.n = int(nM * nD * nRNA * 6)
+        self.d, self.R = 6, 10
+
+    def coords(self, idx):
+        """species counts (M, D, RNA, DNA, DNA.D, DNA.2D) of the states idx"""
+        box = [(idx // self.strides[k]) % self.dims[k] for k in range(3)]
+        cfg = idx // self.strides[3]
+        return box + [self.CFG[cfg, k] for k in range(3)]
+
+    def _prop(self, r, X):
+        m, d_, rna, dna, dnad, dna2d = X
+        c = self.c
+        return (c[0] * rna, c[1] * m, c[2] * dnad, c[3] * rna, c[4] * dna * d_, c[5] * dnad,
+                c[6] * dnad * d_, c[7] * dna2d, c[8] * m * (m - 1) / 2.0, c[9] * d_)[r]
+
+    def _step(self, idx, r, sign):
+        """index of the state reached from idx by reaction r (sign +1) or of the state
+        that reaches idx by it (sign -1); -1 = negative population, -2 = outside the box"""
+        delta, succ = self.REACTIONS[r]
+        cmap = np.asarray(succ, dtype=np.int64)
+        if sign < 0:
+            inv = np.full(6, -1, dtype=np.int64)
+            inv[cmap[cmap >= 0]] = np.nonzero(cmap >= 0)[0]
+            cmap = inv
+        cfg = idx // self.strides[3]
+        cfg2 = cmap[cfg]
+        tgt = idx + (cfg2 - cfg) * self.strides[3]
+        neg = cfg2 < 0
+        out = np.zeros(len(idx), dtype=bool)
+        for k in range(3):
+            s = sign * delta[k]
+            if s:
+                y = (idx // self.strides[k]) % self.dims[k] + s
+                neg |= y < 0
+                out |= y >= self.dims[k]
+                tgt = tgt + s * self.strides[k]
+        return np.where(neg, -1, np.where(out, -2, tgt))
+
+    def ell(self):
+        idx = np.arange(self.n, dtype=np.int64)
+        Xf = [x.astype(np.float64) for x in self.coords(idx)]
+        adj = np.empty((self.n, self.R), dtype=np.int32)
+        off = np.empty((self.n, self.R), dtype=np.float64)
+        diag = np.zeros(self.n, dtype=np.float64)
+        for r in range(self.R):
+            t = self._step(idx, r, +1)
+            adj[:, r] = np.where(t == -1, -1, np.where(t == -2, 0, t + 1))
+            off[:, r] = self._prop(r, Xf)
+            diag += off[:, r]
+        return adj, off, diag
+
+    def csr_rows(self, row0=0, nrows=None):
+        if nrows is None:
+            nrows = self.n - row0
+        rows = np.arange(row0, row0 + nrows, dtype=np.int64)
+        Xf = [x.astype(np.float64) for x in self.coords(rows)]
+        big = np.iinfo(np.int64).max
+        cols = np.full((nrows, self.R + 1), big, dtype=np.int64)
+        vals = np.zeros((nrows, self.R + 1), dtype=np.float64)
+        dsum = np.zeros(nrows, dtype=np.float64)
+        for r in range(self.R):
+            src = self._step(rows, r, -1)
+            ok = src >= 0
+            P = [x.astype(np.float64) for x in self.coords(np.where(ok, src, 0))]
+            cols[:, r] = np.where(ok, src, big)
+            vals[:, r] = np.where(ok, self._prop(r, P), 0.0)
+            dsum += self._prop(r, Xf)
+        cols[:, self.R] = rows
+        vals[:, self.R] = -dsum
+        order = np.argsort(cols, axis=1, kind="stable")
+        cols = np.take_along_axis(cols, order, axis=1)
+        vals = np.take_along_axis(vals, order, axis=1)
+        valid = cols != big
+        rowptr = np.concatenate(([0], np.cumsum(valid.sum(axis=1)))).astype(np.int64)
+        return rowptr, cols[valid].astype(np.int32), vals[valid]
+
+    def nnz(self):
+        """true nonzeros incl. the diagonal (links whose propensity happens to be 0 count, as in BoxModel)"""
+        nnz = self.n
+        for delta, succ in self.REACTIONS:
+            c = sum(1 for s in succ if s >= 0)
+            for k in range(3):
+                c *= max(self.box[k] - abs(delta[k]), 0)
+            nnz += c
+        return nnz
+
+
 def spmv_alg_bytes(nnz, n):
     """Algorithmic bytes of one generator SpMV: CSR with f64
     values + int32 columns (12 B per nonzero incl. the diagonal) and per row a

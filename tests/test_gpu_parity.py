@@ -54,7 +54,8 @@ def test_spmv_synthetic_boxes_ell_and_csr_agree(ctx, oracle):
     from krylovfspssa_amd import synth
     rng = np.random.default_rng(7)
     for mdl in (synth.toggle(130, 77), synth.repressilator(dims=(23, 19, 17)),
-                synth.goutsias_box((7, 6, 5, 3, 3, 3)), synth.birth_death((9, 8, 7, 6))):
+                synth.goutsias_box((7, 6, 5, 3, 3, 3)), synth.birth_death((9, 8, 7, 6)),
+                synth.GoutsiasConserved(11, 9, 8)):
         adj, off, diag = mdl.ell()
         A = oracle.EllMatrix(adj, off, diag)
         x = rng.random(mdl.n)
@@ -239,6 +240,38 @@ def test_size_independent_properties_at_benchmark_size(ctx):
     p0 = synth.poisson_p0(mdl, 30.0)
     ctx.set_vector(p0)
     ws = ctx.expv_fixed(30, 0.01, 2)
+    w = ctx.get_vector()
+    assert np.all(w >= 0) and 0.999 < ws[-1] <= 1.0 + 1e-12
+    assert ws[-1] == pytest.approx(w.sum(), rel=1e-13)
+
+
+def test_size_independent_properties_on_the_config4_state_set(ctx):
+    """BASELINE config 4's generator (Goutsias, conserved DNA: M, D, RNA boxes x 6
+    DNA configurations; here 60^3 x 6 = 1.3e6 states, the full 150^3 x 6 is
+    bench.py --workload c4): banded upload (gather rows) and SELL upload (reference
+    layout) agree, linearity, the mass-balance identity, determinism."""
+    from krylovfspssa_amd import synth
+    mdl = synth.GoutsiasConserved(60, 60, 60)
+    rowptr, col, val = mdl.csr_rows()
+    assert rowptr[-1] == mdl.nnz()
+    rng = np.random.default_rng(5)
+    x, z = rng.random(mdl.n), rng.random(mdl.n)
+    ctx.set_matrix_ell(*mdl.ell())
+    y_sell = ctx.spmv(x)
+    ctx.set_matrix_csr(mdl.n, rowptr, col, val)
+    ax, az = ctx.spmv(x), ctx.spmv(z)
+    mag = np.abs(ax).max()
+    assert np.abs(ax - y_sell).max() <= 1e-12 * mag
+    assert np.abs(ctx.spmv(2.0 * x - 3.0 * z) - (2.0 * ax - 3.0 * az)).max() <= 1e-9 * mag
+    colsum = np.zeros(mdl.n)
+    np.add.at(colsum, col, val)
+    assert (ax.sum() - colsum @ x) == pytest.approx(0.0, abs=1e-7 * np.abs(ax).sum())
+    assert np.array_equal(ax, ctx.spmv(x))
+    # a few fixed steps from a point mass keep the mass (up to the leak) and the sign
+    p0 = np.zeros(mdl.n)
+    p0[2 + 60 * (6 + 60 * 0)] = 1.0                     # (M, D, RNA) = (2, 6, 0), two free DNA copies
+    ctx.set_vector(p0)
+    ws = ctx.expv_fixed(20, 0.05, 2)
     w = ctx.get_vector()
     assert np.all(w >= 0) and 0.999 < ws[-1] <= 1.0 + 1e-12
     assert ws[-1] == pytest.approx(w.sum(), rel=1e-13)
