@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c3x", "c4", "tiny"])
+    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c3x", "c4", "c5s", "tiny"])
     ap.add_argument("--variant", type=int, default=0, help="SpMV kernel variant (0 auto: DIA/SELL, 1 CSR-stream, 2 SELL)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-expv", action="store_true")
@@ -64,6 +64,11 @@ def spmv_model(workload, nranks):
         # the conserved-DNA state set of BASELINE config 4 (2.025e7 states per GPU); ranks stack along RNA
         return (synth.GoutsiasConserved(150, 150, 150) if nranks == 1 else None,
                 "goutsias_model.input propensities, M,D,RNA in [0,150)^3 x 6 DNA configurations (single GPU only)")
+    if workload == "c5s":
+        # per-GPU slab of BASELINE config 5 (6-species birth-death network on 22^6, 12 reactions): three planes
+        # of the slowest species per rank, i.e. 22^5 x 24 = 1.24e8 states on 8 GPUs
+        return (synth.birth_death((22, 22, 22, 22, 22, 3 * nranks)),
+                "synthetic 6-species birth-death network, box 22^5 x (3*ranks) (1.55e7 states per GPU)")
     if workload == "c2":
         return synth.toggle(1000, 1000 * nranks), "toggle_model.input propensities, box 1000x(1000*ranks)"
     return synth.repressilator(dims=(40, 40, 40 * nranks)), "tiny repressilator box 40x40x(40*ranks)"
