@@ -137,6 +137,8 @@ void set_matrix_args(const kfsp_ctx *c, SpmvArgs &a)
     a.D.diag = c->d_diag.p;
     a.D.nchunks = c->nchunks;
     a.D.n = c->n;
+    a.D.gmask = c->dia_masked ? c->d_gmask.p : nullptr;
+    a.D.zero = c->d_zero.p;
     a.udot2 = nullptr;
     a.partial2 = nullptr;
 }
@@ -210,7 +212,7 @@ int run_product(kfsp_ctx *ctx, int mode, SpmvArgs a, const double *src, bool src
         a.trip_split = INT64_MAX;
         a.trip_jump = 0;
         const int g = trips_grid(trips, cap);
-        launch_spmv(mode, g, a, nt, dia, st);
+        launch_spmv(mode, g, a, nt, dia ? (ctx->dia_masked ? 2 : 1) : 0, st);
         if (p1) *p1 = Pending{P1, g};
         if (p2) *p2 = Pending{P2, g};
         return 0;
@@ -231,7 +233,7 @@ int run_product(kfsp_ctx *ctx, int mode, SpmvArgs a, const double *src, bool src
         a.trip_end = e;
         a.trip_split = split;
         a.trip_jump = jump;
-        launch_spmv(mode, g, a, nt, true, st);
+        launch_spmv(mode, g, a, nt, ctx->dia_masked ? 2 : 1, st);
         used += g;
     };
     launch_range(lo, hi, INT64_MAX, 0, std::min<int64_t>(cap, kMaxGrid - 512));   // interior: no halo row is read
@@ -427,6 +429,7 @@ int upload_sell(kfsp_ctx *ctx, const HostSell &S)
 int maybe_upload_dia(kfsp_ctx *ctx, const HostSell &S, const std::vector<int32_t> &cnt)
 {
     ctx->use_dia = false;
+    ctx->dia_masked = false;
     ctx->nd = 0;
     if (ctx->opt_format == 1 || ctx->nloc == 0) return 0;
     const int64_t nloc = ctx->nloc, row0 = ctx->row0;
@@ -467,7 +470,7 @@ int maybe_upload_dia(kfsp_ctx *ctx, const HostSell &S, const std::vector<int32_t
     ctx->dia_ld = ld;
     for (int d = 0; d < nd; ++d) ctx->delta[d] = (int32_t)delta[d];
     ctx->use_dia = true;
-    return 0;
+    return kfsp::build_dia_mask(ctx);
 }
 
 // CSR copy (off-diagonal entries, row order) + tiles of whole rows for the
@@ -552,6 +555,7 @@ int init_context(kfsp_ctx *ctx)
     HIP_TRY(ctx->d_g.reserve(kMH + 2, true));
     HIP_TRY(ctx->d_y.reserve(kMH, true));
     HIP_TRY(ctx->d_flag.reserve(4, true));
+    HIP_TRY(ctx->d_zero.reserve(128, true));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_H), ((size_t)kMH * kMH + 2) * sizeof(double), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_pin), (size_t)(kMH + 8) * sizeof(double), hipHostMallocDefault));
     std::memset(ctx->h_H, 0, ((size_t)kMH * kMH + 2) * sizeof(double));
@@ -603,7 +607,7 @@ int kfsp_destroy(kfsp_ctx *ctx)
     ctx->d_ticket.release(); ctx->d_slot.release(); ctx->d_scan.release(); ctx->d_strip.release();
     ctx->d_perm.release(); ctx->d_iperm.release(); ctx->d_coords.release(); ctx->d_ell_adj2.release();
     ctx->d_ell_off2.release(); ctx->d_ell_diag2.release(); ctx->d_pstage.release(); ctx->d_keys.release();
-    ctx->d_sortidx.release(); ctx->d_sorttmp.release();
+    ctx->d_sortidx.release(); ctx->d_sorttmp.release(); ctx->d_gmask.release(); ctx->d_zero.release();
     if (ctx->h_H) (void)hipHostFree(ctx->h_H);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -1322,6 +1326,7 @@ int kfsp_set_option(kfsp_ctx *ctx, const char *name, int64_t value)
     else if (k == "format") ctx->opt_format = value;
     else if (k == "fused_ortho") ctx->opt_fused = value;
     else if (k == "host_build") ctx->opt_host_build = value;
+    else if (k == "dia_mask") ctx->opt_dia_mask = value;
     else if (k == "state_order") ctx->opt_state_order = value;
     else if (k == "state_order_min") ctx->opt_state_order_min = value;
     else if (k == "state_order_products") ctx->opt_state_order_products = value;

@@ -151,6 +151,27 @@ __global__ __launch_bounds__(kBlock) void k_gather_index(int64_t n, const int32_
     if (i < n) dst[i] = src[index[i]];
 }
 
+// one wavefront per 128-row group: bit d of mask[group] = diagonal d has an entry there
+__global__ __launch_bounds__(kBlock) void k_dia_group_mask(int64_t ngroups, int nd, int64_t ld,
+                                                           const double *__restrict__ val, uint32_t *__restrict__ mask,
+                                                           unsigned long long *__restrict__ empty)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t g = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (g >= ngroups) return;
+    uint32_t m = 0;
+    for (int d = 0; d < nd; ++d) {
+        const double *p = val + (int64_t)d * ld + (g << 7) + 2 * lane;
+        const bool any = p[0] != 0.0 || p[1] != 0.0;
+        if (__ballot(any)) m |= 1u << d;
+    }
+    if (lane == 0) {
+        mask[g] = m;
+        const int e = nd - __popc(m);
+        if (e) atomicAdd(empty, (unsigned long long)e);
+    }
+}
+
 // banded form: diagonal d is slot slot_of[d]; row r reads source r - shift
 __global__ __launch_bounds__(kBlock) void k_ell_to_dia(int64_t n, int ld, const int32_t *__restrict__ adj,
                                                        const double *__restrict__ off,
@@ -372,6 +393,7 @@ int build_from_ell_device(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, cons
     if (banded && (double)nd * (double)nloc > 1.5 * (double)res.nnz_off + 1024.0) banded = false;
 
     ctx->use_dia = false;
+    ctx->dia_masked = false;
     ctx->nd = 0;
     ctx->have_sell = false;
     if (banded) {
@@ -400,7 +422,7 @@ int build_from_ell_device(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, cons
         for (int d = 0; d < nd; ++d) ctx->delta[d] = D.delta[d];
         ctx->use_dia = true;
         ctx->slots = 0;
-        return 0;
+        return build_dia_mask(ctx);
     }
 
     // SELL-64
@@ -429,6 +451,28 @@ int build_from_ell_device(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, cons
     }
     HIP_TRY_B(hipStreamSynchronize(st));
     ctx->have_sell = true;
+    return 0;
+}
+
+int build_dia_mask(kfsp_ctx *ctx)
+{
+    ctx->dia_masked = false;
+    if (!ctx->use_dia || !ctx->opt_dia_mask || ctx->nd < 1) return 0;
+    hipStream_t st = ctx->stream;
+    const int64_t ngroups = ctx->dia_ld >> 7;
+    if (ngroups < 1) return 0;
+    HIP_TRY_B(ctx->d_gmask.reserve((size_t)ngroups + 2, false));
+    unsigned long long *cnt = reinterpret_cast<unsigned long long *>(ctx->d_scan.p);
+    HIP_TRY_B(ctx->d_scan.reserve(sizeof(ScanOut), false));
+    cnt = reinterpret_cast<unsigned long long *>(ctx->d_scan.p);
+    HIP_TRY_B(hipMemsetAsync(cnt, 0, sizeof(unsigned long long), st));
+    hipLaunchKernelGGL(k_dia_group_mask, dim3((int)((ngroups + 3) / 4)), dim3(kBlock), 0, st, ngroups, ctx->nd,
+                       ctx->dia_ld, ctx->d_dia.p, ctx->d_gmask.p, cnt);
+    unsigned long long empty = 0;
+    HIP_TRY_B(hipMemcpyAsync(&empty, cnt, sizeof(empty), hipMemcpyDeviceToHost, st));
+    HIP_TRY_B(hipStreamSynchronize(st));
+    // the masked variant trades a little address arithmetic for the skipped bytes: worth it from ~3 % on
+    ctx->dia_masked = (double)empty >= 0.03 * (double)ctx->nd * (double)ngroups;
     return 0;
 }
 

@@ -92,6 +92,10 @@ struct kfsp_ctx {
     int32_t delta[kMaxDiag] = {0};
     int64_t dia_ld = 0;
     bool have_sell = false;
+    // which 128-row groups of which diagonals hold entries at all (used when enough are empty)
+    DevBuf<uint32_t> d_gmask;
+    DevBuf<double> d_zero;   // 128 zeros, the stand-in for an empty segment
+    bool dia_masked = false;
     // device-side build from the reference layout (kfsp_build.hip)
     DevBuf<int32_t> d_ell_adj, d_cnt, d_ticket;
     DevBuf<double> d_ell_off, d_ell_diag;
@@ -144,6 +148,7 @@ struct kfsp_ctx {
     int64_t opt_small = 1;        // 1: one-launch Arnoldi pass for <= 16384 rows
     int64_t opt_overlap = 1;      // 0: exchange and product strictly one after the other
     int64_t opt_host_build = 0;   // 1: transpose reference-layout input on the host (A/B testing)
+    int64_t opt_dia_mask = 1;             // 0: never skip empty diagonal segments
     int64_t opt_state_order = 0;          // 1: use kfsp_set_state_coords (off: sums stay in the reference's order)
     int64_t opt_state_order_min = 32768;  // smallest generator that is reordered
     int64_t opt_state_order_products = 128;  // ... and only if its predecessor saw this many products
@@ -154,6 +159,9 @@ namespace kfsp {
 // generator build on the device from the reference layout (kfsp_build.hip)
 int build_from_ell_device(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, const int32_t *adj,
                           const double *offdiag, const double *diag);
+// after a banded generator was stored: find the empty (diagonal, 128-row group) segments and
+// switch the masked kernel variant on if they are worth skipping
+int build_dia_mask(kfsp_ctx *ctx);
 // lexicographic order of n states given as ns coordinates each (host array, leading
 // dimension ld): fills d_perm / d_iperm; *ok = false when the packed key needs > 64 bits
 int state_order_from_coords(kfsp_ctx *ctx, int32_t n, int32_t ns, int32_t ld, const int32_t *state, bool *ok);

@@ -44,6 +44,11 @@ struct DiaDev {
     const double *diag;
     int64_t nchunks;
     int64_t n;           // global number of states (clamp bound)
+    // optional: bit d of gmask[c] tells whether diagonal d has any entry in the
+    // 128-row group c; empty segments are then read from `zero` (128 zeros that
+    // stay in cache) instead of from the stored diagonal
+    const uint32_t *gmask;
+    const double *zero;
 };
 
 // Same rows in plain CSR (off-diagonal entries only), for the LDS-staged
@@ -153,7 +158,8 @@ struct SmallArnoldiArgs {
 void launch_arnoldi_small(const SmallArnoldiArgs &a, bool dia, hipStream_t s);
 
 // kernel launchers (kfsp_kernels.hip)
-void launch_spmv(int mode, int grid, const SpmvArgs &a, bool nontemporal, bool dia, hipStream_t s);
+// fmt: 0 SELL-64, 1 banded, 2 banded with group masks
+void launch_spmv(int mode, int grid, const SpmvArgs &a, bool nontemporal, int fmt, hipStream_t s);
 void launch_ortho2(int grid, const Ortho2Args &a, hipStream_t s);
 void launch_spmv_csr_stream(int grid, const CsrDev &A, const double *xg, int64_t row0, double *y, hipStream_t s);
 void launch_ortho(int grid, const OrthoArgs &a, hipStream_t s);

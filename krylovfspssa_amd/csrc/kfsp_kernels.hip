@@ -153,23 +153,28 @@ __device__ __forceinline__ d2 ld_stream2(const double *p)
 // worth ~9 % of HBM rate over 8 B per lane (profiles/r01_stream_widths.log).
 // x is read as two 8-B loads (shifted by delta, so not 16-B aligned in
 // general; it is served from L2 anyway).
-template <bool NT>
+template <bool NT, bool MASKED>
 __device__ __forceinline__ d2 rows_dia(const DiaDev &D, const double *__restrict__ xg, int64_t row0,
-                                       int64_t c, int lane)
+                                       int64_t c, int lane, unsigned m)
 {
     const int64_t r = (c << 7) + 2 * lane;
     const int64_t g = row0 + r;
     const int64_t last = D.n - 1;
     const double *vp = D.val + r;
+    const double *zp = D.zero + 2 * lane;
+    // m: which diagonals have entries in this group (same for the whole wavefront; the
+    // caller fetched it one trip ahead, so no load sits in front of the address arithmetic)
     const d2 dg = ld_stream2<NT>(D.diag + r);
     d2 sum;
     sum.x = -dg.x * xg[g < last ? g : last];
     sum.y = -dg.y * xg[g + 1 < last ? g + 1 : last];
     int d = 0;
     for (; d + 2 <= D.nd; d += 2) {
-        const d2 v0 = ld_stream2<NT>(vp + (int64_t)(d + 0) * D.ld);
-        const d2 v1 = ld_stream2<NT>(vp + (int64_t)(d + 1) * D.ld);
-        int64_t i0 = g + D.delta[d + 0], i1 = g + D.delta[d + 1];
+        const bool on0 = !MASKED || ((m >> d) & 1u), on1 = !MASKED || ((m >> (d + 1)) & 1u);
+        // an empty segment costs no HBM traffic: zeros from a cached line, x from the row itself
+        const d2 v0 = ld_stream2<NT>(on0 ? vp + (int64_t)(d + 0) * D.ld : zp);
+        const d2 v1 = ld_stream2<NT>(on1 ? vp + (int64_t)(d + 1) * D.ld : zp);
+        int64_t i0 = g + (on0 ? D.delta[d + 0] : 0), i1 = g + (on1 ? D.delta[d + 1] : 0);
         int64_t j0 = i0 + 1, j1 = i1 + 1;
         i0 = i0 < 0 ? 0 : (i0 > last ? last : i0);
         j0 = j0 < 0 ? 0 : (j0 > last ? last : j0);
@@ -181,8 +186,9 @@ __device__ __forceinline__ d2 rows_dia(const DiaDev &D, const double *__restrict
         sum.y += v1.y * xg[j1];
     }
     for (; d < D.nd; ++d) {
-        const d2 v0 = ld_stream2<NT>(vp + (int64_t)d * D.ld);
-        int64_t i0 = g + D.delta[d];
+        const bool on0 = !MASKED || ((m >> d) & 1u);
+        const d2 v0 = ld_stream2<NT>(on0 ? vp + (int64_t)d * D.ld : zp);
+        int64_t i0 = g + (on0 ? D.delta[d] : 0);
         int64_t j0 = i0 + 1;
         i0 = i0 < 0 ? 0 : (i0 > last ? last : i0);
         j0 = j0 < 0 ? 0 : (j0 > last ? last : j0);
@@ -192,9 +198,11 @@ __device__ __forceinline__ d2 rows_dia(const DiaDev &D, const double *__restrict
     return sum;
 }
 
-template <int MODE, bool NT, bool DIA>
+// FMT: 0 SELL-64, 1 banded, 2 banded with group masks
+template <int MODE, bool NT, int FMT>
 __global__ __launch_bounds__(kBlock) void k_spmv(SpmvArgs a)
 {
+    constexpr bool DIA = FMT != 0;
     __shared__ double red[12];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -216,8 +224,10 @@ __global__ __launch_bounds__(kBlock) void k_spmv(SpmvArgs a)
     // finished: the partial-sum round trip overlaps the first generator loads.
     d2 sum = {0.0, 0.0};
     int64_t ct = c < a.trip_split ? c : c + a.trip_jump;   // actual trip of linear index c
+    unsigned gm = 0xFFFFFFFFu;                              // group mask of the trip about to be computed
+    if (FMT == 2 && c < cend) gm = __builtin_amdgcn_readfirstlane(a.D.gmask[ct]);
     if (c < cend) {
-        if (DIA) sum = rows_dia<NT>(a.D, a.xg, a.row0, ct, lane);
+        if (DIA) sum = rows_dia<NT, FMT == 2>(a.D, a.xg, a.row0, ct, lane, gm);
         else sum.x = row_sell<NT>(a.A, a.xg, a.row0, ct, lane);
     }
 
@@ -238,6 +248,9 @@ __global__ __launch_bounds__(kBlock) void k_spmv(SpmvArgs a)
 
     double acc = 0.0, acc2 = 0.0;
     while (c < cend) {
+        const int64_t cn = c + cstep;
+        const int64_t ctn = cn < a.trip_split ? cn : cn + a.trip_jump;
+        if (FMT == 2 && cn < cend) gm = __builtin_amdgcn_readfirstlane(a.D.gmask[ctn]);
         if (DIA) {
             const int64_t r = (ct << 7) + 2 * lane;
             if (MODE != 0) {
@@ -268,10 +281,10 @@ __global__ __launch_bounds__(kBlock) void k_spmv(SpmvArgs a)
             if (MODE == 2) acc += v * v;
             if (MODE == 3) acc2 += a.udot2[r] * v;
         }
-        c += cstep;
-        ct = c < a.trip_split ? c : c + a.trip_jump;
+        c = cn;
+        ct = ctn;
         if (c < cend) {
-            if (DIA) sum = rows_dia<NT>(a.D, a.xg, a.row0, ct, lane);
+            if (DIA) sum = rows_dia<NT, FMT == 2>(a.D, a.xg, a.row0, ct, lane, gm);
             else sum.x = row_sell<NT>(a.A, a.xg, a.row0, ct, lane);
         }
     }
@@ -288,24 +301,26 @@ __global__ __launch_bounds__(kBlock) void k_spmv(SpmvArgs a)
     }
 }
 
-template <bool NT, bool DIA>
+template <bool NT, int FMT>
 static void launch_spmv_mode(int mode, dim3 g, dim3 b, const SpmvArgs &a, hipStream_t st)
 {
-    if (mode == 0) hipLaunchKernelGGL((k_spmv<0, NT, DIA>), g, b, 0, st, a);
-    else if (mode == 1) hipLaunchKernelGGL((k_spmv<1, NT, DIA>), g, b, 0, st, a);
-    else if (mode == 2) hipLaunchKernelGGL((k_spmv<2, NT, DIA>), g, b, 0, st, a);
-    else hipLaunchKernelGGL((k_spmv<3, NT, DIA>), g, b, 0, st, a);
+    if (mode == 0) hipLaunchKernelGGL((k_spmv<0, NT, FMT>), g, b, 0, st, a);
+    else if (mode == 1) hipLaunchKernelGGL((k_spmv<1, NT, FMT>), g, b, 0, st, a);
+    else if (mode == 2) hipLaunchKernelGGL((k_spmv<2, NT, FMT>), g, b, 0, st, a);
+    else hipLaunchKernelGGL((k_spmv<3, NT, FMT>), g, b, 0, st, a);
 }
 
-void launch_spmv(int mode, int grid, const SpmvArgs &a, bool nt, bool dia, hipStream_t st)
+void launch_spmv(int mode, int grid, const SpmvArgs &a, bool nt, int fmt, hipStream_t st)
 {
     dim3 g(grid), b(kBlock);
     if (nt) {
-        if (dia) launch_spmv_mode<true, true>(mode, g, b, a, st);
-        else launch_spmv_mode<true, false>(mode, g, b, a, st);
+        if (fmt == 2) launch_spmv_mode<true, 2>(mode, g, b, a, st);
+        else if (fmt == 1) launch_spmv_mode<true, 1>(mode, g, b, a, st);
+        else launch_spmv_mode<true, 0>(mode, g, b, a, st);
     } else {
-        if (dia) launch_spmv_mode<false, true>(mode, g, b, a, st);
-        else launch_spmv_mode<false, false>(mode, g, b, a, st);
+        if (fmt == 2) launch_spmv_mode<false, 2>(mode, g, b, a, st);
+        else if (fmt == 1) launch_spmv_mode<false, 1>(mode, g, b, a, st);
+        else launch_spmv_mode<false, 0>(mode, g, b, a, st);
     }
 }
 
