@@ -5,7 +5,7 @@
 
 Launches, in order: 3 x k_stream_read for each lane width 4/8/16 B over a
 2 GiB buffer (known bytes, far larger than the 256 MiB Infinity Cache), then 5 x
-the c3 generator SpMV.  profiles/pmc_reduce.py turns the two CSVs into
+the generator SpMV of the workload given as argument (c3, c3x, c4, c4_nomask).  profiles/pmc_reduce.py turns the two CSVs into
 profiles/pmc_traffic.json.
 """
 import os
@@ -21,7 +21,12 @@ workload = sys.argv[1] if len(sys.argv) > 1 else "c3"
 ctx = KfspContext(0)
 for w in (4, 8, 16):
     ctx.selftest_stream(2 << 30, w, 3)
-mdl = synth.repressilator(171) if workload == "c3" else synth.repressilator(216)
+if workload.startswith("c4"):                     # c4 / c4_nomask: BASELINE config 4, with / without group masks
+    mdl = synth.GoutsiasConserved(150, 150, 150)
+    if workload == "c4_nomask":
+        ctx.set_option("dia_mask", 0)
+else:
+    mdl = synth.repressilator(171) if workload == "c3" else synth.repressilator(216)
 ctx.set_matrix_csr(mdl.n, *mdl.csr_rows())
 ctx.set_vector(np.random.default_rng(12345).random(mdl.n))
 ctx.begin_step()
