@@ -245,6 +245,39 @@ def test_size_independent_properties_at_benchmark_size(ctx):
     assert ws[-1] == pytest.approx(w.sum(), rel=1e-13)
 
 
+def test_size_independent_properties_at_config3_size(oracle):
+    """BASELINE config 3 (repressilator box 171^3, N = 5 000 211, the bench.py
+    workload) at full size: banded and SELL-64 forms agree, linearity, the
+    mass-balance identity, determinism; a sample of rows against the oracle's
+    scatter product."""
+    from krylovfspssa_amd import KfspContext, synth
+    mdl = synth.repressilator(171)
+    assert mdl.n == 5_000_211
+    rowptr, col, val = mdl.csr_rows()
+    assert rowptr[-1] == mdl.nnz() == 34_826_031
+    rng = np.random.default_rng(12345)
+    x, z = rng.random(mdl.n), rng.random(mdl.n)
+    c = KfspContext(0)
+    try:
+        c.set_matrix_csr(mdl.n, rowptr, col, val)
+        ax, az = c.spmv(x), c.spmv(z)
+        mag = np.abs(ax).max()
+        assert np.abs(c.spmv(2.0 * x - 3.0 * z) - (2.0 * ax - 3.0 * az)).max() <= 1e-9 * mag
+        colsum = np.zeros(mdl.n)
+        np.add.at(colsum, col, val)
+        assert (ax.sum() - colsum @ x) == pytest.approx(0.0, abs=1e-7 * np.abs(ax).sum())
+        assert np.array_equal(ax, c.spmv(x))
+        c.set_option("format", 1)                                   # SELL-64 on the same rows
+        c.set_matrix_csr(mdl.n, rowptr, col, val)
+        assert np.abs(c.spmv(x) - ax).max() <= 1e-12 * mag
+    finally:
+        c.close()
+    rows = np.unique(np.concatenate([np.arange(512), np.arange(mdl.n - 512, mdl.n), rng.integers(0, mdl.n, 4096)]))
+    ref = np.array([val[rowptr[r]:rowptr[r + 1]] @ x[col[rowptr[r]:rowptr[r + 1]]] for r in rows])
+    scale = np.array([np.abs(val[rowptr[r]:rowptr[r + 1]]) @ x[col[rowptr[r]:rowptr[r + 1]]] for r in rows])
+    assert np.all(np.abs(ax[rows] - ref) <= 1e-13 * scale)
+
+
 def test_size_independent_properties_on_the_config4_state_set(ctx):
     """BASELINE config 4's generator (Goutsias, conserved DNA: M, D, RNA boxes x 6
     DNA configurations; here 60^3 x 6 = 1.3e6 states, the full 150^3 x 6 is
