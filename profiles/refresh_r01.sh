@@ -7,6 +7,9 @@ O=$R/gpurun_out
 mkdir -p $O/prof
 python bench.py > $O/bench_final.json 2> $O/bench_final.err
 python bench.py --force-comm --no-cpu > $O/bench_final_comm1.json 2> $O/bench_final_comm1.err
+python bench.py --workload c4 --no-expv > $O/bench_final_c4.json 2> $O/bench_final_c4.err
+python bench.py --workload c5s --no-expv --no-cpu > $O/bench_final_c5s.json 2> $O/bench_final_c5s.err
+python bench.py --workload c3x --no-expv --no-cpu > $O/bench_final_c3x.json 2> $O/bench_final_c3x.err
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o final -- python3 $R/bench.py --no-cpu > $O/bench_final_prof.json 2> $O/bench_final_prof.err
 cd $R
