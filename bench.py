@@ -90,6 +90,8 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    # the pool's host driver only supports dmabuf IPC: without this RCCL cannot share buffers across ranks
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
