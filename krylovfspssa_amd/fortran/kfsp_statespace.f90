@@ -65,7 +65,7 @@ MODULE STATESPACE
      PROCEDURE :: INDEX => INDEX_STATE
   END TYPE FINITE_STATE_PROJECTION
 
-  PRIVATE :: TICK, STATE_HASH, LOOKUP, PROBE, INSERT_RANGE, APPEND_CANDIDATES, CUSTOMPROP_IS_PURE, TABLE_INSERT, REBUILD_TABLE, LEGAL, RESERVE_TABLE, APPEND_STATE, &
+  PRIVATE :: SSA_STREAMS_REQUESTED, SSA_EXTENDER_STREAMS, STREAM_PATH, TICK, STATE_HASH, LOOKUP, PROBE, INSERT_RANGE, APPEND_CANDIDATES, CUSTOMPROP_IS_PURE, TABLE_INSERT, REBUILD_TABLE, LEGAL, RESERVE_TABLE, APPEND_STATE, &
        LINK_ONE, LINK_NEW, HOST_THREADS
 
   INTEGER(8), PARAMETER, PRIVATE :: LOW32 = 4294967295_8
@@ -87,7 +87,7 @@ MODULE STATESPACE
   ! 1-3 ONESTEP_EXTENDER scan / append / link, 4-5 SSA_EXTENDER walk / link,
   ! 6-9 DROP_STATES threshold+flags / compaction / renumbering / table
   DOUBLE PRECISION, SAVE :: STATESPACE_SEC(9) = 0.0D0
-  INTEGER, PRIVATE, SAVE :: NTHREADS_CACHED = 0, PARALLEL_MIN = -1
+  INTEGER, PRIVATE, SAVE :: NTHREADS_CACHED = 0, PARALLEL_MIN = -1, SSA_STREAMS_FLAG = -1
   INTEGER, PRIVATE, SAVE :: TOUCH_SINK = 0        ! keeps the early loads of SSA_EXTENDER alive
 
 CONTAINS
@@ -970,6 +970,10 @@ CONTAINS
     ! here instead, and the generator is set to where it would stand at the end.
     LOGICAL :: FAST
     INTEGER(8) :: RS, G1, G2
+    IF (SSA_STREAMS_REQUESTED()) THEN
+       CALL SSA_EXTENDER_STREAMS(TIMESTEP, FSP, MODEL)
+       RETURN
+    ENDIF
     SD = MODEL%NSPECIES
     PD = MODEL%NREACTIONS
     N0 = FSP%SIZE
@@ -1062,5 +1066,206 @@ CONTAINS
     CALL TICK(5, TCLK)
     TOUCH_SINK = TOUCH
   END SUBROUTINE SSA_EXTENDER
+
+  ! one path of SSA_EXTENDER_STREAMS: from listed state J0, on the stream of (SEEDMIX, J0);
+  ! unlisted states it passes through are appended to the caller's record list
+  SUBROUTINE STREAM_PATH(TIMESTEP, FSP, MODEL, NU, J0, SEEDMIX, RECX, RECJ, NREC, CAP)
+    DOUBLE PRECISION, INTENT(IN) :: TIMESTEP
+    TYPE(FINITE_STATE_PROJECTION), INTENT(IN) :: FSP
+    TYPE(CME_MODEL), INTENT(IN) :: MODEL
+    INTEGER, INTENT(IN) :: NU(:, :), J0
+    INTEGER(8), INTENT(IN) :: SEEDMIX
+    INTEGER, ALLOCATABLE, INTENT(INOUT) :: RECX(:, :), RECJ(:)
+    INTEGER, INTENT(INOUT) :: NREC, CAP
+    INTEGER :: SD, PD, J, K, S, IDX, X(MODEL%NSPECIES), Y(MODEL%NSPECIES)
+    INTEGER, ALLOCATABLE :: TMPX(:, :), TMPJ(:)
+    DOUBLE PRECISION :: TT, R1, R2, R2A, ACC, A0, PR(MODEL%NREACTIONS)
+    INTEGER(8) :: H, RS, G1, G2
+    LOGICAL :: NEG, VIRTUAL
+    SD = MODEL%NSPECIES
+    PD = MODEL%NREACTIONS
+    ! the path's own stream: a 64-bit mix of (call, seed state) folded into the generator's range
+    RS = IEOR(SEEDMIX * 2654435761_8, INT(J0, 8) * 40503_8 + 12345_8)
+    RS = IAND(IEOR(RS, ISHFT(RS, -29)), LOW32) * 1181783497_8
+    RS = 1_8 + MOD(IAND(IEOR(RS, ISHFT(RS, -32)), 9223372036854775807_8), LCG_M - 1_8)
+    J = J0
+    VIRTUAL = .FALSE.
+    X = FSP%STATE(1:SD, J)
+    TT = 0.0D0
+    DO
+       G1 = RS
+       RS = MOD(RS * LCG_A, LCG_M)
+       G2 = RS
+       RS = MOD(RS * LCG_A, LCG_M)
+       R1 = DBLE(ISHFT(IOR(ISHFT(G1, 30), IAND(G2 - 1_8, LCG_LOW)), -7)) * LCG_SCALE
+       G1 = RS
+       RS = MOD(RS * LCG_A, LCG_M)
+       G2 = RS
+       RS = MOD(RS * LCG_A, LCG_M)
+       R2 = DBLE(ISHFT(IOR(ISHFT(G1, 30), IAND(G2 - 1_8, LCG_LOW)), -7)) * LCG_SCALE
+       IF (R1 <= 0.0D0) R1 = LCG_SCALE
+       IF (VIRTUAL) THEN
+          A0 = 0.0D0
+          DO K = 1, PD
+             PR(K) = MODEL%PROPENSITY(X, K)
+             A0 = A0 + PR(K)
+          ENDDO
+       ELSE
+          A0 = FSP%MATRIX%DIAG(J)
+          PR = FSP%MATRIX%OFFDIAG(1:PD, J)
+       ENDIF
+       IF (.NOT. (A0 > 0.0D0)) EXIT                 ! absorbing state
+       TT = MIN(TIMESTEP, TT + (-LOG(R1) / A0))
+       ACC = PR(1)
+       K = 1
+       R2A = MIN(R2 * A0, A0)
+       DO WHILE (ACC < R2A .AND. K < PD)
+          K = K + 1
+          ACC = ACC + PR(K)
+       ENDDO
+       NEG = .FALSE.
+       DO S = 1, SD
+          Y(S) = X(S) + NU(S, K)
+          NEG = NEG .OR. Y(S) < 0
+       ENDDO
+       IF (NEG) EXIT
+       IDX = 0
+       IF (.NOT. VIRTUAL) IDX = MAX(FSP%MATRIX%ADJ(K, J), 0)
+       IF (IDX == 0) THEN
+          IF (.NOT. LEGAL(Y)) EXIT
+          CALL LOOKUP(FSP, Y, IDX, H)
+       ENDIF
+       X = Y
+       IF (IDX > 0) THEN
+          J = IDX
+          VIRTUAL = .FALSE.
+          IF (J < J0) EXIT                          ! fell back onto an earlier seed
+       ELSE
+          VIRTUAL = .TRUE.
+          IF (NREC == CAP) THEN
+             ALLOCATE(TMPX(SD, 2 * CAP), TMPJ(2 * CAP))
+             TMPX(:, 1:CAP) = RECX
+             TMPJ(1:CAP) = RECJ
+             CALL MOVE_ALLOC(TMPX, RECX)
+             CALL MOVE_ALLOC(TMPJ, RECJ)
+             CAP = 2 * CAP
+          ENDIF
+          NREC = NREC + 1
+          RECX(:, NREC) = Y
+          RECJ(NREC) = J0
+       ENDIF
+       IF (.NOT. (TT < TIMESTEP)) EXIT
+    ENDDO
+  END SUBROUTINE STREAM_PATH
+
+  ! KFSP_SSA_STREAMS=1: every path gets a random stream of its own (below)
+  LOGICAL FUNCTION SSA_STREAMS_REQUESTED()
+    CHARACTER(LEN=8) :: BUF
+    INTEGER :: L, ST
+    IF (SSA_STREAMS_FLAG < 0) THEN
+       SSA_STREAMS_FLAG = 0
+       CALL GET_ENVIRONMENT_VARIABLE('KFSP_SSA_STREAMS', BUF, L, ST)
+       IF (ST == 0 .AND. L > 0) THEN
+          IF (BUF(1:1) == '1') SSA_STREAMS_FLAG = 1
+       ENDIF
+    ENDIF
+    SSA_STREAMS_REQUESTED = SSA_STREAMS_FLAG == 1
+  END FUNCTION SSA_STREAMS_REQUESTED
+
+  ! OPT-IN VARIANT, NOT the reference's sampling order (KFSP_SSA_STREAMS=1).
+  ! The reference's paths share one random stream and each sees the states the
+  ! earlier ones added, which makes the walk - two thirds of a large adaptive run -
+  ! strictly sequential.  Here every path draws from a stream of its own (seeded
+  ! from one number of RANDOM_NUMBER per call and the index of its seed state),
+  ! walks the FSP as it stood when the call began, and continues through unlisted
+  ! states by evaluating their propensities on the fly; the paths are independent
+  ! and run on the thread team.  The states they met are then appended in path
+  ! order (duplicates once) and linked.  The result is a valid expansion in the
+  ! sense of the algorithm (any superset serves; the FSP criterion decides), it is
+  ! the same for every number of threads, but states are found in another order
+  ! than the reference finds them, so indices and later random numbers differ.
+  ! A CUSTOMPROP function is called from the team only if declared free of side
+  ! effects (KFSP_HOST_PARALLEL_PROPENSITY=1); otherwise one thread does all paths.
+  SUBROUTINE SSA_EXTENDER_STREAMS(TIMESTEP, FSP, MODEL)
+    DOUBLE PRECISION :: TIMESTEP
+    TYPE(FINITE_STATE_PROJECTION) :: FSP
+    TYPE(CME_MODEL), INTENT(IN) :: MODEL
+    INTEGER :: SD, PD, N0, NT, NTH, TID, J0, IDX, NREC, CAP, T, I
+    INTEGER :: NU(MODEL%NSPECIES, MODEL%NREACTIONS), Y(MODEL%NSPECIES)
+    INTEGER, ALLOCATABLE :: RECX(:, :), RECJ(:)
+    ! the records of all threads, concatenated after the walk
+    INTEGER, ALLOCATABLE :: ALLX(:, :), ALLJ(:), CNT(:), OFS(:), HEAD(:), ORDER(:)
+    DOUBLE PRECISION :: BASE
+    INTEGER(8) :: H, SEEDMIX, TCLK
+    SD = MODEL%NSPECIES
+    PD = MODEL%NREACTIONS
+    N0 = FSP%SIZE
+    NU = MODEL%STOICHIOMETRY(1:SD, 1:PD)
+    CALL TICK(0, TCLK)
+    CALL RANDOM_NUMBER(BASE)
+    SEEDMIX = INT(BASE * 2147483647.0D0, 8)
+    NT = HOST_THREADS(N0, 1024)
+    IF (ASSOCIATED(MODEL%CUSTOMPROP) .AND. .NOT. CUSTOMPROP_IS_PURE()) NT = 1
+    ALLOCATE(CNT(0:NT), OFS(0:NT))
+    CNT = 0
+    NTH = 1
+    !$OMP PARALLEL NUM_THREADS(NT) IF(NT > 1) PRIVATE(TID, J0, NREC, CAP, RECX, RECJ)
+    TID = 0
+    !$ TID = OMP_GET_THREAD_NUM()
+    !$OMP SINGLE
+    !$ NTH = OMP_GET_NUM_THREADS()
+    !$OMP END SINGLE
+    CAP = 1024
+    ALLOCATE(RECX(SD, CAP), RECJ(CAP))
+    NREC = 0
+    !$OMP DO SCHEDULE(DYNAMIC, 256)
+    DO J0 = 1, N0
+       CALL STREAM_PATH(TIMESTEP, FSP, MODEL, NU, J0, SEEDMIX, RECX, RECJ, NREC, CAP)
+    ENDDO
+    !$OMP END DO
+    CNT(TID + 1) = NREC
+    !$OMP BARRIER
+    !$OMP SINGLE
+    OFS(0) = 0
+    DO T = 1, NTH
+       OFS(T) = OFS(T - 1) + CNT(T)
+    ENDDO
+    ALLOCATE(ALLX(SD, MAX(OFS(NTH), 1)), ALLJ(MAX(OFS(NTH), 1)))
+    !$OMP END SINGLE
+    IF (NREC > 0) THEN
+       ALLX(:, OFS(TID) + 1:OFS(TID) + NREC) = RECX(:, 1:NREC)
+       ALLJ(OFS(TID) + 1:OFS(TID) + NREC) = RECJ(1:NREC)
+    ENDIF
+    DEALLOCATE(RECX, RECJ)
+    !$OMP END PARALLEL
+    CALL TICK(4, TCLK)
+
+    ! append in path order (seed state, then order along the path), first occurrence of a
+    ! state wins.  A path's records sit together in one thread's list, but which thread
+    ! walked which path depends on the schedule: a counting sort by seed state restores an
+    ! order that does not.
+    ALLOCATE(HEAD(N0 + 1))
+    HEAD = 0
+    DO I = 1, OFS(NTH)
+       HEAD(ALLJ(I) + 1) = HEAD(ALLJ(I) + 1) + 1
+    ENDDO
+    HEAD(1) = 1
+    DO J0 = 2, N0 + 1
+       HEAD(J0) = HEAD(J0) + HEAD(J0 - 1)          ! HEAD(j) = first position of path j's records
+    ENDDO
+    ALLOCATE(ORDER(MAX(OFS(NTH), 1)))
+    DO I = 1, OFS(NTH)
+       ORDER(HEAD(ALLJ(I))) = I
+       HEAD(ALLJ(I)) = HEAD(ALLJ(I)) + 1
+    ENDDO
+    DO I = 1, OFS(NTH)
+       Y = ALLX(:, ORDER(I))
+       IF (FSP%SIZE >= FSP%MAX_SIZE) EXIT
+       CALL LOOKUP(FSP, Y, IDX, H)
+       IF (IDX == 0) CALL APPEND_STATE(FSP, MODEL, Y, H)
+    ENDDO
+    IF (FSP%SIZE > N0) CALL LINK_NEW(FSP, MODEL, N0 + 1, FSP%SIZE, .TRUE.)
+    CALL TICK(5, TCLK)
+  END SUBROUTINE SSA_EXTENDER_STREAMS
 
 END MODULE STATESPACE

@@ -71,6 +71,43 @@ def test_ssa_and_onestep_growth_is_bit_exact(dump, tmp_path, name, k, dt, thread
     assert d["vector"][0] == float(g["next_uniform"])
 
 
+@pytest.mark.parametrize("name,k,dt", MG.SSA_CASES)
+def test_independent_stream_ssa_is_a_consistent_expansion(dump, tmp_path, name, k, dt):
+    """KFSP_SSA_STREAMS=1 (opt-in, NOT the reference's sampling order): every path on
+    its own random stream, walked by the thread team.  The result must not depend
+    on the number of threads, must contain the seed, list no state twice, and carry
+    exactly the links of the listed states (StateSpace.f90:204-244 invariants)."""
+    outs = []
+    for threads in (1, 4):
+        p = str(tmp_path / f"s{threads}.bin")
+        _run(dump, ["ssa", name, str(k), repr(dt), p], tmp_path,
+             env=dict(_threads_env(threads), KFSP_SSA_STREAMS="1"))
+        outs.append(MG.read_fsp(p))
+    a, b = outs
+    assert a["n"] == b["n"]
+    for key in ("state", "adj", "offdiag", "diag"):
+        assert np.array_equal(a[key], b[key]), key
+    g = np.load(os.path.join(GOLDEN, MG.ssa_fixture_name(name, k, dt)))
+    assert not np.array_equal(a["state"][:min(a["n"], int(g["n"]))], g["state"][:min(a["n"], int(g["n"]))])
+    index = {tuple(s): i + 1 for i, s in enumerate(a["state"].tolist())}
+    assert len(index) == a["n"] and tuple(g["state"][0].tolist()) == tuple(a["state"][0].tolist())
+    asm = np.load(os.path.join(GOLDEN, f"assembly_{name}_k5.npz"))
+    # stoichiometry from the reference's own assembly: successor = state + (state_j - state_i) of a linked pair
+    nr = a["adj"].shape[1]
+    nu = [None] * nr
+    for i, row in enumerate(asm["adj"]):
+        for r, j in enumerate(row):
+            if j > 0 and nu[r] is None:
+                nu[r] = asm["state"][j - 1] - asm["state"][i]
+    assert all(v is not None for v in nu)
+    for i, x in enumerate(a["state"]):
+        for r in range(nr):
+            y = x + nu[r]
+            expect = -1 if (y < 0).any() else index.get(tuple(y.tolist()), 0)
+            assert a["adj"][i, r] == expect, (i, r)
+    assert np.allclose(a["diag"], a["offdiag"].sum(axis=1), rtol=1e-15, atol=0)
+
+
 @pytest.mark.parametrize("threads", [1, 4])
 @pytest.mark.parametrize("name,k,dsum", MG.DROP_CASES)
 def test_drop_states_is_bit_exact(dump, tmp_path, name, k, dsum, threads):
@@ -174,6 +211,24 @@ def test_cme_solve_with_internal_state_order(dump, tmp_path, fixture, case):
     assert np.array_equal(d["state"], g["state"]) and np.array_equal(d["adj"], g["adj"])
     assert np.abs(log["wsum"] - g["wsum"]).max() < 1e-10
     assert np.abs(d["vector"] - g["vector"]).sum() < 1e-10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fixture,case", [("toggle_input", "toggle_input"), ("goutsias_input_T40", "goutsias_input"),
+                                          ("repressilator_input_T1", "repressilator_input")])
+def test_cme_solve_with_independent_stream_ssa(dump, tmp_path, fixture, case):
+    """The adaptive solver on FSPs grown by the opt-in independent-stream SSA: other
+    states are sampled than the reference samples, the solution is the same within
+    the FSP tolerance (probabilities compared state by state)."""
+    g, d, log = _solve(dump, tmp_path, fixture, case, env={"KFSP_SSA_STREAMS": "1", "KFSP_HOST_THREADS": "4",
+                                                            "KFSP_HOST_PARALLEL_MIN": "1"})
+    ref = {tuple(s): v for s, v in zip(g["state"].tolist(), g["vector"].tolist())}
+    got = {tuple(s): v for s, v in zip(d["state"].tolist(), d["vector"].tolist())}
+    l1 = sum(abs(ref.get(k, 0.0) - got.get(k, 0.0)) for k in set(ref) | set(got))
+    print(f"{fixture}: N={d['n']} (ref {int(g['n'])}) l1={l1:.3e} sum={d['vector'].sum():.16f}")
+    assert l1 < float(g["fsptol"])
+    assert 1.0 - d["vector"].sum() < float(g["fsptol"])
+    assert np.all(d["vector"] >= 0)
 
 
 @pytest.mark.gpu
