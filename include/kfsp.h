@@ -81,7 +81,8 @@ int kfsp_set_matrix_ell(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld,
  * next kfsp_set_matrix_ell with the same n only, and not below option
  * state_order_min states, with a communicator, or while generators are
  * short-lived (the one being replaced saw fewer than option
- * state_order_products products: reordering costs about 130 of them). */
+ * state_order_products products: reordering costs about 20 of them at 10^6
+ * states). */
 int kfsp_set_state_coords(kfsp_ctx *ctx, int32_t n, int32_t ns, int32_t ld, const int32_t *state);
 /* 1 if the generator last set is held in the internal state order */
 int kfsp_state_order_active(const kfsp_ctx *ctx, int *active);
@@ -222,7 +223,7 @@ int kfsp_add_timer(kfsp_ctx *ctx, int phase, double ms);
  * "host_build", "halo", "overlap", "small_kernel", "state_order" (1: use
  * kfsp_set_state_coords; default 0), "state_order_min" (smallest generator that is
  * reordered, default 32768), "state_order_products" (products the previous
- * generator must have seen, default 128) ... see DESIGN.md */
+ * generator must have seen, default 48) ... see DESIGN.md */
 int kfsp_set_option(kfsp_ctx *ctx, const char *name, int64_t value);
 
 #ifdef __cplusplus

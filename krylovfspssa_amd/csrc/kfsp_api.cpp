@@ -829,7 +829,7 @@ int kfsp_set_state_coords(kfsp_ctx *ctx, int32_t n, int32_t ns, int32_t ld, cons
         if (!state) return fail(ctx, -5, "null state");
         ctx->perm_pending_n = 0;
         if (!ctx->opt_state_order || n < ctx->opt_state_order_min || ctx->use_comm) return 0;
-        // Sorting, relabelling and the extra upload cost about as much as 130 products
+        // Sorting, relabelling and the extra upload cost about as much as 20 products (at 10^6 states)
         // save: worth it only while generators live that long.  The generator being
         // replaced is the best predictor there is.
         if (ctx->prod_count < ctx->opt_state_order_products) return 0;

@@ -46,35 +46,58 @@ __device__ __forceinline__ int wave_max_i(int v)
     return v;
 }
 
-// one lane per source state: link statistics per slot + in-degree of local rows
+// one lane per source state (grid-stride): link statistics per slot + in-degree of
+// local rows.  The per-slot statistics are combined in LDS first: a global atomic
+// per wavefront and slot on the same forty addresses costs 1.7 ms at 10^6 states.
 __global__ __launch_bounds__(kBlock) void k_ell_scan(int64_t n, int bw, int ld, const int32_t *__restrict__ adj,
                                                      int64_t row0, int64_t nloc, int32_t *__restrict__ cnt,
                                                      ScanOut *__restrict__ out)
 {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    const bool live = i < n;
-    for (int j = 0; j < bw; ++j) {
-        const int k = live ? adj[i * ld + j] : 0;
-        if (k > n) out->bad = 1;
-        const bool valid = k >= 1 && k <= n;
-        const int64_t r = (int64_t)k - 1 - row0;
-        const bool local = valid && r >= 0 && r < nloc;
-        if (local) atomicAdd(&cnt[r], 1);
-        const int d = (int)((int64_t)k - 1 - i);
-        const int lo = wave_min_i(valid ? d : INT_MAX);
-        const int hi = wave_max_i(valid ? d : INT_MIN);
-        const unsigned long long m = __ballot(local);
-        if ((threadIdx.x & 63) == 0) {
-            if (lo != INT_MAX) {
-                atomicMin(&out->dmin[j], lo);
-                atomicMax(&out->dmax[j], hi);
-            }
-            if (m) {
-                atomicAdd(&out->dcount[j], (unsigned long long)__popcll(m));
-                atomicAdd(&out->nnz_off, (unsigned long long)__popcll(m));
+    __shared__ int smin[kMaxBw], smax[kMaxBw];
+    __shared__ unsigned int scnt[kMaxBw];
+    __shared__ int sbad;
+    for (int j = threadIdx.x; j < kMaxBw; j += kBlock) {
+        smin[j] = INT_MAX;
+        smax[j] = INT_MIN;
+        scnt[j] = 0;
+    }
+    if (threadIdx.x == 0) sbad = 0;
+    __syncthreads();
+    for (int64_t base = (int64_t)blockIdx.x * kBlock; base < n; base += (int64_t)gridDim.x * kBlock) {
+        const int64_t i = base + threadIdx.x;
+        const bool live = i < n;
+        for (int j = 0; j < bw; ++j) {
+            const int k = live ? adj[i * ld + j] : 0;
+            if (k > n) sbad = 1;
+            const bool valid = k >= 1 && k <= n;
+            const int64_t r = (int64_t)k - 1 - row0;
+            const bool local = valid && r >= 0 && r < nloc;
+            if (local) atomicAdd(&cnt[r], 1);
+            const int d = (int)((int64_t)k - 1 - i);
+            const int lo = wave_min_i(valid ? d : INT_MAX);
+            const int hi = wave_max_i(valid ? d : INT_MIN);
+            const unsigned long long m = __ballot(local);
+            if ((threadIdx.x & 63) == 0) {
+                if (lo != INT_MAX) {
+                    atomicMin(&smin[j], lo);
+                    atomicMax(&smax[j], hi);
+                }
+                if (m) atomicAdd(&scnt[j], (unsigned int)__popcll(m));
             }
         }
     }
+    __syncthreads();
+    for (int j = threadIdx.x; j < bw; j += kBlock) {
+        if (smin[j] != INT_MAX) {
+            atomicMin(&out->dmin[j], smin[j]);
+            atomicMax(&out->dmax[j], smax[j]);
+        }
+        if (scnt[j]) {
+            atomicAdd(&out->dcount[j], (unsigned long long)scnt[j]);
+            atomicAdd(&out->nnz_off, (unsigned long long)scnt[j]);
+        }
+    }
+    if (threadIdx.x == 0 && sbad) out->bad = 1;
 }
 
 // ---- internal state order ------------------------------------------------------
@@ -87,34 +110,49 @@ __global__ __launch_bounds__(kBlock) void k_ell_relabel(int64_t n, int bw, int l
                                                         const double *__restrict__ diag, int32_t *__restrict__ adj2,
                                                         double *__restrict__ off2, double *__restrict__ diag2)
 {
-    const int64_t i2 = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i2 >= n) return;
+    // one lane per (state, slot): the ld slots of a state are read by neighbouring lanes
+    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= n * ld) return;
+    const int64_t i2 = t / ld;
+    const int j = (int)(t - i2 * ld);
     const int64_t i = perm[i2];
-    diag2[i2] = diag[i];
-    for (int j = 0; j < bw; ++j) {
+    if (j == 0) diag2[i2] = diag[i];
+    if (j < bw) {
         const int k = adj[i * ld + j];
-        adj2[i2 * ld + j] = (k >= 1 && k <= n) ? iperm[k - 1] + 1 : k;
-        off2[i2 * ld + j] = off[i * ld + j];
-    }
-    for (int j = bw; j < ld; ++j) {
-        adj2[i2 * ld + j] = 0;
-        off2[i2 * ld + j] = 0.0;
+        adj2[t] = (k >= 1 && k <= n) ? iperm[k - 1] + 1 : k;
+        off2[t] = off[i * ld + j];
+    } else {
+        adj2[t] = 0;
+        off2[t] = 0.0;
     }
 }
 
-// smallest and largest count of every species (mm[2k], mm[2k+1])
+// smallest and largest count of every species (mm[2k], mm[2k+1]); grid-stride,
+// combined per workgroup in LDS before the global atomics
 __global__ __launch_bounds__(kBlock) void k_coord_minmax(int64_t n, int ns, int ld, const int32_t *__restrict__ state,
                                                          int *__restrict__ mm)
 {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    __shared__ int smm[32];
+    if (threadIdx.x < 32) smm[threadIdx.x] = (threadIdx.x & 1) ? INT_MIN : INT_MAX;
+    __syncthreads();
     for (int k = 0; k < ns; ++k) {
-        const int v = i < n ? state[i * ld + k] : 0;
-        const int lo = wave_min_i(i < n ? v : INT_MAX);
-        const int hi = wave_max_i(i < n ? v : INT_MIN);
-        if ((threadIdx.x & 63) == 0 && lo != INT_MAX) {
-            atomicMin(&mm[2 * k], lo);
-            atomicMax(&mm[2 * k + 1], hi);
+        int lo = INT_MAX, hi = INT_MIN;
+        for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+            const int v = state[i * ld + k];
+            lo = v < lo ? v : lo;
+            hi = v > hi ? v : hi;
         }
+        lo = wave_min_i(lo);
+        hi = wave_max_i(hi);
+        if ((threadIdx.x & 63) == 0 && lo != INT_MAX) {
+            atomicMin(&smm[2 * k], lo);
+            atomicMax(&smm[2 * k + 1], hi);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * ns) {
+        if (threadIdx.x & 1) atomicMax(&mm[threadIdx.x], smm[threadIdx.x]);
+        else if (smm[threadIdx.x] != INT_MAX) atomicMin(&mm[threadIdx.x], smm[threadIdx.x]);
     }
 }
 
@@ -343,7 +381,7 @@ int build_from_ell_device(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, cons
         HIP_TRY_B(ctx->d_ell_adj2.reserve(nent, false));
         HIP_TRY_B(ctx->d_ell_off2.reserve(nent, false));
         HIP_TRY_B(ctx->d_ell_diag2.reserve((size_t)n, false));
-        hipLaunchKernelGGL(k_ell_relabel, dim3((int)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, (int64_t)n,
+        hipLaunchKernelGGL(k_ell_relabel, dim3((int)(((int64_t)n * ld + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, (int64_t)n,
                            (int)bw, (int)ld, ctx->d_perm.p, ctx->d_iperm.p, ctx->d_ell_adj.p, ctx->d_ell_off.p,
                            ctx->d_ell_diag.p, ctx->d_ell_adj2.p, ctx->d_ell_off2.p, ctx->d_ell_diag2.p);
         ell_adj = ctx->d_ell_adj2.p;
@@ -365,7 +403,7 @@ int build_from_ell_device(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, cons
     HIP_TRY_B(hipMemcpyAsync(ctx->d_scan.p, &init, sizeof(init), hipMemcpyHostToDevice, st));
     ScanOut *dscan = reinterpret_cast<ScanOut *>(ctx->d_scan.p);
     const int gsrc = (int)((n + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(k_ell_scan, dim3(gsrc), dim3(kBlock), 0, st, (int64_t)n, (int)bw, (int)ld, ell_adj,
+    hipLaunchKernelGGL(k_ell_scan, dim3(std::min(gsrc, 1024)), dim3(kBlock), 0, st, (int64_t)n, (int)bw, (int)ld, ell_adj,
                        row0, nloc, ctx->d_cnt.p, dscan);
     ScanOut res;
     HIP_TRY_B(hipMemcpyAsync(&res, dscan, sizeof(res), hipMemcpyDeviceToHost, st));
@@ -499,8 +537,8 @@ int state_order_from_coords(kfsp_ctx *ctx, int32_t n, int32_t ns, int32_t ld, co
     int *dmm = reinterpret_cast<int *>(ctx->d_coords.p + nent);
     HIP_TRY_B(hipMemcpyAsync(dmm, mm, sizeof(int) * 2 * (size_t)ns, hipMemcpyHostToDevice, st));
     const int grid = (int)(((int64_t)n + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(k_coord_minmax, dim3(grid), dim3(kBlock), 0, st, (int64_t)n, (int)ns, (int)ld, ctx->d_coords.p,
-                       dmm);
+    hipLaunchKernelGGL(k_coord_minmax, dim3(std::min(grid, 1024)), dim3(kBlock), 0, st, (int64_t)n, (int)ns, (int)ld,
+                       ctx->d_coords.p, dmm);
     HIP_TRY_B(hipMemcpyAsync(mm, dmm, sizeof(int) * 2 * (size_t)ns, hipMemcpyDeviceToHost, st));
     HIP_TRY_B(hipStreamSynchronize(st));
     KeyLayout L;

@@ -151,7 +151,7 @@ struct kfsp_ctx {
     int64_t opt_dia_mask = 1;             // 0: never skip empty diagonal segments
     int64_t opt_state_order = 0;          // 1: use kfsp_set_state_coords (off: sums stay in the reference's order)
     int64_t opt_state_order_min = 32768;  // smallest generator that is reordered
-    int64_t opt_state_order_products = 128;  // ... and only if its predecessor saw this many products
+    int64_t opt_state_order_products = 48;   // ... and only if its predecessor saw this many products
     double t_ms[KFSP_T_COUNT] = {0, 0, 0, 0, 0, 0};
 };
 

@@ -153,7 +153,7 @@ CONTAINS
     ! KFSP_STATE_ORDER=1 lets the device keep large, long-lived FSPs in its own state
     ! order (off by default: it changes the order of the sums); KFSP_STATE_ORDER_MIN:
     ! smallest FSP that is reordered (library default 32768), KFSP_STATE_ORDER_PRODUCTS:
-    ! products the previous generator must have seen (default 128)
+    ! products the previous generator must have seen (default 48)
     CALL GET_ENVIRONMENT_VARIABLE('KFSP_STATE_ORDER_MIN', ENV, L, STAT)
     IF (STAT == 0 .AND. L > 0) THEN
        READ(ENV(1:L), *, IOSTAT=STAT) V8
