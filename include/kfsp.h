@@ -220,7 +220,7 @@ int kfsp_add_timer(kfsp_ctx *ctx, int phase, double ms);
 
 /* tuning knobs (name/value); unknown name -> -2: "grid_blocks",
  * "vec_grid_blocks", "nt_loads", "build_csr", "format", "fused_ortho",
- * "host_build", "halo", "overlap", "small_kernel", "state_order" (1: use
+ * "host_build", "halo", "overlap", "small_kernel", "small_lds", "dia_mask", "state_order" (1: use
  * kfsp_set_state_coords; default 0), "state_order_min" (smallest generator that is
  * reordered, default 32768), "state_order_products" (products the previous
  * generator must have seen, default 48) ... see DESIGN.md */

@@ -556,6 +556,11 @@ int init_context(kfsp_ctx *ctx)
     HIP_TRY(ctx->d_y.reserve(kMH, true));
     HIP_TRY(ctx->d_flag.reserve(4, true));
     HIP_TRY(ctx->d_zero.reserve(128, true));
+    {
+        int v = 0;
+        HIP_TRY(hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, ctx->device));
+        ctx->lds_per_block = v;
+    }
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_H), ((size_t)kMH * kMH + 2) * sizeof(double), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_pin), (size_t)(kMH + 8) * sizeof(double), hipHostMallocDefault));
     std::memset(ctx->h_H, 0, ((size_t)kMH * kMH + 2) * sizeof(double));
@@ -958,7 +963,9 @@ int kfsp_arnoldi(kfsp_ctx *ctx, int m, int jold, int qiop, double break_tol, dou
         sa.Hd = Hd;
         sa.break_tol = break_tol;
         sa.brk_flag = flag;
-        launch_arnoldi_small(sa, ctx->use_dia, st);
+        sa.slots = ctx->use_dia ? 0 : ctx->slots;
+        if (const int e = launch_arnoldi_small(sa, ctx->use_dia, ctx->opt_small_lds ? ctx->lds_per_block : 0, st))
+            return hip_fail(ctx, (hipError_t)e, "hipFuncSetAttribute(k_arnoldi_small)");
     }
     Pending pend_sq{sq + jold, 1};
     Pending pend_g{gfin + jold, 1};      // u_jold . u_{jold-1}, finished by the pass that built column jold
@@ -1327,6 +1334,7 @@ int kfsp_set_option(kfsp_ctx *ctx, const char *name, int64_t value)
     else if (k == "fused_ortho") ctx->opt_fused = value;
     else if (k == "host_build") ctx->opt_host_build = value;
     else if (k == "dia_mask") ctx->opt_dia_mask = value;
+    else if (k == "small_lds") ctx->opt_small_lds = value;
     else if (k == "state_order") ctx->opt_state_order = value;
     else if (k == "state_order_min") ctx->opt_state_order_min = value;
     else if (k == "state_order_products") ctx->opt_state_order_products = value;

@@ -148,6 +148,8 @@ struct kfsp_ctx {
     int64_t opt_small = 1;        // 1: one-launch Arnoldi pass for <= 16384 rows
     int64_t opt_overlap = 1;      // 0: exchange and product strictly one after the other
     int64_t opt_host_build = 0;   // 1: transpose reference-layout input on the host (A/B testing)
+    int64_t opt_small_lds = 1;            // 0: the one-launch Arnoldi kernel reads the generator from global memory
+    int64_t lds_per_block = 65536;        // device limit (hipDeviceAttributeMaxSharedMemoryPerBlock)
     int64_t opt_dia_mask = 1;             // 0: never skip empty diagonal segments
     int64_t opt_state_order = 0;          // 1: use kfsp_set_state_coords (off: sums stay in the reference's order)
     int64_t opt_state_order_min = 32768;  // smallest generator that is reordered

@@ -154,8 +154,10 @@ struct SmallArnoldiArgs {
     double *Hd;           // kMH x kMH image + avnorm^2, avnorm behind it
     double break_tol;
     int *brk_flag;
+    int64_t slots;        // stored SELL slots (the generator goes to LDS when they fit beside the source column)
 };
-void launch_arnoldi_small(const SmallArnoldiArgs &a, bool dia, hipStream_t s);
+// lds_limit: bytes of LDS one workgroup may use; returns a hipError_t
+int launch_arnoldi_small(const SmallArnoldiArgs &a, bool dia, int64_t lds_limit, hipStream_t s);
 
 // kernel launchers (kfsp_kernels.hip)
 // fmt: 0 SELL-64, 1 banded, 2 banded with group masks

@@ -483,22 +483,24 @@ void launch_ortho2(int grid, const Ortho2Args &a, hipStream_t st)
 constexpr int kSmallBlock = 1024;
 constexpr int kSmallTrips = kSmallRows / kSmallBlock;      // rows per lane
 
-__device__ __forceinline__ void small_reduce2(double &a, double &b, double *red)
+// Two block sums with ONE barrier: the caller alternates between the two halves of
+// red (64 doubles), so a half is rewritten only after another barrier has separated
+// the writers from the last readers.
+__device__ __forceinline__ void small_reduce2(double &a, double &b, double *red_half)
 {
     a = wave_allreduce_sum(a);
     b = wave_allreduce_sum(b);
     const int wave = threadIdx.x >> 6;
-    __syncthreads();                                   // red free to be overwritten
     if ((threadIdx.x & 63) == 0) {
-        red[wave] = a;
-        red[16 + wave] = b;
+        red_half[wave] = a;
+        red_half[16 + wave] = b;
     }
     __syncthreads();
     double sa = 0.0, sb = 0.0;
 #pragma unroll
     for (int w = 0; w < kSmallBlock / 64; ++w) {
-        sa += red[w];
-        sb += red[16 + w];
+        sa += red_half[w];
+        sb += red_half[16 + w];
     }
     a = sa;
     b = sb;
@@ -545,20 +547,57 @@ __device__ __forceinline__ double row_sell_pre(const SellDev &A, const double *x
     return sum;
 }
 
-template <bool DIA>
-__device__ __forceinline__ double small_product_row(const SmallArnoldiArgs &a, const double *xs, int64_t r,
-                                                    int64_t off, int w)
+// the same with the chunk's slots copied to LDS (values, and columns as 16-bit numbers:
+// there are at most 4096 rows)
+__device__ __forceinline__ double row_sell_lds(const double *vs, const unsigned short *cs, const double *diag,
+                                               const double *xs, int64_t r, int64_t off, int w)
 {
-    if (DIA) return row_dia1(a.D, xs, r);
+    const int lane = (int)(r & 63);
+    const unsigned short *cp = cs + off + lane;
+    const double *vp = vs + off + lane;
+    double sum = -diag[r] * xs[r];
+    int k = 0;
+    for (; k + 4 <= w; k += 4) {
+        const int c0 = cp[(k + 0) * 64], c1 = cp[(k + 1) * 64], c2 = cp[(k + 2) * 64], c3 = cp[(k + 3) * 64];
+        const double v0 = vp[(k + 0) * 64], v1 = vp[(k + 1) * 64], v2 = vp[(k + 2) * 64], v3 = vp[(k + 3) * 64];
+        sum += v0 * xs[c0];
+        sum += v1 * xs[c1];
+        sum += v2 * xs[c2];
+        sum += v3 * xs[c3];
+    }
+    for (; k < w; ++k) sum += vp[k * 64] * xs[cp[k * 64]];
+    return sum;
+}
+
+// FMT: 0 SELL from global memory, 1 banded, 2 SELL from LDS
+template <int FMT>
+__device__ __forceinline__ double small_product_row(const SmallArnoldiArgs &a, const double *xs, const double *vs,
+                                                    const unsigned short *cs, int64_t r, int64_t off, int w)
+{
+    if (FMT == 1) return row_dia1(a.D, xs, r);
+    if (FMT == 2) return row_sell_lds(vs, cs, a.A.diag, xs, r, off, w);
     return row_sell_pre(a.A, xs, r, off, w);
 }
 
-template <bool DIA>
+template <int FMT>
 __global__ __launch_bounds__(kSmallBlock) void k_arnoldi_small(SmallArnoldiArgs a)
 {
-    __shared__ double xs[kSmallRows];                  // the source column u_j
-    __shared__ double red[32];
+    constexpr bool DIA = FMT == 1;
+    // dynamic LDS: the source column u_j [nact doubles]; FMT 2 also the generator's slots
+    // [slots doubles | slots 16-bit columns]
+    extern __shared__ double dyn_lds[];
+    double *xs = dyn_lds;
+    double *vs = dyn_lds + a.nact;
+    unsigned short *cs = reinterpret_cast<unsigned short *>(vs + (FMT == 2 ? a.slots : 0));
+    __shared__ double red[64];
+    int rb = 0;                                        // which half of red the next reduction uses
     const int tid = threadIdx.x;
+    if (FMT == 2) {
+        for (int64_t i = tid; i < a.slots; i += kSmallBlock) {
+            vs[i] = a.A.val[i];
+            cs[i] = (unsigned short)a.A.col[i];
+        }
+    }
     double *Hd = a.Hd;
     double S = a.sq[a.jold];          // squared norm of the column about to be multiplied
     double g = a.gfin[a.jold];        // u_jold . u_{jold-1}
@@ -581,8 +620,16 @@ __global__ __launch_bounds__(kSmallBlock) void k_arnoldi_small(SmallArnoldiArgs 
     }
     __syncthreads();
     bool broke = false;
+    // u_{j-1} on this lane's rows: read once for the first column, then carried over (it is
+    // the source column of the previous iteration)
+    double v1[kSmallTrips];
+#pragma unroll
+    for (int t = 0; t < kSmallTrips; ++t) {
+        const int64_t r = small_row<DIA>(t);
+        v1[t] = (a.jold >= 2 && r < a.nact) ? a.V[(size_t)(a.jold - 2) * a.ldv + r] : 0.0;
+    }
     for (int j = a.jold; j <= a.m; ++j) {
-        const double *u1 = j >= 2 ? a.V + (size_t)(j - 2) * a.ldv : nullptr;
+        const bool u1 = j >= 2;
         double *dst = a.V + (size_t)j * a.ldv;
         const double nrm = sqrt(S);
         if (tid == 0) {
@@ -594,21 +641,20 @@ __global__ __launch_bounds__(kSmallBlock) void k_arnoldi_small(SmallArnoldiArgs 
             break;
         }
         const double s2 = 1.0 / nrm;
-        double y[kSmallTrips], v1[kSmallTrips];
+        double y[kSmallTrips];
         double pa = 0.0, pb = 0.0;
 #pragma unroll
         for (int t = 0; t < kSmallTrips; ++t) {
             const int64_t r = small_row<DIA>(t);
             y[t] = 0.0;
-            v1[t] = 0.0;
             if (r < a.nact) {
-                if (u1) v1[t] = u1[r];
-                y[t] = s2 * small_product_row<DIA>(a, xs, r, offs[t], wid[t]);
+                y[t] = s2 * small_product_row<FMT>(a, xs, vs, cs, r, offs[t], wid[t]);
                 pa += v1[t] * y[t];
                 pb += xs[r] * y[t];
             }
         }
-        small_reduce2(pa, pb, red);
+        small_reduce2(pa, pb, red + rb);                // (also: every lane is past its gathers from xs)
+        rb ^= 32;
         double c1 = 0.0, h2;
         if (u1) {
             const double h1 = pa * s1;
@@ -630,22 +676,18 @@ __global__ __launch_bounds__(kSmallBlock) void k_arnoldi_small(SmallArnoldiArgs 
             if (r < a.nact) {
                 const double v2 = xs[r];
                 const double w = y[t] - c1 * v1[t] - c2 * v2;
-                y[t] = w;
+                v1[t] = v2;              // next column's u_{j-1}
                 dst[r] = w;
+                xs[r] = w;               // own rows only; nobody gathers before the barrier below
                 asq += w * w;
                 ag += w * v2;
             }
         }
-        small_reduce2(asq, ag, red);     // every lane is past its reads of xs after these barriers
+        small_reduce2(asq, ag, red + rb);               // its barrier also publishes the new source column
+        rb ^= 32;
         S = asq;
         g = ag;
         s1 = s2;
-#pragma unroll
-        for (int t = 0; t < kSmallTrips; ++t) {
-            const int64_t r = small_row<DIA>(t);
-            if (r < a.nact) xs[r] = y[t];
-        }
-        __syncthreads();
     }
     if (broke) {
         if (tid == 0) *a.brk_flag = 1;
@@ -673,22 +715,40 @@ __global__ __launch_bounds__(kSmallBlock) void k_arnoldi_small(SmallArnoldiArgs 
     for (int t = 0; t < kSmallTrips; ++t) {
         const int64_t r = small_row<DIA>(t);
         if (r < a.nact) {
-            const double yv = s2 * small_product_row<DIA>(a, xs, r, offs[t], wid[t]);
+            const double yv = s2 * small_product_row<FMT>(a, xs, vs, cs, r, offs[t], wid[t]);
             dst[r] = yv;
             av += yv * yv;
         }
     }
-    small_reduce2(av, dummy, red);
+    small_reduce2(av, dummy, red + rb);
     if (tid == 0) {
         Hd[(size_t)kMH * kMH] = av;
         Hd[(size_t)kMH * kMH + 1] = sqrt(av);
     }
 }
 
-void launch_arnoldi_small(const SmallArnoldiArgs &a, bool dia, hipStream_t st)
+// bytes of dynamic LDS the generator-in-LDS variant needs
+size_t small_lds_bytes(int64_t nact, int64_t slots, bool with_matrix)
 {
-    if (dia) hipLaunchKernelGGL((k_arnoldi_small<true>), dim3(1), dim3(kSmallBlock), 0, st, a);
-    else hipLaunchKernelGGL((k_arnoldi_small<false>), dim3(1), dim3(kSmallBlock), 0, st, a);
+    return (size_t)nact * 8 + (with_matrix ? (size_t)slots * 10 + 16 : 0);
+}
+
+int launch_arnoldi_small(const SmallArnoldiArgs &a, bool dia, int64_t lds_limit, hipStream_t st)
+{
+    static bool raised = false;
+    const size_t want = small_lds_bytes(a.nact, a.slots, true);
+    const bool lmat = !dia && a.slots > 0 && (int64_t)want + 512 <= lds_limit;
+    if (lmat && !raised) {
+        // more than the default 64 KiB of dynamic LDS has to be asked for once per kernel
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_arnoldi_small<2>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit - 512);
+        if (e != hipSuccess) return (int)e;
+        raised = true;
+    }
+    if (dia) hipLaunchKernelGGL((k_arnoldi_small<1>), dim3(1), dim3(kSmallBlock), small_lds_bytes(a.nact, 0, false), st, a);
+    else if (lmat) hipLaunchKernelGGL((k_arnoldi_small<2>), dim3(1), dim3(kSmallBlock), want, st, a);
+    else hipLaunchKernelGGL((k_arnoldi_small<0>), dim3(1), dim3(kSmallBlock), small_lds_bytes(a.nact, 0, false), st, a);
+    return 0;
 }
 
 // ------------------------------------------------------------------ combine
