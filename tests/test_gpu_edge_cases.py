@@ -157,3 +157,26 @@ def test_one_launch_arnoldi_equals_multi_launch(oracle, golden_dir, fixture):
         assert np.abs(v51 - V[:, 50]).max() < 1e-10
     assert np.abs(out[1][0] - out[0][0]).max() <= 1e-12 * np.abs(Href).max()
     assert out[1][4] == pytest.approx(out[0][4], rel=1e-12)
+
+
+@pytest.mark.parametrize("fixture", ["solve_toggle_input.npz", "solve_ring6.npz"])
+def test_one_launch_arnoldi_with_and_without_the_generator_in_lds(golden_dir, fixture):
+    """When the SELL slots fit beside the source column in the workgroup's LDS the
+    one-launch kernel copies them there (values + 16-bit columns); option
+    small_lds = 0 keeps them in global memory.  Same operations in the same order:
+    identical bits."""
+    import os
+    from krylovfspssa_amd import KfspContext
+    g = np.load(os.path.join(golden_dir, fixture))
+    w = np.random.default_rng(5).random(int(g["n"]))
+    out = []
+    for lds in (1, 0):
+        with KfspContext(0) as c:
+            c.set_option("small_lds", lds)
+            c.set_matrix_ell(g["adj"], g["offdiag"], g["diag"])
+            c.set_vector(w)
+            c.begin_step()
+            H, mb, k1, av = c.arnoldi(30)
+            out.append((H.copy(), av, c.get_basis(31), (mb, k1)))
+    assert out[0][3] == out[1][3]
+    assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1] and np.array_equal(out[0][2], out[1][2])
