@@ -15,7 +15,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o final -- pyth
 cd $R
 find $O/prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/final_kernel_stats.csv
 B=krylovfspssa_amd/fortran/_build
-/opt/rocm/lib/llvm/bin/flang -O3 -fopenmp -I$B profiles/statespace_bench.f90 $B/libkfsp_fortran.a -o /tmp/ssb
+(cd /tmp && /opt/rocm/lib/llvm/bin/flang -O3 -fopenmp -I$R/$B $R/profiles/statespace_bench.f90 $R/$B/libkfsp_fortran.a -o /tmp/ssb)
 ( lscpu | grep "Model name"; for t in 1 16; do echo "KFSP_HOST_THREADS=$t"; KFSP_HOST_THREADS=$t /tmp/ssb 2.0 38 | tail -2; done ) > $O/statespace_bench.log 2>&1
 cd tests/golden/models
 ( for p in toggle TestSolverFromFile repressilator transcr6d; do
