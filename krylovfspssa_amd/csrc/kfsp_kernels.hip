@@ -528,12 +528,13 @@ __device__ __forceinline__ int64_t small_row(int t)
 
 // SELL row with the chunk's offset and width already in registers (they do not
 // change from column to column, so the dependent off[] load is paid once per pass)
-__device__ __forceinline__ double row_sell_pre(const SellDev &A, const double *xs, int64_t r, int64_t off, int w)
+__device__ __forceinline__ double row_sell_pre(const SellDev &A, const double *xs, int64_t r, int64_t off, int w,
+                                               double dg)
 {
     const int lane = (int)(r & 63);
     const int32_t *cp = A.col + off + lane;
     const double *vp = A.val + off + lane;
-    double sum = -A.diag[r] * xs[r];
+    double sum = -dg * xs[r];
     int k = 0;
     for (; k + 4 <= w; k += 4) {
         const int32_t c0 = cp[(k + 0) * 64], c1 = cp[(k + 1) * 64], c2 = cp[(k + 2) * 64], c3 = cp[(k + 3) * 64];
@@ -549,13 +550,13 @@ __device__ __forceinline__ double row_sell_pre(const SellDev &A, const double *x
 
 // the same with the chunk's slots copied to LDS (values, and columns as 16-bit numbers:
 // there are at most 4096 rows)
-__device__ __forceinline__ double row_sell_lds(const double *vs, const unsigned short *cs, const double *diag,
+__device__ __forceinline__ double row_sell_lds(const double *vs, const unsigned short *cs, double dg,
                                                const double *xs, int64_t r, int64_t off, int w)
 {
     const int lane = (int)(r & 63);
     const unsigned short *cp = cs + off + lane;
     const double *vp = vs + off + lane;
-    double sum = -diag[r] * xs[r];
+    double sum = -dg * xs[r];
     int k = 0;
     for (; k + 4 <= w; k += 4) {
         const int c0 = cp[(k + 0) * 64], c1 = cp[(k + 1) * 64], c2 = cp[(k + 2) * 64], c3 = cp[(k + 3) * 64];
@@ -572,11 +573,11 @@ __device__ __forceinline__ double row_sell_lds(const double *vs, const unsigned 
 // FMT: 0 SELL from global memory, 1 banded, 2 SELL from LDS
 template <int FMT>
 __device__ __forceinline__ double small_product_row(const SmallArnoldiArgs &a, const double *xs, const double *vs,
-                                                    const unsigned short *cs, int64_t r, int64_t off, int w)
+                                                    const unsigned short *cs, int64_t r, int64_t off, int w, double dg)
 {
     if (FMT == 1) return row_dia1(a.D, xs, r);
-    if (FMT == 2) return row_sell_lds(vs, cs, a.A.diag, xs, r, off, w);
-    return row_sell_pre(a.A, xs, r, off, w);
+    if (FMT == 2) return row_sell_lds(vs, cs, dg, xs, r, off, w);
+    return row_sell_pre(a.A, xs, r, off, w, dg);
 }
 
 template <int FMT>
@@ -604,14 +605,17 @@ __global__ __launch_bounds__(kSmallBlock) void k_arnoldi_small(SmallArnoldiArgs 
     double s1 = a.jold >= 2 ? 1.0 / sqrt(a.sq[a.jold - 1]) : 0.0;   // 1/||u_{j-1}||, carried in a register
     int64_t offs[kSmallTrips];
     int wid[kSmallTrips];
+    double dg[kSmallTrips];                            // DIAG of this lane's rows: the same in every column
 #pragma unroll
     for (int t = 0; t < kSmallTrips; ++t) {
         const int64_t r = small_row<DIA>(t);
         offs[t] = 0;
         wid[t] = 0;
+        dg[t] = 0.0;
         if (!DIA && r < a.nact) {
             offs[t] = a.A.off[r >> 6];
             wid[t] = (int)((a.A.off[(r >> 6) + 1] - offs[t]) >> 6);
+            dg[t] = a.A.diag[r];
         }
     }
     {
@@ -648,7 +652,7 @@ __global__ __launch_bounds__(kSmallBlock) void k_arnoldi_small(SmallArnoldiArgs 
             const int64_t r = small_row<DIA>(t);
             y[t] = 0.0;
             if (r < a.nact) {
-                y[t] = s2 * small_product_row<FMT>(a, xs, vs, cs, r, offs[t], wid[t]);
+                y[t] = s2 * small_product_row<FMT>(a, xs, vs, cs, r, offs[t], wid[t], dg[t]);
                 pa += v1[t] * y[t];
                 pb += xs[r] * y[t];
             }
@@ -715,7 +719,7 @@ __global__ __launch_bounds__(kSmallBlock) void k_arnoldi_small(SmallArnoldiArgs 
     for (int t = 0; t < kSmallTrips; ++t) {
         const int64_t r = small_row<DIA>(t);
         if (r < a.nact) {
-            const double yv = s2 * small_product_row<FMT>(a, xs, vs, cs, r, offs[t], wid[t]);
+            const double yv = s2 * small_product_row<FMT>(a, xs, vs, cs, r, offs[t], wid[t], dg[t]);
             dst[r] = yv;
             av += yv * yv;
         }
