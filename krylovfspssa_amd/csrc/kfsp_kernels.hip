@@ -21,12 +21,33 @@ namespace kfsp {
 
 // ---------------------------------------------------------------- reductions
 
+// v of a lane CTRL away (DPP: a register-file crossbar move, no LDS traffic); lanes the
+// masks exclude and lanes without a source get 0
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ double dpp_get(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, BANK_MASK, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, BANK_MASK, true);
+    return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ double wave_allreduce_sum(double v)
 {
-    // xor butterfly over the 64 lanes: every lane ends with the same bits
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    // Sum of the 64 lanes, the same bits in every lane.  Row-shift / row-broadcast DPP
+    // steps (the ds_bpermute of a shuffle butterfly goes through the LDS pipeline and is
+    // ~5x slower, which the one-launch Arnoldi kernel pays four times per column):
+    // prefix sums inside each row of 16 lanes, then lane 15 of every row is folded into
+    // the next rows; lane 63 ends with the total, which is read back as a scalar.
+    const double v1 = v + dpp_get<0x111, 0xf, 0xf>(v);          // row_shr:1
+    const double v2 = v1 + dpp_get<0x112, 0xf, 0xf>(v);         // row_shr:2
+    double w = v2 + dpp_get<0x113, 0xf, 0xf>(v);                // row_shr:3 -> sums of 4
+    w += dpp_get<0x114, 0xf, 0xe>(w);                           // row_shr:4, banks 1-3
+    w += dpp_get<0x118, 0xf, 0xc>(w);                           // row_shr:8, banks 2-3 -> lane 15 = row total
+    w += dpp_get<0x142, 0xa, 0xf>(w);                           // row_bcast:15 into rows 1 and 3
+    w += dpp_get<0x143, 0xc, 0xf>(w);                           // row_bcast:31 into rows 2 and 3
+    const int lo = __builtin_amdgcn_readlane(__double2loint(w), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(w), 63);
+    return __hiloint2double(hi, lo);
 }
 
 // Sum over the block, result in every thread.  red: 4 doubles of LDS.
