@@ -56,3 +56,14 @@ def test_library_padm_matches_reference_dgpadm(lib, golden_dir):
         ref = g[f"E{c}"]
         assert ns == int(g[f"ns{c}"])
         assert np.abs(E - ref).max() <= 1e-13 * np.abs(ref).max()
+
+
+def test_every_library_option_is_documented_in_the_header():
+    """kfsp_set_option names (csrc/kfsp_api.cpp) all appear in include/kfsp.h."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "krylovfspssa_amd", "csrc", "kfsp_api.cpp")).read()
+    hdr = open(os.path.join(root, "include", "kfsp.h")).read()
+    names = re.findall(r'k == "([a-z_]+)"', src)
+    assert len(names) >= 10
+    assert not [n for n in names if f'"{n}"' not in hdr]
