@@ -155,6 +155,17 @@ def make_drop(tmp):
     print("droptol", a[1])
 
 
+def make_exprtable(tmp):
+    # G4b: the reference's expression type on a model file of our own that exercises operator
+    # classes, associativity, unary minus, '**', all functions, D/E exponents, dotted names
+    # and the error rules (x/0, log of a non-positive number)
+    p = os.path.join(tmp, "exprtable.bin")
+    run_dump(["exprtable", p])
+    P = np.fromfile(p).reshape(13, 13, 3, 16)
+    np.savez_compressed(os.path.join(GOLDEN, "exprtable.npz"), P=P)
+    print("exprtable", P.shape, float(np.abs(P).max()))
+
+
 def main():
     if not os.path.exists(os.path.join(REF_DIR, "ref_dump")):
         sys.exit("oracle/_ref/ref_dump missing: run `make -C oracle` where /root/reference exists")
@@ -165,6 +176,7 @@ def main():
     if not only:
         make_ssa(tmp)
         make_drop(tmp)
+        make_exprtable(tmp)
     if sys.argv[1:] == ["statespace"]:
         return
 

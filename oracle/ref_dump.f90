@@ -21,6 +21,7 @@
 !         ref_dump solve    <case> <out.bin> [T]    (log goes to stdout)
 !         ref_dump padm     <out.bin>
 !         ref_dump proptable <out.bin>
+!         ref_dump exprtable <out.bin>
 !
 ! binary layout (stream, native endian):
 !   fsp file : int32 ns, nr, n ; int32 STATE(ns,n) ; int32 ADJ(nr,n) ;
@@ -101,6 +102,8 @@ PROGRAM REF_DUMP
      CALL DO_PADM(TRIM(ARG2))
   CASE ('proptable')
      CALL DO_PROPTABLE(TRIM(ARG2))
+  CASE ('exprtable')
+     CALL DO_EXPRTABLE(TRIM(ARG2))
   CASE DEFAULT
      STOP 'ref_dump: unknown mode'
   END SELECT
@@ -489,5 +492,32 @@ CONTAINS
     WRITE(U) P
     CLOSE(U)
   END SUBROUTINE DO_PROPTABLE
+
+  SUBROUTINE DO_EXPRTABLE(FNAME)
+    ! propensities of expr_test_model.input (a model file of OURS: operator
+    ! precedence and associativity, unary minus, '**', every function of the
+    ! expression type, D/E exponents, a species name with '.' and digits,
+    ! division by zero and log of a non-positive number) on a 13 x 13 x 3 grid.
+    ! file: f64 P(16,3,13,13)  (reaction fastest, then DNA.2D, Y, X)
+    CHARACTER(LEN=*), INTENT(IN) :: FNAME
+    TYPE(CME_MODEL) :: MODEL
+    DOUBLE PRECISION :: P(16, 3, 13, 13)
+    INTEGER :: I, J, K, R, U
+    CALL MODEL%LOAD('expr_test_model.input')
+    CALL MODEL%RESET_PARAMETERS((/7.5D0, 2.0D0, 0.75D0, 0.3D0, 4.0D0/))
+    DO I = 0, 12
+       DO J = 0, 12
+          DO K = 0, 2
+             DO R = 1, 16
+                P(R, K + 1, J + 1, I + 1) = MODEL%PROPENSITY((/I, J, K/), R)
+             ENDDO
+          ENDDO
+       ENDDO
+    ENDDO
+    OPEN(NEWUNIT=U, FILE=FNAME, ACCESS='STREAM', FORM='UNFORMATTED', STATUS='REPLACE')
+    WRITE(U) P
+    CLOSE(U)
+    PRINT *, 'EXPRTABLE ', MODEL%NSPECIES, MODEL%NREACTIONS, P(:, 1, 5, 8)
+  END SUBROUTINE DO_EXPRTABLE
 
 END PROGRAM REF_DUMP

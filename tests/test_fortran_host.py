@@ -150,6 +150,24 @@ def test_parsed_propensities_match_reference_parser(dump, tmp_path):
     assert np.abs(P - closed).max() <= 1e-12 * np.abs(closed).max()
 
 
+def test_expression_engine_matches_the_reference_parser_on_every_construct(dump, tmp_path):
+    """tests/golden/models/expr_test_model.input (ours): sixteen propensity strings covering
+    the operator classes and their associativity, unary minus, '**', all fourteen functions,
+    D/E exponents, a species called DNA.2D, x/0 and log of a non-positive number - evaluated
+    on a 13 x 13 x 3 grid by the reference's parser (fixture) and by ours: identical bits."""
+    p = str(tmp_path / "e.bin")
+    _run(dump, ["exprtable", p], tmp_path)
+    P = np.fromfile(p).reshape(13, 13, 3, 16)
+    G = np.load(os.path.join(GOLDEN, "exprtable.npz"))["P"]
+    assert np.array_equal(P, G)
+    x = np.arange(13.0)[:, None, None]
+    y = np.arange(13.0)[None, :, None]
+    assert np.array_equal(P[..., 0], np.full((13, 13, 3), 7.5 - 2.0 - 0.75))          # (a - b) - c
+    assert np.array_equal(P[..., 1], np.full((13, 13, 3), 7.5 / 2.0 / 0.75))          # (a / b) / c
+    assert np.allclose(P[..., 8], 0.3 * x * (x - 1) / 2 + 0 * y, rtol=1e-15)
+    assert np.all(P[:, 3, :, 14] == 0.0) and np.all(P[:6, :, :, 15] == 0.0)           # x/0 and log(<= 0) give 0
+
+
 def _solve(dump, tmp_path, fixture, case, env=None):
     g = np.load(os.path.join(GOLDEN, f"solve_{fixture}.npz"))
     p = str(tmp_path / "s.bin")
