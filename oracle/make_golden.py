@@ -162,7 +162,8 @@ def make_exprtable(tmp):
     p = os.path.join(tmp, "exprtable.bin")
     run_dump(["exprtable", p])
     P = np.fromfile(p).reshape(13, 13, 3, 16)
-    np.savez_compressed(os.path.join(GOLDEN, "exprtable.npz"), P=P)
+    st = np.fromfile(p + ".stoich", dtype=np.int32)
+    np.savez_compressed(os.path.join(GOLDEN, "exprtable.npz"), P=P, stoich=st[2:].reshape(int(st[1]), int(st[0])))
     print("exprtable", P.shape, float(np.abs(P).max()))
 
 

@@ -517,6 +517,11 @@ CONTAINS
     OPEN(NEWUNIT=U, FILE=FNAME, ACCESS='STREAM', FORM='UNFORMATTED', STATUS='REPLACE')
     WRITE(U) P
     CLOSE(U)
+    ! the stoichiometry LOAD read from the reaction strings ('2X -> Y', 'X -> DNA.2D', ...)
+    OPEN(NEWUNIT=U, FILE=FNAME // '.stoich', ACCESS='STREAM', FORM='UNFORMATTED', STATUS='REPLACE')
+    WRITE(U) MODEL%NSPECIES, MODEL%NREACTIONS
+    WRITE(U) MODEL%STOICHIOMETRY(1:MODEL%NSPECIES, 1:MODEL%NREACTIONS)
+    CLOSE(U)
     PRINT *, 'EXPRTABLE ', MODEL%NSPECIES, MODEL%NREACTIONS, P(:, 1, 5, 8)
   END SUBROUTINE DO_EXPRTABLE
 

@@ -158,8 +158,14 @@ def test_expression_engine_matches_the_reference_parser_on_every_construct(dump,
     p = str(tmp_path / "e.bin")
     _run(dump, ["exprtable", p], tmp_path)
     P = np.fromfile(p).reshape(13, 13, 3, 16)
-    G = np.load(os.path.join(GOLDEN, "exprtable.npz"))["P"]
+    fix = np.load(os.path.join(GOLDEN, "exprtable.npz"))
+    G = fix["P"]
     assert np.array_equal(P, G)
+    # the reaction strings ('2X -> Y', 'Y -> 2X', 'X -> DNA.2D', '0 -> X', ...) give the reference's stoichiometry
+    st = np.fromfile(p + ".stoich", dtype=np.int32)
+    assert (int(st[0]), int(st[1])) == (3, 16)
+    assert np.array_equal(st[2:].reshape(16, 3), fix["stoich"])
+    assert fix["stoich"][8].tolist() == [-2, 1, 0] and fix["stoich"][14].tolist() == [-1, 0, 1]
     x = np.arange(13.0)[:, None, None]
     y = np.arange(13.0)[None, :, None]
     assert np.array_equal(P[..., 0], np.full((13, 13, 3), 7.5 - 2.0 - 0.75))          # (a - b) - c
