@@ -167,6 +167,18 @@ def make_exprtable(tmp):
     print("exprtable", P.shape, float(np.abs(P).max()))
 
 
+def make_api(tmp):
+    # G1d: ADD / INDEX / PROBABILITY as a driver may call them (StateSpace.f90:19-45)
+    p = os.path.join(tmp, "api.bin")
+    run_dump(["api", p])
+    d = read_fsp(p)
+    with open(p + ".q", "rb") as f:
+        idx = np.fromfile(f, dtype=np.int32, count=8)
+        prob = np.fromfile(f, dtype=np.float64, count=8)
+    np.savez_compressed(os.path.join(GOLDEN, "api_toggle.npz"), idx=idx, prob=prob, **d)
+    print("api", d["n"], idx)
+
+
 def main():
     if not os.path.exists(os.path.join(REF_DIR, "ref_dump")):
         sys.exit("oracle/_ref/ref_dump missing: run `make -C oracle` where /root/reference exists")
@@ -178,6 +190,7 @@ def main():
         make_ssa(tmp)
         make_drop(tmp)
         make_exprtable(tmp)
+        make_api(tmp)
     if sys.argv[1:] == ["statespace"]:
         return
 

@@ -22,6 +22,7 @@
 !         ref_dump padm     <out.bin>
 !         ref_dump proptable <out.bin>
 !         ref_dump exprtable <out.bin>
+!         ref_dump api      <out.bin>
 !
 ! binary layout (stream, native endian):
 !   fsp file : int32 ns, nr, n ; int32 STATE(ns,n) ; int32 ADJ(nr,n) ;
@@ -104,6 +105,8 @@ PROGRAM REF_DUMP
      CALL DO_PROPTABLE(TRIM(ARG2))
   CASE ('exprtable')
      CALL DO_EXPRTABLE(TRIM(ARG2))
+  CASE ('api')
+     CALL DO_API(TRIM(ARG2))
   CASE DEFAULT
      STOP 'ref_dump: unknown mode'
   END SELECT
@@ -524,5 +527,48 @@ CONTAINS
     CLOSE(U)
     PRINT *, 'EXPRTABLE ', MODEL%NSPECIES, MODEL%NREACTIONS, P(:, 1, 5, 8)
   END SUBROUTINE DO_EXPRTABLE
+
+  SUBROUTINE DO_API(FNAME)
+    ! the bound procedures of FINITE_STATE_PROJECTION a driver may call itself
+    ! (StateSpace.f90:19-45): ADD (repeated, unordered, one state twice, a negative one),
+    ! INDEX and PROBABILITY of listed and unlisted states.  The FSP goes to FNAME, the
+    ! query results to FNAME.q (int32 idx(nq), f64 prob(nq)).
+    CHARACTER(LEN=*), INTENT(IN) :: FNAME
+    TYPE(CME_MODEL) :: MODEL
+    TYPE(FINITE_STATE_PROJECTION) :: FSP
+    INTEGER, ALLOCATABLE :: X0(:)
+    INTEGER, PARAMETER :: NQ = 8
+    INTEGER :: I, U, Q(2, NQ), IDX(NQ), ST(2)
+    DOUBLE PRECISION :: PR(NQ)
+    CALL LOAD_INPUT_MODEL('toggle', MODEL, X0)
+    CALL FSP%CREATE(MODEL, TABLEN)
+    FSP%SIZE = 1
+    FSP%STATE(:, 1) = X0
+    FSP%VECTOR = 0.0D0
+    CALL MATRIX_STARTER(FSP, MODEL)
+    DO I = 1, 3
+       CALL ONESTEP_EXTENDER(FSP, MODEL)
+    ENDDO
+    ST = [7, 2];  CALL FSP%ADD(MODEL, ST)
+    ST = [1, 4];  CALL FSP%ADD(MODEL, ST)
+    ST = [7, 2];  CALL FSP%ADD(MODEL, ST)          ! already listed
+    ST = [6, 2];  CALL FSP%ADD(MODEL, ST)          ! neighbour of a listed one
+    ST = [-1, 3]; CALL FSP%ADD(MODEL, ST)          ! not a state
+    ST = [0, 4];  CALL FSP%ADD(MODEL, ST)
+    DO I = 1, FSP%SIZE
+       FSP%VECTOR(I) = 1.0D0 / DBLE(I + 1)
+    ENDDO
+    Q = RESHAPE([0, 0, 7, 2, 1, 4, 6, 2, 5, 5, -1, 3, 0, 4, 2, 1], [2, NQ])
+    DO I = 1, NQ
+       IDX(I) = FSP%INDEX(Q(:, I))
+       PR(I) = FSP%PROBABILITY(Q(:, I))
+    ENDDO
+    CALL WRITE_FSP(FNAME, MODEL, FSP)
+    OPEN(NEWUNIT=U, FILE=FNAME // '.q', ACCESS='STREAM', FORM='UNFORMATTED', STATUS='REPLACE')
+    WRITE(U) IDX
+    WRITE(U) PR
+    CLOSE(U)
+    PRINT *, 'API N=', FSP%SIZE, ' IDX=', IDX
+  END SUBROUTINE DO_API
 
 END PROGRAM REF_DUMP

@@ -150,6 +150,23 @@ def test_parsed_propensities_match_reference_parser(dump, tmp_path):
     assert np.abs(P - closed).max() <= 1e-12 * np.abs(closed).max()
 
 
+def test_fsp_bound_procedures_behave_like_the_reference(dump, tmp_path):
+    """FSP%ADD (unordered, a duplicate, a neighbour of a listed state, a negative state),
+    FSP%INDEX and FSP%PROBABILITY of listed and unlisted states (StateSpace.f90:19-45)."""
+    p = str(tmp_path / "a.bin")
+    _run(dump, ["api", p], tmp_path)
+    d = MG.read_fsp(p)
+    g = np.load(os.path.join(GOLDEN, "api_toggle.npz"))
+    assert d["n"] == int(g["n"]) == 14
+    for key in ("state", "adj", "offdiag", "diag", "vector"):
+        assert np.array_equal(d[key], g[key]), key
+    with open(p + ".q", "rb") as f:
+        idx = np.fromfile(f, dtype=np.int32, count=8)
+        prob = np.fromfile(f, dtype=np.float64, count=8)
+    assert np.array_equal(idx, g["idx"]) and np.array_equal(prob, g["prob"])
+    assert idx.tolist() == [1, 11, 12, 13, 0, 0, 14, 8] and prob[4] == 0.0
+
+
 def test_expression_engine_matches_the_reference_parser_on_every_construct(dump, tmp_path):
     """tests/golden/models/expr_test_model.input (ours): sixteen propensity strings covering
     the operator classes and their associativity, unary minus, '**', all fourteen functions,
