@@ -161,7 +161,9 @@ enum {
     KFSP_EV_STEP = 3,        /* nstep, n, t_step, t_new, t_now, m */
     KFSP_EV_REJECT_STEP = 4, /* t_old, err_loc, err_required, t_step_new */
     KFSP_EV_DIM_CHANGE = 5,  /* err_loc, err_required, m_new */
-    KFSP_EV_CALL_SSA = 6     /* t_ssa */
+    KFSP_EV_CALL_SSA = 6,    /* t_ssa */
+    KFSP_EV_READY = 7        /* nstep, t_now, beta, n: w and the FSP are final for the step that
+                                begins next (after :540; also once before the first step, :177) */
 };
 typedef struct {
     void *user;
@@ -187,6 +189,74 @@ typedef struct {
  * >0 device/host failure as everywhere. */
 int kfsp_dgexpv(kfsp_ctx *ctx, double t, double fsptol, double krytol, int n_reactions,
                 const kfsp_fsp_ops *ops, kfsp_stats *stats);
+
+/* ---- lock-step diagnostics ---------------------------------------------- */
+/* The accept/reject decisions of DGEXPV_FSP hinge on quantities that amplify
+ * rounding differences (the tail of exp(tau*H) after ~75 IOP columns), so two
+ * correct implementations eventually take different - equally valid - steps.
+ * To compare the ARITHMETIC of this library with a recorded run of another
+ * implementation step by step, kfsp_dgexpv_replay runs the loop of kfsp_dgexpv
+ * but lets a record of that run make every choice.  Each choice is still
+ * computed here first; where it differs from the record a kfsp_fork entry says
+ * which comparison went the other way and by how much.
+ *
+ * script: n_rows rows of 4 doubles (kind, a, b, c), in the order the loop
+ * consumes them:
+ *   1 BEGIN   (t_step, m, -)        a time step starts with T_STEP (:208; 0 = not recorded,
+ *                                   nothing is compared or forced) and M (:211)
+ *   2 KRYLOV  (code, t_step, m)     outcome of the error test (:375) after each Pade
+ *                                   evaluation: 0 accept; 1 redo with step size t_step on the
+ *                                   same basis (:377-399); 2 extend the basis to dimension m and
+ *                                   use step size t_step (:400-432)
+ *   3 FSP     (code, t_step, wsum)  outcome of the mass test (:458) after each solution
+ *                                   update; wsum = the recorded WSUM (compared, see
+ *                                   max_wsum_diff): 0 accept; 1 retry with step size t_step
+ *                                   (:471-493); 2 fifth failure, restore w and expand (:466-470)
+ *   4 END     (n, t_new, -)         the step is over: n = size of the FSP the next step runs
+ *                                   on (compared after the drop / expand callbacks); t_new =
+ *                                   T_NEW as known from the recorded run at :502 (0 = unknown)
+ * returns like kfsp_dgexpv; 20 = the script ended early or its next row is not
+ * of the kind the loop needs (the runs are no longer comparable); 21 = a happy
+ * breakdown on one side only; -8 bad replay. */
+enum {
+    KFSP_FORK_BEGIN_TAU = 1,     /* own[0]/forced[0] = T_STEP; lhs = T_NEW, rhs = T_OUT - T_NOW */
+    KFSP_FORK_BEGIN_M = 2,       /* own[0]/forced[0] = M; lhs = M_NEW, rhs = N - 1 */
+    KFSP_FORK_KRYLOV_TEST = 3,   /* accept vs reject: own/forced = (code, value); lhs = OMEGA, rhs = DELTA */
+    KFSP_FORK_KRYLOV_CHOICE = 4, /* step size vs dimension: lhs = COST1, rhs = COST2 (:359-362) */
+    KFSP_FORK_KRYLOV_VALUE = 5,  /* same branch, other value: own/forced = (t_step, m) */
+    KFSP_FORK_FSP_TEST = 6,      /* own/forced = (code, wsum); lhs = WSUM, rhs = 1 - FERRORBOUND */
+    KFSP_FORK_FSP_TAU = 7,       /* own[0]/forced[0] = T_STEP of the retry; lhs = ERROR, rhs = FSPORDER */
+    KFSP_FORK_T_NEW = 8,         /* own[0]/forced[0] = T_NEW after the step; lhs = OMEGA, rhs = ORDER */
+    KFSP_FORK_FSP_SIZE = 9,      /* own[0]/forced[0] = FSP size after the callbacks */
+    KFSP_FORK_UNSAFE_ACCEPT = 10,/* safe mode: the recorded accept fails this run's test even at M_MAX
+                                    and is carried out all the same; lhs = OMEGA, rhs = DELTA */
+    KFSP_FORK_BREAKDOWN = 11     /* happy breakdown (:249) on one side only: own[0] = column here (0 = none),
+                                    forced[0] = 1 if recorded; lhs = h(j+1,j), rhs = BREAK_TOL; returns 21 */
+};
+typedef struct {
+    int32_t step;        /* NSTEP at the decision */
+    int32_t kind;        /* KFSP_FORK_* */
+    double own[2];       /* what this run computed */
+    double forced[2];    /* what the record made it do */
+    double lhs, rhs;     /* the two sides of the comparison behind the choice */
+} kfsp_fork;
+typedef struct {
+    const double *script;   /* in: rows of 4 doubles */
+    int64_t n_rows;
+    kfsp_fork *forks;       /* in: room for max_forks entries (may be NULL) */
+    int32_t max_forks;
+    int32_t n_forks;        /* out: differences found (may exceed max_forks; the first ones are kept) */
+    int64_t rows_used;      /* out */
+    double max_wsum_diff;   /* out: max |WSUM here - recorded WSUM| over all solution updates */
+    int32_t safe;           /* in: 0 = carry out every recorded choice; 1 = when the record accepts a
+                               Krylov step that fails THIS run's error test (OMEGA > DELTA), keep the
+                               recorded step size but enlarge the basis by the run's own rule until the
+                               test passes (m < M_MAX), so that no error the record does not have is
+                               injected and the two runs stay comparable step by step */
+    int32_t n_safe_extensions;   /* out: how often that happened */
+} kfsp_replay;
+int kfsp_dgexpv_replay(kfsp_ctx *ctx, double t, double fsptol, double krytol, int n_reactions,
+                       const kfsp_fsp_ops *ops, kfsp_stats *stats, kfsp_replay *replay);
 
 /* ---- benchmark mode --------------------------------------------------- */
 /* nsteps steps of fixed Krylov dimension m and fixed step tau on the resident

@@ -16,7 +16,7 @@ using namespace kfsp;
 
 namespace {
 
-constexpr int kAbiVersion = 1;
+constexpr int kAbiVersion = 2;   // 2: kfsp_dgexpv_replay, KFSP_EV_READY
 
 }  // namespace
 

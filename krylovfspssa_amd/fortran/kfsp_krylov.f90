@@ -23,6 +23,30 @@ MODULE KRYLOVSOLVER
   ! arrays and loses them, :554-573)
   TYPE(KFSP_STATS), SAVE :: LAST_SOLVE_STATS
 
+  ! Observer (optional): called whenever w and the FSP are final for the step that
+  ! begins next - once before the first step (KrylovSolver.f90:177) and after every
+  ! step's DROP_STATES / SSA expansion (:540).  FSP%VECTOR(1:FSP%SIZE) holds w.
+  ABSTRACT INTERFACE
+     SUBROUTINE KFSP_OBSERVER(NSTEP, T_NOW, BETA, FSP)
+       IMPORT :: FINITE_STATE_PROJECTION
+       INTEGER, INTENT(IN) :: NSTEP
+       DOUBLE PRECISION, INTENT(IN) :: T_NOW, BETA
+       TYPE(FINITE_STATE_PROJECTION), INTENT(IN) :: FSP
+     END SUBROUTINE KFSP_OBSERVER
+  END INTERFACE
+  PROCEDURE(KFSP_OBSERVER), POINTER, SAVE :: KFSP_STEP_OBSERVER => NULL()
+
+  ! Lock-step diagnostics (kfsp_dgexpv_replay, include/kfsp.h): when a script is
+  ! associated the next solve follows it; the differences found are left in
+  ! KFSP_REPLAY_FORKS(1:MIN(KFSP_REPLAY_NFORKS, SIZE)) and KFSP_REPLAY_RC (0, or 20
+  ! when the script and the run went out of step).
+  REAL(C_DOUBLE), POINTER, SAVE :: KFSP_REPLAY_SCRIPT(:, :) => NULL()     ! (4, rows)
+  TYPE(KFSP_FORK), ALLOCATABLE, TARGET, SAVE :: KFSP_REPLAY_FORKS(:)
+  INTEGER, SAVE :: KFSP_REPLAY_NFORKS = 0, KFSP_REPLAY_RC = 0
+  INTEGER, SAVE :: KFSP_REPLAY_SAFE = 0          ! kfsp_replay.safe for the next solve
+  INTEGER, SAVE :: KFSP_REPLAY_EXTENSIONS = 0    ! kfsp_replay.n_safe_extensions of the last one
+  DOUBLE PRECISION, SAVE :: KFSP_REPLAY_WSUM_DIFF = 0.0D0
+
   TYPE(C_PTR), SAVE, PRIVATE :: CTX = C_NULL_PTR
   TYPE(FINITE_STATE_PROJECTION), POINTER, SAVE, PRIVATE :: CUR_FSP => NULL()
   TYPE(CME_MODEL), POINTER, SAVE, PRIVATE :: CUR_MODEL => NULL()
@@ -67,6 +91,7 @@ CONTAINS
     INTEGER :: ITRACE
     INTEGER :: IFLAG
     TYPE(KFSP_FSP_OPS) :: OPS
+    TYPE(KFSP_REPLAY) :: RP
     DOUBLE PRECISION, ALLOCATABLE :: P0(:)
     REAL(C_DOUBLE) :: TMS(6)
     INTEGER :: I, N0, RC
@@ -100,8 +125,24 @@ CONTAINS
     OPS%DROP = C_FUNLOC(CB_DROP)
     OPS%EXPAND = C_FUNLOC(CB_EXPAND)
     OPS%LOG = C_FUNLOC(CB_LOG)
-    RC = KFSP_DGEXPV(CTX, T, FSPTOL, KRYTOL, INT(MODEL%NREACTIONS, C_INT), OPS, LAST_SOLVE_STATS)
-    CALL CHECK(RC, 'kfsp_dgexpv')
+    IF (ASSOCIATED(KFSP_REPLAY_SCRIPT)) THEN
+       IF (.NOT. ALLOCATED(KFSP_REPLAY_FORKS)) ALLOCATE(KFSP_REPLAY_FORKS(4096))
+       RP%SCRIPT = C_LOC(KFSP_REPLAY_SCRIPT(1, 1))
+       RP%N_ROWS = SIZE(KFSP_REPLAY_SCRIPT, 2)
+       RP%FORKS = C_LOC(KFSP_REPLAY_FORKS(1))
+       RP%MAX_FORKS = SIZE(KFSP_REPLAY_FORKS)
+       RP%SAFE = KFSP_REPLAY_SAFE
+       RC = KFSP_DGEXPV_REPLAY(CTX, T, FSPTOL, KRYTOL, INT(MODEL%NREACTIONS, C_INT), OPS, LAST_SOLVE_STATS, RP)
+       KFSP_REPLAY_NFORKS = RP%N_FORKS
+       KFSP_REPLAY_WSUM_DIFF = RP%MAX_WSUM_DIFF
+       KFSP_REPLAY_EXTENSIONS = RP%N_SAFE_EXTENSIONS
+       KFSP_REPLAY_RC = RC
+       IF (RC == 20 .OR. RC == 21) RC = 0
+       CALL CHECK(RC, 'kfsp_dgexpv_replay')
+    ELSE
+       RC = KFSP_DGEXPV(CTX, T, FSPTOL, KRYTOL, INT(MODEL%NREACTIONS, C_INT), OPS, LAST_SOLVE_STATS)
+       CALL CHECK(RC, 'kfsp_dgexpv')
+    ENDIF
 
     RC = KFSP_GET_VECTOR(CTX, INT(FSP%SIZE, C_INT64_T), FSP%VECTOR)
     CALL CHECK(RC, 'kfsp_get_vector')
@@ -139,6 +180,8 @@ CONTAINS
 
   SUBROUTINE ENSURE_CONTEXT()
     CHARACTER(LEN=16) :: ENV
+    CHARACTER(LEN=512) :: OPTS
+    INTEGER :: P0, P1, PE
     INTEGER :: DEV, L, STAT, RC
     INTEGER(C_INT64_T) :: V8
     IF (C_ASSOCIATED(CTX)) RETURN
@@ -168,6 +211,28 @@ CONTAINS
     IF (STAT == 0 .AND. L > 0) THEN
        READ(ENV(1:L), *, IOSTAT=STAT) V8
        IF (STAT == 0) RC = KFSP_SET_OPTION(CTX, 'state_order' // C_NULL_CHAR, V8)
+    ENDIF
+    ! any other library option (kfsp_set_option, include/kfsp.h): KFSP_OPTIONS="name=value,name=value"
+    CALL GET_ENVIRONMENT_VARIABLE('KFSP_OPTIONS', OPTS, L, STAT)
+    IF (STAT == 0 .AND. L > 0) THEN
+       P0 = 1
+       DO WHILE (P0 <= L)
+          P1 = INDEX(OPTS(P0:L), ',')
+          IF (P1 == 0) THEN
+             P1 = L + 1
+          ELSE
+             P1 = P0 + P1 - 1
+          ENDIF
+          PE = INDEX(OPTS(P0:P1 - 1), '=')
+          IF (PE > 1) THEN
+             READ(OPTS(P0 + PE:P1 - 1), *, IOSTAT=STAT) V8
+             IF (STAT == 0) THEN
+                RC = KFSP_SET_OPTION(CTX, TRIM(ADJUSTL(OPTS(P0:P0 + PE - 2))) // C_NULL_CHAR, V8)
+                IF (RC /= 0) PRINT *, 'KFSP: UNKNOWN OPTION IN KFSP_OPTIONS: ', OPTS(P0:P1 - 1)
+             ENDIF
+          ENDIF
+          P0 = P1 + 1
+       ENDDO
     ENDIF
   END SUBROUTINE ENSURE_CONTEXT
 
@@ -285,6 +350,11 @@ CONTAINS
        ENDIF
     CASE (KFSP_EV_CALL_SSA)
        IF (CUR_TRACE /= 0) PRINT *, 'CALLING SSA'
+    CASE (KFSP_EV_READY)
+       IF (ASSOCIATED(KFSP_STEP_OBSERVER)) THEN
+          IF (KFSP_GET_VECTOR(CTX, INT(CUR_FSP%SIZE, C_INT64_T), CUR_FSP%VECTOR) == 0) &
+               CALL KFSP_STEP_OBSERVER(INT(VALS(1)), VALS(2), VALS(3), CUR_FSP)
+       ENDIF
     END SELECT
   END SUBROUTINE CB_LOG
 

@@ -179,7 +179,118 @@ def make_api(tmp):
     print("api", d["n"], idx)
 
 
+# (fixture, ref_cases workload, number of leading steps whose solution vector is kept)
+LOCKSTEP_CASES = [("toggle_input", "toggle_input", 72), ("toggle_example", "toggle_example", 72)]
+
+
+def run_trace(case, trace, out, T=None):
+    cmd = "ulimit -s unlimited && exec ../ref_trace " + " ".join([case, trace, out] + ([repr(T)] if T else []))
+    env = dict(os.environ, MKL_NUM_THREADS="1")
+    return subprocess.run(["bash", "-c", cmd], cwd=os.path.join(REF_DIR, "models"), env=env,
+                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, check=True, text=True).stdout
+
+
+def make_lockstep(tmp):
+    """G7: the reference's own decisions, state lists and solution vectors step by step
+    (oracle/ref_trace_main.f90 + the BLAS observers of oracle/ref_trace.c), for the lock-step
+    tests.  The observed run must be bit-identical to the plain one (solve_<name>.npz)."""
+    from oracle import lockstep as L
+    for name, case, keep in LOCKSTEP_CASES:
+        _, T, fsptol, krytol = SOLVE_CASES[name]
+        trace, out = os.path.join(tmp, f"{name}.trace"), os.path.join(tmp, f"{name}.tr.bin")
+        text = run_trace(case, trace, out)
+        plain = np.load(os.path.join(GOLDEN, f"solve_{name}.npz"))
+        dout = read_fsp(out)
+        assert np.array_equal(dout["state"], plain["state"]) and np.array_equal(dout["vector"], plain["vector"]), \
+            "the observers changed the run"
+        log = parse_log(text)
+        r = L.build_script(L.read_trace(trace), log, T, fsptol)
+        ev = r["events"]
+        arrays = dict(T=T, fsptol=fsptol, krytol=krytol, script=r["script"], n_after=r["n_after"],
+                      beta=np.array([e["beta"] for e in ev if e["tag"] == "B"]),
+                      fsp_at=np.array([k for k, _ in r["fsps"]], dtype=np.int64), keep=np.int64(keep),
+                      final_state=dout["state"], final_vector=dout["vector"])
+        for k, f in r["fsps"]:
+            arrays[f"state_{k}"] = f["state"]
+        for k in range(min(keep, len(r["w_after"]))):
+            arrays[f"w_{k}"] = r["w_after"][k]
+        # time at every B event (accepted steps advance it, give-ups do not)
+        t_now, times = 0.0, [0.0]
+        for row in r["script"]:
+            if row[0] == L.FSP and row[1] == 0.0:
+                t_now += row[2]
+            if row[0] == L.END:
+                times.append(t_now)
+        arrays["t_at"] = np.array(times[:len(r["n_after"])])
+        np.savez_compressed(os.path.join(GOLDEN, f"lockstep_{name}.npz"), **arrays)
+        print(f"lockstep {name}: {len(r['script'])} script rows, {len(r['n_after'])} steps, {len(r['fsps'])} state lists")
+        if name == "toggle_input":
+            make_sensitivity_sample(r, os.path.join(GOLDEN, "lockstep_sample_toggle.npz"))
+
+
+def make_sensitivity_sample(r, path):
+    """One Krylov pass of the toggle_input run in full (the first pass whose error estimate an
+    independent implementation does not reproduce, step 4: N = 438, m = 75): start vector,
+    generator, the reference's Hessenberg matrix and AVNORM, its step sizes, the coefficient vector
+    and the solution it produced; plus a few (H, t, exp(tH) e1) triples of DGPADM(norm) calls."""
+    from oracle import oracle as O
+    ev = r["events"]
+
+    def err_loc(E, m, beta, avnorm):
+        p1, p2 = abs(E[m, 0]) * beta, abs(E[m + 1, 0]) * beta * avnorm
+        return p2 if p1 > 10.0 * p2 else (p1 * p2 / (p1 - p2) if p1 > p2 else p1)
+
+    # the first time step (single Krylov pass: no dimension change inside it) whose error estimate
+    # the C restatement misses by more than 1 %
+    bs = [i for i, e in enumerate(ev) if e["tag"] == "B"]
+    F, chosen = None, None
+    for a, b in zip(bs, bs[1:]):
+        seg = ev[a:b]
+        F = next((e for e in seg if e["tag"] == "F"), F)
+        ps = [e for e in seg if e["tag"] == "P"]
+        cs = [e for e in seg if e["tag"] == "C"]
+        if len({p["m"] for p in ps}) != 1 or ps[0]["mx"] != ps[0]["m"] + 2 or not cs or cs[0]["mx"] != ps[0]["m"] + 1:
+            continue
+        m, beta = ps[0]["m"], ev[a]["beta"]
+        A = O.EllMatrix(F["adj"], F["offdiag"], F["diag"])
+        V, H, mb, k1, av = O.arnoldi(A, ev[a]["w"] / beta, m)
+        e_o = err_loc(O.padm(H, ps[0]["t"])[0], m, beta, av)
+        e_r = err_loc(O.padm(ps[0]["H"], ps[0]["t"])[0], m, beta, ps[0]["avnorm"])
+        if abs(e_o - e_r) > 1e-2 * e_r:
+            chosen = (a, seg, ps, cs)
+            break
+    assert chosen is not None
+    a, seg, ps, cs = chosen
+    ib = a
+    # krylov evaluations before the first solution update, and that update
+    kp = [e for e in seg[:seg.index(cs[0])] if e["tag"] == "P"]
+    c = cs[0]
+    s = seg[seg.index(c) + 1]
+    assert s["tag"] == "S"
+    out = dict(adj=F["adj"], offdiag=F["offdiag"], diag=F["diag"], w0=ev[ib]["w"], beta=ev[ib]["beta"],
+               H=kp[0]["H"], avnorm=kp[0]["avnorm"], t_first=kp[0]["t"], t_second=kp[-1]["t"],
+               y=c["y"], w1=s["w"], wsum=s["wsum"])
+    ps = kp
+    # DGPADM samples: (H, t) of an accepted evaluation and the coefficient vector DGEMV received
+    k = 0
+    last_p = None
+    for e in ev:
+        if e["tag"] == "P":
+            last_p = e
+        if e["tag"] == "C" and last_p is not None and last_p["mx"] >= e["mx"] and k < 8 and e["mx"] in (38, 79, 77, 102, 93, 68, 58, 45, 90):
+            out[f"pH{k}"] = last_p["H"]
+            out[f"pt{k}"] = last_p["t"]
+            out[f"py{k}"] = e["y"]
+            k += 1
+    out["npade"] = np.int32(k)
+    np.savez_compressed(path, **out)
+    print(f"sensitivity sample: step {bs.index(ib)} N={F['n']} m={ps[0]['m']} t={[p['t'] for p in ps]} pade samples={k}")
+
+
 def main():
+    if sys.argv[1:2] == ["lockstep"]:
+        make_lockstep(tempfile.mkdtemp(prefix="kfsp_golden_"))
+        return
     if not os.path.exists(os.path.join(REF_DIR, "ref_dump")):
         sys.exit("oracle/_ref/ref_dump missing: run `make -C oracle` where /root/reference exists")
     os.makedirs(GOLDEN, exist_ok=True)

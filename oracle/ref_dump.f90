@@ -27,28 +27,6 @@
 ! binary layout (stream, native endian):
 !   fsp file : int32 ns, nr, n ; int32 STATE(ns,n) ; int32 ADJ(nr,n) ;
 !              f64 OFFDIAG(nr,n) ; f64 DIAG(n) ; f64 VECTOR(n)
-MODULE REF_DUMP_RING
-  ! closed-ring test model: module procedure (no host association, so the
-  ! procedure pointer stored in CME_MODEL%CUSTOMPROP needs no trampoline)
-  IMPLICIT NONE
-  DOUBLE PRECISION :: RING_CF(6), RING_CB(6)
-  INTEGER :: RING_NS
-CONTAINS
-  DOUBLE PRECISION FUNCTION RING_PROP(STATE, REACTION, PARAMETERS)
-    INTEGER, INTENT(IN) :: STATE(:), REACTION
-    DOUBLE PRECISION, INTENT(IN), OPTIONAL :: PARAMETERS(:)
-    INTEGER :: I, K
-    I = (REACTION + 1) / 2
-    K = MOD(I, RING_NS) + 1
-    IF (MOD(REACTION, 2) == 1) THEN
-       RING_PROP = RING_CF(I) * STATE(I)
-    ELSE
-       RING_PROP = RING_CB(I) * STATE(K)
-    ENDIF
-  END FUNCTION RING_PROP
-
-END MODULE REF_DUMP_RING
-
 MODULE REF_DUMP_MATVEC
   ! y = A x in the scatter form of the column layout (what the solver hands to
   ! DROP_STATES as its FMATVEC argument, KrylovSolver.f90:511,577-607)
@@ -73,14 +51,13 @@ CONTAINS
 END MODULE REF_DUMP_MATVEC
 
 PROGRAM REF_DUMP
-  USE REF_DUMP_RING
+  USE REF_CASES
   USE REF_DUMP_MATVEC
   USE STATESPACE
   USE KRYLOVSOLVER
   IMPLICIT NONE
 
   CHARACTER(LEN=256) :: MODE, ARG2, ARG3, ARG4, ARG5
-  INTEGER, PARAMETER :: TABLEN = 100009   ! prime, see StateSpace.f90:9
 
   CALL GET_COMMAND_ARGUMENT(1, MODE)
   CALL GET_COMMAND_ARGUMENT(2, ARG2)
@@ -112,52 +89,6 @@ PROGRAM REF_DUMP
   END SELECT
 
 CONTAINS
-
-  !---------------------------------------------------------------- helpers
-  SUBROUTINE WRITE_FSP(FNAME, MODEL, FSP)
-    CHARACTER(LEN=*), INTENT(IN) :: FNAME
-    TYPE(CME_MODEL), INTENT(IN) :: MODEL
-    TYPE(FINITE_STATE_PROJECTION), INTENT(IN) :: FSP
-    INTEGER :: U, N
-    N = FSP%SIZE
-    OPEN(NEWUNIT=U, FILE=FNAME, ACCESS='STREAM', FORM='UNFORMATTED', STATUS='REPLACE')
-    WRITE(U) MODEL%NSPECIES, MODEL%NREACTIONS, N
-    WRITE(U) FSP%STATE(1:MODEL%NSPECIES, 1:N)
-    WRITE(U) FSP%MATRIX%ADJ(1:MODEL%NREACTIONS, 1:N)
-    WRITE(U) FSP%MATRIX%OFFDIAG(1:MODEL%NREACTIONS, 1:N)
-    WRITE(U) FSP%MATRIX%DIAG(1:N)
-    WRITE(U) FSP%VECTOR(1:N)
-    CLOSE(U)
-  END SUBROUTINE WRITE_FSP
-
-  SUBROUTINE LOAD_INPUT_MODEL(NAME, MODEL, X0)
-    ! the three complete models/*.input files (keywords upper-cased by the
-    ! Makefile: ModelModule.f90:95-140 matches upper case only) with the
-    ! parameter values the reference's own drivers use.
-    CHARACTER(LEN=*), INTENT(IN) :: NAME
-    TYPE(CME_MODEL), INTENT(INOUT) :: MODEL
-    INTEGER, ALLOCATABLE, INTENT(OUT) :: X0(:)
-    SELECT CASE (NAME)
-    CASE ('toggle')
-       CALL MODEL%LOAD('toggle_model.input')
-       ! test/TestSolverFromFile.f90:31
-       CALL MODEL%RESET_PARAMETERS([1.0D0, 100.0D0, 1.0D0, 1.0D0, 100.0D0, 1.0D0])
-       X0 = [0, 0]
-    CASE ('repressilator')
-       CALL MODEL%LOAD('repressilator_model.input')
-       CALL MODEL%RESET_PARAMETERS([100.0D0, 100.0D0, 100.0D0, 1.0D0, 1.0D0, 1.0D0])
-       X0 = [22, 0, 0]          ! examples/repressilator.f90:36
-    CASE ('goutsias')
-       CALL MODEL%LOAD('goutsias_model.input')
-       ! examples/transcr6d.f90:23-32
-       CALL MODEL%RESET_PARAMETERS([0.043D0, 0.0007D0, 0.0715D0, 0.0039D0, &
-            0.0199264663575241D0, 0.4791D0, 0.000199264663575241D0, &
-            0.8765D0 * 1.0D-11, 0.0830269431563506104D0, 0.5D0])
-       X0 = [2, 6, 0, 2, 0, 0]  ! examples/transcr6d.f90:50
-    CASE DEFAULT
-       STOP 'ref_dump: unknown model'
-    END SELECT
-  END SUBROUTINE LOAD_INPUT_MODEL
 
   !---------------------------------------------------------------- G1
   SUBROUTINE DO_ASSEMBLY(NAME, KSTR, FNAME)
@@ -291,57 +222,12 @@ CONTAINS
     CHARACTER(LEN=*), INTENT(IN) :: CASENAME, FNAME
     TYPE(CME_MODEL) :: MODEL
     TYPE(FINITE_STATE_PROJECTION) :: FSP_IN, FSP
-    INTEGER, ALLOCATABLE :: X0(:)
     DOUBLE PRECISION :: T, FSPTOL, KRYTOL
-    INTEGER :: NMOL, N, I
+    INTEGER :: N
     ! the reference's drivers call this first (TestSolverFromFile.f90:19)
     CALL RANDOM_SEED()
 
-    SELECT CASE (CASENAME)
-    CASE ('toggle_input')
-       ! test/TestSolverFromFile.f90:35
-       CALL LOAD_INPUT_MODEL('toggle', MODEL, X0)
-       T = 1000.0D0; FSPTOL = 1.0D-4; KRYTOL = 1.0D-10
-       CALL SEED_POINT(MODEL, FSP_IN, FSP, X0)
-    CASE ('toggle_example')
-       ! examples/toggle.f90:14-48 (compiled-in propensities)
-       CALL MODEL%CREATE(2, 4, 6)
-       MODEL%STOICHIOMETRY = RESHAPE((/1, 0, -1, 0, 0, 1, 0, -1/), (/2, 4/))
-       MODEL%CUSTOMPROP => TOGGLE_EXAMPLE_PROP
-       CALL MODEL%RESET_PARAMETERS([1.0D0, 100.0D0, 1.0D0, 1.0D0, 100.0D0, 1.0D0])
-       MODEL%LOADED = .TRUE.
-       T = 100.0D0; FSPTOL = 1.0D-4; KRYTOL = 1.0D-8
-       X0 = [0, 0]
-       CALL SEED_POINT(MODEL, FSP_IN, FSP, X0)
-    CASE ('repressilator_input')
-       ! models/repressilator_model.input with the tolerances of toggle_input
-       CALL LOAD_INPUT_MODEL('repressilator', MODEL, X0)
-       T = 10.0D0; FSPTOL = 1.0D-4; KRYTOL = 1.0D-10
-       CALL SEED_POINT(MODEL, FSP_IN, FSP, X0)
-    CASE ('goutsias_input')
-       ! models/goutsias_model.input with the tolerances of examples/transcr6d.f90:16
-       CALL LOAD_INPUT_MODEL('goutsias', MODEL, X0)
-       T = 300.0D0; FSPTOL = 1.0D-6; KRYTOL = 1.0D-8
-       CALL SEED_POINT(MODEL, FSP_IN, FSP, X0)
-    CASE ('ring6')
-       ! closed 6-species ring, 8 molecules: every state is seeded, nothing
-       ! leaks and nothing is droppable, so the FSP never changes and the run
-       ! is a pure fixed-matrix adaptive expv (pins KrylovSolver.f90:206-550
-       ! with :509-534 idle).
-       RING_NS = 6; NMOL = 8
-       RING_CF = [1.00D0, 1.10D0, 0.90D0, 1.05D0, 0.95D0, 1.00D0]
-       RING_CB = [0.90D0, 1.00D0, 1.10D0, 0.95D0, 1.05D0, 1.00D0]
-       T = 60.0D0; FSPTOL = 1.0D-4; KRYTOL = 1.0D-10
-       CALL SEED_RING(MODEL, FSP_IN, FSP, NMOL)
-    CASE ('ring4')
-       RING_NS = 4; NMOL = 12
-       RING_CF = [2.00D0, 1.50D0, 1.80D0, 2.20D0, 0.0D0, 0.0D0]
-       RING_CB = [1.70D0, 2.10D0, 1.60D0, 1.90D0, 0.0D0, 0.0D0]
-       T = 50.0D0; FSPTOL = 1.0D-6; KRYTOL = 1.0D-8
-       CALL SEED_RING(MODEL, FSP_IN, FSP, NMOL)
-    CASE DEFAULT
-       STOP 'ref_dump: unknown solve case'
-    END SELECT
+    CALL SETUP_SOLVE_CASE(CASENAME, MODEL, FSP_IN, FSP, T, FSPTOL, KRYTOL)
 
     ! optional 4th argument overrides the end time (used when bisecting a
     ! trajectory against the restatement)
@@ -355,83 +241,6 @@ CONTAINS
     PRINT *, 'FINAL SIZE', N
     PRINT *, 'FINAL SUM ', SUM(FSP%VECTOR(1:N))
   END SUBROUTINE DO_SOLVE
-
-  SUBROUTINE SEED_POINT(MODEL, FSP_IN, FSP, X0)
-    TYPE(CME_MODEL), INTENT(IN) :: MODEL
-    TYPE(FINITE_STATE_PROJECTION), INTENT(INOUT) :: FSP_IN, FSP
-    INTEGER, INTENT(IN) :: X0(:)
-    CALL FSP_IN%CREATE(MODEL, TABLEN)
-    CALL FSP%CREATE(MODEL, TABLEN)
-    FSP_IN%SIZE = 1
-    FSP_IN%STATE(:, 1) = X0
-    FSP_IN%VECTOR = 0.0D0
-    FSP_IN%VECTOR(1) = 1.0D0
-    FSP = FSP_IN                  ! as the drivers do (toggle.f90:45)
-  END SUBROUTINE SEED_POINT
-
-  SUBROUTINE SEED_RING(MODEL, FSP_IN, FSP, NMOL)
-    TYPE(CME_MODEL), INTENT(INOUT) :: MODEL
-    TYPE(FINITE_STATE_PROJECTION), INTENT(INOUT) :: FSP_IN, FSP
-    INTEGER, INTENT(IN) :: NMOL
-    INTEGER :: NS, I, K, N, X(6), S
-    DOUBLE PRECISION :: TOT
-    NS = RING_NS
-    CALL MODEL%CREATE(NS, 2 * NS, 2 * NS)
-    MODEL%STOICHIOMETRY = 0
-    DO I = 1, NS
-       K = MOD(I, NS) + 1
-       ! reaction 2i-1 : S_i -> S_{i+1} ; reaction 2i : S_{i+1} -> S_i
-       MODEL%STOICHIOMETRY(I, 2 * I - 1) = -1
-       MODEL%STOICHIOMETRY(K, 2 * I - 1) = 1
-       MODEL%STOICHIOMETRY(K, 2 * I) = -1
-       MODEL%STOICHIOMETRY(I, 2 * I) = 1
-    ENDDO
-    MODEL%CUSTOMPROP => RING_PROP
-    MODEL%PARAMETER_VAL = 0.0D0
-    MODEL%LOADED = .TRUE.
-    CALL FSP_IN%CREATE(MODEL, TABLEN)
-    CALL FSP%CREATE(MODEL, TABLEN)
-    ! enumerate every composition of NMOL into NS parts (odometer on the
-    ! first NS-1 coordinates)
-    N = 0
-    X = 0
-    DO
-       S = SUM(X(1:NS - 1))
-       IF (S <= NMOL) THEN
-          N = N + 1
-          FSP_IN%STATE(1:NS - 1, N) = X(1:NS - 1)
-          FSP_IN%STATE(NS, N) = NMOL - S
-       ENDIF
-       I = 1
-       DO WHILE (I <= NS - 1)
-          X(I) = X(I) + 1
-          IF (X(I) <= NMOL) EXIT
-          X(I) = 0
-          I = I + 1
-       ENDDO
-       IF (I > NS - 1) EXIT
-    ENDDO
-    FSP_IN%SIZE = N
-    FSP_IN%VECTOR = 0.0D0
-    TOT = 0.0D0
-    DO I = 1, N
-       FSP_IN%VECTOR(I) = 1.0D0 + 0.5D0 * SIN(DBLE(I))
-       TOT = TOT + FSP_IN%VECTOR(I)
-    ENDDO
-    FSP_IN%VECTOR(1:N) = FSP_IN%VECTOR(1:N) / TOT
-    FSP = FSP_IN
-  END SUBROUTINE SEED_RING
-
-  DOUBLE PRECISION FUNCTION TOGGLE_EXAMPLE_PROP(STATE, REACTION, PARAMETERS)
-    ! the propensities of examples/toggle.f90:55-69, restated
-    INTEGER, INTENT(IN) :: STATE(:), REACTION
-    DOUBLE PRECISION, INTENT(IN), OPTIONAL :: PARAMETERS(:)
-    TOGGLE_EXAMPLE_PROP = 0.0D0
-    IF (REACTION == 1) TOGGLE_EXAMPLE_PROP = PARAMETERS(1) + PARAMETERS(2) / (1D0 + STATE(2)**1.5D0)
-    IF (REACTION == 2) TOGGLE_EXAMPLE_PROP = PARAMETERS(3) * STATE(1)
-    IF (REACTION == 3) TOGGLE_EXAMPLE_PROP = PARAMETERS(4) + PARAMETERS(5) / (1D0 + STATE(1)**3.5D0)
-    IF (REACTION == 4) TOGGLE_EXAMPLE_PROP = PARAMETERS(6) * STATE(2)
-  END FUNCTION TOGGLE_EXAMPLE_PROP
 
   !---------------------------------------------------------------- G5
   SUBROUTINE DO_PADM(FNAME)
