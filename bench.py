@@ -13,9 +13,18 @@ of ranks, rows are partitioned contiguously, no data-path collective except the
 all-gather the path itself has).  value = algorithmic GB/s of the whole job,
 B_alg = 12 nnz + 20 N per launch.
 
+With --gpus N > 1 and no launcher (WORLD_SIZE unset) the script starts its N ranks itself:
+child processes of this same file, one per GPU, created BEFORE anything here touches the
+GPU; rank 0's JSON line is relayed.  Under torch.distributed.run it joins the ranks it is given.
+
 The same JSON line carries
   roofline      the SpMV kernel against the HBM roofline (HIP events on the
-                library's own stream, measured over the timed region)
+                library's own stream, measured over the timed region): `frac` is the
+                SURVEY 8(d) figure (CSR algorithmic bytes / time / peak); `frac_traffic` the
+                same with the bytes the kernel's own layout moves (the banded form stores no
+                column indices, so this is the physically meaningful fraction)
+  self_check    the product that is timed, checked in this process against numpy on sampled
+                rows of every rank (always, also on one GPU)
   expv          the exp(tA)v half of the metric: BASELINE configs[1] (toggle box
                 10^6 states per GPU, Krylov m = 30, tau = 0.01, 10 steps) wall
                 time per step and its l1 error against the CPU path
@@ -74,15 +83,48 @@ def spmv_model(workload, nranks):
     return synth.repressilator(dims=(40, 40, 40 * nranks)), "tiny repressilator box 40x40x(40*ranks)"
 
 
+def spawn_ranks(nranks, argv, script=None, env=None, popen=None):
+    """Start `nranks` copies of this script as child processes, one per GPU (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR / MASTER_PORT in their environment, as torch.distributed.run would
+    set them), wait for all, relay rank 0's stdout (the JSON line).  The parent never touches the
+    GPU and never exec()s.  -> exit code (0 only if every rank succeeded)."""
+    import socket
+    import subprocess
+    popen = popen or subprocess.Popen
+    script = script or os.path.abspath(__file__)
+    base = dict(os.environ if env is None else env)
+    if "MASTER_PORT" not in base:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            base["MASTER_PORT"] = str(s.getsockname()[1])
+    base.setdefault("MASTER_ADDR", "127.0.0.1")
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = []
+    for r in range(nranks):
+        e = dict(base, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nranks), LOCAL_WORLD_SIZE=str(nranks))
+        procs.append(popen([sys.executable, script] + list(argv), env=e,
+                           stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    if out0:
+        sys.stdout.write(out0.decode() if isinstance(out0, bytes) else out0)
+        sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        print(f"[bench] ranks failed: {bad}", file=sys.stderr)
+        return 1
+    return 0
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: be our own launcher (before torch / HIP are even imported)
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched by torch.distributed.run with N ranks")
-        args.gpus = world
+    args.gpus = world
 
     # stdout must carry exactly one JSON line, but RCCL writes its version banner
     # and topology warnings there: keep the real stdout aside and point fd 1 at
@@ -146,54 +188,60 @@ def main():
     b_alg_global = synth.spmv_alg_bytes(nnz_global, mdl.n)
     b_alg_local = synth.spmv_alg_bytes(nnz_local, nrows)
 
-    def distributed_product_ok():
-        """y = A x through the solver's own exchange (halo strips or all-gather)
-        against numpy on a sample of this rank's rows; collective verdict."""
+    def product_check():
+        """y = A x through the solver's own path (plain launch on one rank; halo strips or
+        all-gather with more) against numpy on a sample of this rank's rows.
+        -> worst relative error over all ranks (inf: the product did not run on some rank)."""
+        failed = None
         try:
             y = ctx.spmv_w()
-        except RuntimeError as e:                 # an exchange mode that does not even run counts as failed
-            print(f"[bench] rank {rank}: product failed in this exchange mode: {e}", file=sys.stderr)
+        except RuntimeError as e:
+            failed = e
             y = None
         if world > 1:
+            # a rank whose product raised has left the library's communicator out of step with
+            # the others: no fallback is possible on it - every rank learns of it and stops
+            if max_over_ranks(1.0 if failed is not None else 0.0) > 0.0:
+                print(f"[bench] rank {rank}: product failed ({failed}); aborting all ranks", file=sys.stderr)
+                sys.exit(3)
             xs = torch.zeros(L, dtype=torch.float64, device="cuda")
             xs[:nrows] = torch.from_numpy(x).cuda()
             xall = torch.zeros(world * L, dtype=torch.float64, device="cuda")
             dist.all_gather_into_tensor(xall, xs)
             xg = xall.cpu().numpy()
         else:
+            if failed is not None:
+                raise failed
             xg = x
         bad = 0.0
-        if y is None:
-            bad = float("inf")
-        elif nrows > 0:
+        if nrows > 0:
             rows = np.unique(np.concatenate([np.arange(min(nrows, 256)), np.arange(max(nrows - 256, 0), nrows),
                                              np.random.default_rng(7).integers(0, nrows, 2048)]))
             ref = np.array([val[rowptr[r]:rowptr[r + 1]] @ xg[col[rowptr[r]:rowptr[r + 1]]] for r in rows])
             mag = np.array([np.abs(val[rowptr[r]:rowptr[r + 1]]) @ np.abs(xg[col[rowptr[r]:rowptr[r + 1]]]) for r in rows])
             bad = float(np.max(np.abs(y[rows] - ref) / (mag + 1e-300)))
-        return max_over_ranks(bad) < 1e-12
+        return max_over_ranks(bad)
 
-    L = 0
+    from krylovfspssa_amd import host as _host
+    L = _host.partition(mdl.n, world, rank)[2]
     exchange = "none (single rank)"
+    check_err = product_check()
     if world > 1 or args.force_comm:
-        from krylovfspssa_amd import host as _host
-        L = _host.partition(mdl.n, world, rank)[2]
         exchange = "halo strips (banded generator), overlapped with the interior rows when the block is large"
         # never report a number from a wrong product: step down to the simpler exchanges
         for opt, label in (("overlap", "halo strips, not overlapped (overlap self-check failed)"),
                            ("halo", "all-gather of the whole vector (halo self-check failed)")):
-            if distributed_product_ok():
+            if check_err < 1e-12:
                 break
             ctx.set_option(opt, 0)
             ctx.set_matrix_csr(mdl.n, rowptr, col, val)
             ctx.set_vector(x)
             ctx.begin_step()
             exchange = label
-        else:
-            if not distributed_product_ok():
-                exchange = "all-gather; SELF-CHECK FAILED"
-        ctx.set_vector(x)
-        ctx.begin_step()
+            check_err = product_check()
+    check_ok = check_err < 1e-12
+    ctx.set_vector(x)
+    ctx.begin_step()
 
     ctx.spmv_bench(max(args.warmup, 1), args.variant)
     barrier()
@@ -206,11 +254,18 @@ def main():
     kern_ms = ms_events / args.steps
     achieved = b_alg_local / (kern_ms * 1e-3) / 1e9
 
-    traffic = None
+    # bytes the kernel's own layout moves per launch (kfsp_matrix_bytes) and, when this run is the
+    # profiled configuration, the HBM bytes rocprofv3 counted for it (profiles/, NOT this run)
+    real_bytes = ctx.matrix_bytes(force_sell=(args.variant == 2)) if args.variant != 1 else None
+    traffic, traffic_src = None, None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tpath):
+    plain_run = world == 1 and not args.opt and not args.force_comm and args.variant in (0, 2)
+    if plain_run and os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(args.workload, {}).get("hbm_bytes_per_launch")
+            key = args.workload + ("_sell64" if args.variant == 2 else "")
+            traffic = json.load(open(tpath)).get(key, {}).get("hbm_bytes_per_launch")
+            if traffic is not None:
+                traffic_src = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, not this run)"
         except Exception:
             traffic = None
 
@@ -236,14 +291,20 @@ def main():
             "kernel_variant": {0: "auto (banded DIA when the rows allow it, else SELL-64)", 1: "csr_stream", 2: "sell64"}[args.variant],
             "stored_slots_local": info["slots"],
         },
+        "self_check": {"ok": bool(check_ok), "max_rel_err": check_err,
+                       "what": "the timed product (same context, same exchange) vs numpy on 2.5k sampled rows per rank"},
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "kernel": "k_spmv", "avg_launch_ms": round(kern_ms, 5),
             "alg_bytes_per_launch": int(b_alg_local),
-            "note": "per-GPU algorithmic bytes (CSR figure 12 nnz + 20 N, SURVEY 8d) / HIP-event time of the timed "
-                    "launches; the banded kernel stores no column indices, so its real traffic (see traffic) is ~0.7x "
-                    "the algorithmic bytes and frac can approach or exceed 1"
+            "real_bytes_per_launch": real_bytes,
+            "real_GBps": None if real_bytes is None else round(real_bytes / (kern_ms * 1e-3) / 1e9, 2),
+            "frac_traffic": None if real_bytes is None else round(real_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "note": "achieved/frac: per-GPU algorithmic bytes (CSR figure 12 nnz + 20 N, SURVEY 8d) / HIP-event time of "
+                    "the timed launches.  The banded kernel stores no column indices, so it moves fewer bytes than "
+                    "that: real_bytes_per_launch is the layout's own byte count (generator as stored + 24 B/row), "
+                    "frac_traffic = real_GBps / peak is the fraction of HBM bandwidth actually sustained"
                     + ("; includes the exchange of the source vector" if world > 1 else ""),
         },
         "input_generation_s": round(t_gen, 2),
@@ -325,6 +386,9 @@ def main():
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.destroy_process_group()
+    if not check_ok:
+        print(f"[bench] SELF-CHECK FAILED: max relative error {check_err:.3e}", file=sys.stderr)
+        sys.exit(4)
 
 
 if __name__ == "__main__":

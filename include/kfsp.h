@@ -52,6 +52,16 @@ int kfsp_abi_version(void);
  *   [rank*L, min((rank+1)*L, n)),  L = ceil(n / nranks) rounded up to 64. */
 int kfsp_comm_unique_id(void *id_bytes /* [KFSP_UNIQUE_ID_BYTES] */);
 int kfsp_comm_init(kfsp_ctx *ctx, int nranks, int rank, const void *id_bytes);
+/* Loop-back transport for boxes with ONE GPU: nranks contexts of one process (all of them may sit
+ * on the same device), each driven by its own host thread, form a group whose collectives are host
+ * barriers around device copies.  Everything around the collective - strip packing, halo margins,
+ * split interior/boundary launches, staged scalars, the row-block arithmetic for rank > 0 - is the
+ * code that runs over RCCL.  For tests; not a performance path.  Calls on the contexts of a group
+ * must be made by all ranks in the same order (as with RCCL); a rank that never arrives makes the
+ * others fail with code 2999 after 120 s. */
+int kfsp_loopback_create(int nranks, void **group);
+int kfsp_loopback_destroy(void *group);   /* after the contexts that used it */
+int kfsp_comm_init_loopback(kfsp_ctx *ctx, void *group, int rank);
 int kfsp_row_block(const kfsp_ctx *ctx, int64_t n, int64_t *row0, int64_t *nrows);
 /* the same arithmetic without a context (host only; usable without a GPU):
  * block of `rank` out of `nranks` for n states, and the padded block length L */
@@ -94,6 +104,12 @@ int kfsp_set_matrix_csr(kfsp_ctx *ctx, int64_t n, int64_t row0, int64_t nrows,
 /* what the device holds: rows (local), stored off-diagonal slots incl. padding,
  * true nonzeros incl. diagonal (local rows) */
 int kfsp_matrix_info(const kfsp_ctx *ctx, int64_t *nrows, int64_t *slots, int64_t *nnz);
+/* HBM bytes ONE product launch has to move for the layout the device holds (local rows): the
+ * stored generator (banded: 8 B per stored diagonal entry, minus the empty 128-row segments the
+ * masked kernel skips, plus its mask words; SELL-64: 12 B per slot incl. padding plus chunk
+ * offsets) + 24 B per row (DIAG, x once, y).  x re-fetches are not in it; the rocprofv3 counters
+ * are.  force_sell = 1: the figure for kfsp_spmv_bench variant 2. */
+int kfsp_matrix_bytes(const kfsp_ctx *ctx, int force_sell, int64_t *bytes);
 /* global number of states of the generator last set (FSP%SIZE) */
 int kfsp_num_states(const kfsp_ctx *ctx, int64_t *n);
 

@@ -143,6 +143,55 @@ void set_matrix_args(const kfsp_ctx *c, SpmvArgs &a)
     a.partial2 = nullptr;
 }
 
+// ---- the two collectives of the data path, over RCCL or the loop-back transport ----
+constexpr int kLoopScratch = 64 * 4;   // doubles: up to 64 ranks x 3 scalars (+ result)
+
+// buf[0..count) <- sum (or max) over ranks, in place, on stream st
+int comm_allreduce(kfsp_ctx *ctx, double *buf, int count, bool take_max, hipStream_t st)
+{
+    if (!ctx->loop) {
+        NCCL_TRY(ncclAllReduce(buf, buf, (size_t)count, ncclDouble, take_max ? ncclMax : ncclSum, ctx->comm, st));
+        return 0;
+    }
+    kfsp::LoopGroup *g = ctx->loop;
+    if (count > 3 || g->n > 64) return fail(ctx, -1, "loop-back all-reduce: too many values");
+    HIP_TRY(hipStreamSynchronize(st));                  // this rank's contribution is in memory
+    g->slot[(size_t)ctx->rank] = buf;
+    if (!g->barrier()) return fail(ctx, 2999, "loop-back barrier timed out");
+    double *h = ctx->h_loop;
+    for (int p = 0; p < g->n; ++p)
+        HIP_TRY(hipMemcpyAsync(h + 4 * p, g->slot[(size_t)p], (size_t)count * sizeof(double), hipMemcpyDefault, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (!g->barrier()) return fail(ctx, 2999, "loop-back barrier timed out");   // everyone has read
+    double *r = h + 4 * g->n;
+    for (int i = 0; i < count; ++i) {
+        double a = h[i];
+        for (int p = 1; p < g->n; ++p) a = take_max ? std::max(a, h[4 * p + i]) : a + h[4 * p + i];   // rank order: same bits on every rank
+        r[i] = a;
+    }
+    HIP_TRY(hipMemcpyAsync(buf, r, (size_t)count * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
+// recv[p*count .. (p+1)*count) <- send of rank p, on stream st
+int comm_allgather(kfsp_ctx *ctx, const double *send, double *recv, size_t count, hipStream_t st)
+{
+    if (!ctx->loop) {
+        NCCL_TRY(ncclAllGather(send, recv, count, ncclDouble, ctx->comm, st));
+        return 0;
+    }
+    kfsp::LoopGroup *g = ctx->loop;
+    HIP_TRY(hipStreamSynchronize(st));
+    g->slot[(size_t)ctx->rank] = send;
+    if (!g->barrier()) return fail(ctx, 2999, "loop-back barrier timed out");
+    for (int p = 0; p < g->n; ++p)
+        HIP_TRY(hipMemcpyAsync(recv + (size_t)p * count, g->slot[(size_t)p], count * sizeof(double), hipMemcpyDefault, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (!g->barrier()) return fail(ctx, 2999, "loop-back barrier timed out");   // nobody reuses its send buffer before all have copied
+    return 0;
+}
+
 // Make block partials a scalar every rank agrees on.
 int publish(kfsp_ctx *ctx, Pending local, Pending *out)
 {
@@ -153,7 +202,7 @@ int publish(kfsp_ctx *ctx, Pending local, Pending *out)
     double *st = ctx->d_stage.p + ctx->stage_rr;
     ctx->stage_rr = (ctx->stage_rr + 1) % kNumStage;
     launch_finalize(local, st, nullptr, ctx->stream);
-    NCCL_TRY(ncclAllReduce(st, st, 1, ncclDouble, ncclSum, ctx->comm, ctx->stream));
+    if (int rc = comm_allreduce(ctx, st, 1, false, ctx->stream)) return rc;
     *out = Pending{st, 1};
     return 0;
 }
@@ -257,7 +306,7 @@ int publish_n(kfsp_ctx *ctx, const Pending *local, int k, Pending *out)
     double *st = ctx->d_stage.p + ctx->stage_rr;
     ctx->stage_rr = (ctx->stage_rr + k) % kNumStage;
     for (int i = 0; i < k; ++i) launch_finalize(local[i], st + i, nullptr, ctx->stream);
-    NCCL_TRY(ncclAllReduce(st, st, (size_t)k, ncclDouble, ncclSum, ctx->comm, ctx->stream));
+    if (int rc = comm_allreduce(ctx, st, k, false, ctx->stream)) return rc;
     for (int i = 0; i < k; ++i) out[i] = Pending{st + i, 1};
     return 0;
 }
@@ -274,7 +323,7 @@ int exchange_strips(kfsp_ctx *ctx, const double *src_local, hipStream_t st)
     double *send = ctx->d_strip.p, *recv = ctx->d_strip.p + 2 * H;
     HIP_TRY(hipMemcpyAsync(send, src_local, (size_t)H * sizeof(double), hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemcpyAsync(send + H, src_local + (L - H), (size_t)H * sizeof(double), hipMemcpyDeviceToDevice, st));
-    NCCL_TRY(ncclAllGather(send, recv, (size_t)(2 * H), ncclDouble, ctx->comm, st));
+    if (int rc = comm_allgather(ctx, send, recv, (size_t)(2 * H), st)) return rc;
     double *col = const_cast<double *>(src_local);
     if (ctx->rank > 0)                 // the previous rank's LAST rows sit just below row 0
         HIP_TRY(hipMemcpyAsync(col - H, recv + (size_t)(ctx->rank - 1) * 2 * H + H, (size_t)H * sizeof(double),
@@ -297,7 +346,7 @@ int gather_source(kfsp_ctx *ctx, const double *src_local, const double **xg)
         *xg = src_local - ctx->row0;       // global index g lives at src_local[g - row0]
         return 0;
     }
-    NCCL_TRY(ncclAllGather(src_local, ctx->d_xg.p, (size_t)ctx->L, ncclDouble, ctx->comm, ctx->stream));
+    if (int rc = comm_allgather(ctx, src_local, ctx->d_xg.p, (size_t)ctx->L, ctx->stream)) return rc;
     *xg = ctx->d_xg.p;
     return 0;
 }
@@ -317,7 +366,7 @@ int setup_exchange(kfsp_ctx *ctx)
     double h[2] = {ok_local ? 0.0 : 1.0, (double)reach};          // max over ranks of (not ok, reach)
     double *st = ctx->d_stage.p;
     HIP_TRY(hipMemcpyAsync(st, h, sizeof(h), hipMemcpyHostToDevice, ctx->stream));
-    NCCL_TRY(ncclAllReduce(st, st, 2, ncclDouble, ncclMax, ctx->comm, ctx->stream));
+    if (int rc = comm_allreduce(ctx, st, 2, true, ctx->stream)) return rc;
     HIP_TRY(hipMemcpyAsync(h, st, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     const int64_t H = round_up(std::max<int64_t>((int64_t)h[1], 1), 8);
@@ -613,6 +662,7 @@ int kfsp_destroy(kfsp_ctx *ctx)
     ctx->d_perm.release(); ctx->d_iperm.release(); ctx->d_coords.release(); ctx->d_ell_adj2.release();
     ctx->d_ell_off2.release(); ctx->d_ell_diag2.release(); ctx->d_pstage.release(); ctx->d_keys.release();
     ctx->d_sortidx.release(); ctx->d_sorttmp.release(); ctx->d_gmask.release(); ctx->d_zero.release();
+    if (ctx->h_loop) (void)hipHostFree(ctx->h_loop);
     if (ctx->h_H) (void)hipHostFree(ctx->h_H);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -646,6 +696,7 @@ int kfsp_comm_init(kfsp_ctx *ctx, int nranks, int rank, const void *id_bytes)
         (void)ncclCommDestroy(ctx->comm);
         ctx->comm = nullptr;
     }
+    ctx->loop = nullptr;
     ctx->nranks = nranks;
     ctx->rank = rank;
     // a unique id with nranks == 1 still creates a (one-rank) communicator, so the
@@ -661,6 +712,51 @@ int kfsp_comm_init(kfsp_ctx *ctx, int nranks, int rank, const void *id_bytes)
             HIP_TRY(hipEventCreateWithFlags(&ctx->ev_src, hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&ctx->ev_halo, hipEventDisableTiming));
         }
+    }
+    ctx->ldv = 0;   // force re-layout on the next matrix
+    ctx->use_halo = false;
+    return 0;
+}
+
+int kfsp_loopback_create(int nranks, void **group)
+{
+    if (nranks < 1 || nranks > 64) return -1;
+    if (!group) return -2;
+    kfsp::LoopGroup *g = new (std::nothrow) kfsp::LoopGroup;
+    if (!g) return 4001;
+    g->n = nranks;
+    g->slot.assign((size_t)nranks, nullptr);
+    *group = g;
+    return 0;
+}
+
+int kfsp_loopback_destroy(void *group)
+{
+    delete static_cast<kfsp::LoopGroup *>(group);
+    return 0;
+}
+
+int kfsp_comm_init_loopback(kfsp_ctx *ctx, void *group, int rank)
+{
+    if (!ctx) return -1;
+    if (!group) return fail(ctx, -2, "null group");
+    kfsp::LoopGroup *g = static_cast<kfsp::LoopGroup *>(group);
+    if (rank < 0 || rank >= g->n) return fail(ctx, -3, "rank out of range");
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (ctx->comm) {
+        (void)ncclCommDestroy(ctx->comm);
+        ctx->comm = nullptr;
+    }
+    ctx->loop = g;
+    ctx->nranks = g->n;
+    ctx->rank = rank;
+    ctx->use_comm = true;
+    if (!ctx->h_loop)
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_loop), (size_t)(kLoopScratch + 8) * sizeof(double), hipHostMallocDefault));
+    if (!ctx->comm_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&ctx->ev_src, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ctx->ev_halo, hipEventDisableTiming));
     }
     ctx->ldv = 0;   // force re-layout on the next matrix
     ctx->use_halo = false;
@@ -863,6 +959,23 @@ int kfsp_matrix_info(const kfsp_ctx *ctx, int64_t *nrows, int64_t *slots, int64_
     if (nrows) *nrows = ctx->nloc;
     if (slots) *slots = ctx->use_dia ? (int64_t)ctx->nd * ctx->dia_ld : ctx->slots;
     if (nnz) *nnz = ctx->nnz;
+    return 0;
+}
+
+int kfsp_matrix_bytes(const kfsp_ctx *ctx, int force_sell, int64_t *bytes)
+{
+    if (!ctx) return -1;
+    if (!bytes) return -3;
+    if (ctx->ldv == 0) return -1;
+    const int64_t rows = ctx->nchunks * kChunk;
+    int64_t b = rows * 24;                                    // diag, x (once), y
+    if (ctx->use_dia && !force_sell) {
+        b += (int64_t)ctx->nd * ctx->dia_ld * 8;
+        if (ctx->dia_masked) b += (ctx->dia_ld >> 7) * 4 - ctx->dia_empty_segments * 128 * 8;
+    } else {
+        b += ctx->slots * 12 + (ctx->nchunks + 1) * 8;
+    }
+    *bytes = b;
     return 0;
 }
 

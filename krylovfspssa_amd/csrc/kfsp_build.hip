@@ -495,6 +495,7 @@ int build_from_ell_device(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, cons
 int build_dia_mask(kfsp_ctx *ctx)
 {
     ctx->dia_masked = false;
+    ctx->dia_empty_segments = 0;
     if (!ctx->use_dia || !ctx->opt_dia_mask || ctx->nd < 1) return 0;
     hipStream_t st = ctx->stream;
     const int64_t ngroups = ctx->dia_ld >> 7;
@@ -511,6 +512,7 @@ int build_dia_mask(kfsp_ctx *ctx)
     HIP_TRY_B(hipStreamSynchronize(st));
     // the masked variant trades a little address arithmetic for the skipped bytes: worth it from ~3 % on
     ctx->dia_masked = (double)empty >= 0.03 * (double)ctx->nd * (double)ngroups;
+    ctx->dia_empty_segments = (int64_t)empty;
     return 0;
 }
 

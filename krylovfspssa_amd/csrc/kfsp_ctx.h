@@ -8,6 +8,9 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -46,6 +49,34 @@ struct DevBuf {
 
 inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 
+// Loop-back transport: the ranks of a row partition are contexts of ONE process, each
+// driven by its own host thread, and "collectives" are host barriers around plain device
+// copies.  Everything above the collective itself - packing the strips, dropping the
+// neighbours' strips into the halo margins, the split interior / boundary launches, the
+// staged scalars - is the code that runs over RCCL, so a one-GPU box exercises the
+// rank > 0 branches.  Not a performance path.
+struct LoopGroup {
+    int n = 0;
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0;
+    uint64_t generation = 0;
+    std::vector<const void *> slot;   // what each rank contributes to the collective in flight
+    // false = a peer did not arrive within 120 s (its thread died): the caller reports an error
+    bool barrier()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        const uint64_t gen = generation;
+        if (++arrived == n) {
+            arrived = 0;
+            ++generation;
+            cv.notify_all();
+            return true;
+        }
+        return cv.wait_for(lk, std::chrono::seconds(120), [&] { return generation != gen; });
+    }
+};
+
 }  // namespace kfsp
 
 using kfsp::DevBuf;
@@ -60,6 +91,8 @@ struct kfsp_ctx {
     // partition
     int nranks = 1, rank = 0;
     ncclComm_t comm = nullptr;
+    kfsp::LoopGroup *loop = nullptr;   // loop-back transport instead of RCCL (kfsp_comm_init_loopback)
+    double *h_loop = nullptr;          // its pinned scratch
     bool use_comm = false;   // collectives on the data path (nranks > 1, or a 1-rank communicator for testing)
     // halo exchange instead of the full all-gather (banded generators only):
     // every basis column carries `margin` rows on either side that receive the
@@ -96,6 +129,7 @@ struct kfsp_ctx {
     DevBuf<uint32_t> d_gmask;
     DevBuf<double> d_zero;   // 128 zeros, the stand-in for an empty segment
     bool dia_masked = false;
+    int64_t dia_empty_segments = 0;   // (diagonal, 128-row group) pairs without entries
     // device-side build from the reference layout (kfsp_build.hip)
     DevBuf<int32_t> d_ell_adj, d_cnt, d_ticket;
     DevBuf<double> d_ell_off, d_ell_diag;

@@ -44,6 +44,9 @@ def load_library():
         "kfsp_abi_version": [],
         "kfsp_comm_unique_id": [vp],
         "kfsp_comm_init": [vp, C.c_int, C.c_int, vp],
+        "kfsp_loopback_create": [C.c_int, C.POINTER(vp)],
+        "kfsp_loopback_destroy": [vp],
+        "kfsp_comm_init_loopback": [vp, vp, C.c_int],
         "kfsp_row_block": [vp, i64, C.POINTER(i64), C.POINTER(i64)],
         "kfsp_partition": [i64, C.c_int, C.c_int, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)],
         "kfsp_set_matrix_ell": [vp, i32, i32, i32, vp, vp, vp],
@@ -51,6 +54,7 @@ def load_library():
         "kfsp_set_state_coords": [vp, i32, i32, i32, vp],
         "kfsp_state_order_active": [vp, C.POINTER(C.c_int)],
         "kfsp_matrix_info": [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)],
+        "kfsp_matrix_bytes": [vp, C.c_int, C.POINTER(i64)],
         "kfsp_num_states": [vp, C.POINTER(i64)],
         "kfsp_dgexpv": [vp, dbl, dbl, dbl, C.c_int, vp, vp],
         "kfsp_set_vector": [vp, i64, vp],
@@ -129,6 +133,50 @@ def partition(n, nranks, rank):
     return r0.value, nr.value, L.value
 
 
+class LoopbackGroup:
+    """kfsp_loopback_create: nranks contexts of this process exchanging through device copies
+    (one-GPU rehearsal of the row partition; see include/kfsp.h)."""
+
+    def __init__(self, nranks):
+        self.handle = C.c_void_p()
+        rc = load_library().kfsp_loopback_create(int(nranks), C.byref(self.handle))
+        if rc:
+            raise KfspError(f"kfsp_loopback_create -> {rc}")
+        self.nranks = int(nranks)
+
+    def close(self):
+        if self.handle:
+            load_library().kfsp_loopback_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+
+def run_loopback_ranks(nranks, body, device=0):
+    """body(ctx, rank) on nranks contexts of one loop-back group, one thread per rank (ctypes
+    releases the GIL inside the library); returns the list of results, re-raises the first error."""
+    import threading
+    group = LoopbackGroup(nranks)
+    results, errors = [None] * nranks, [None] * nranks
+
+    def work(rank):
+        try:
+            with KfspContext(device) as ctx:
+                ctx.comm_init_loopback(group, rank)
+                results[rank] = body(ctx, rank)
+        except BaseException as e:   # noqa: BLE001 - reported to the caller below
+            errors[rank] = e
+
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(nranks)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    group.close()
+    for e in errors:
+        if e is not None:
+            raise e
+    return results
+
+
 class KfspContext:
     """One device context = one rank's share of the solver workspace."""
 
@@ -180,6 +228,11 @@ class KfspContext:
         self._chk(self._lib.kfsp_comm_init(self._h, nranks, rank, None if buf is None else _p(buf)), "kfsp_comm_init")
         self.nranks, self.rank = nranks, rank
 
+    def comm_init_loopback(self, group, rank):
+        """Join a LoopbackGroup (ranks = contexts of this process, one host thread each)."""
+        self._chk(self._lib.kfsp_comm_init_loopback(self._h, group.handle, int(rank)), "kfsp_comm_init_loopback")
+        self.nranks, self.rank = group.nranks, int(rank)
+
     def row_block(self, n):
         r0, nr = C.c_int64(0), C.c_int64(0)
         self._chk(self._lib.kfsp_row_block(self._h, int(n), C.byref(r0), C.byref(nr)), "kfsp_row_block")
@@ -229,6 +282,11 @@ class KfspContext:
         return dict(rows=a.value, slots=b.value, nnz=c.value)
 
     # -- vectors
+    def matrix_bytes(self, force_sell=False):
+        b = C.c_int64(0)
+        self._chk(self._lib.kfsp_matrix_bytes(self._h, int(bool(force_sell)), C.byref(b)), "kfsp_matrix_bytes")
+        return b.value
+
     def set_vector(self, w):
         w = np.ascontiguousarray(w, dtype=np.float64)
         self._chk(self._lib.kfsp_set_vector(self._h, len(w), _p(w)), "kfsp_set_vector")
