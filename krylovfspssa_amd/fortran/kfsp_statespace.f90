@@ -1268,4 +1268,39 @@ CONTAINS
     CALL TICK(5, TCLK)
   END SUBROUTINE SSA_EXTENDER_STREAMS
 
+  ! COMPUTE_RKEY (StateSpace.f90:635-669): the change of the reference's POSITIONAL state key,
+  ! key(x) = 2 + sum_k x_k (MAXNUMBERMOLECULES + 1)**(k-1) (HashTable.f90:39-59), under each
+  ! reaction: key(x + nu_j) = key(x) + RKEYSIGN(j) * REACTIONKEY(j).  Same arguments and the same
+  ! integers as the reference returns; its 35-digit BIG_INTEGER is INTEGER(16) here (10001**9 <
+  ! 2**127 covers nine species; more raise an error).  This module does not use positional keys
+  ! itself (FSP%KEY holds 64-bit hashes, the table compares states), the routine is kept for
+  ! drivers that call it.
+  SUBROUTINE COMPUTE_RKEY(REACTIONKEY, RKEYSIGN, SD, PD, MODEL)
+    INTEGER :: SD, PD
+    INTEGER(16) :: REACTIONKEY(PD)
+    INTEGER :: RKEYSIGN(PD)
+    TYPE(CME_MODEL), INTENT(IN) :: MODEL
+    INTEGER :: I, J, RS(SD), SGN
+    INTEGER(16) :: RKEY, BASE, POW
+    IF (SD > 9) STOP 'COMPUTE_RKEY: MORE THAN 9 SPECIES DO NOT FIT THE 128-BIT POSITIONAL KEY'
+    BASE = INT(MAXNUMBERMOLECULES, 16) + 1_16
+    DO J = 1, PD
+       RS = MODEL%STOICHIOMETRY(1:SD, J)
+       SGN = 1
+       RKEY = 0_16
+       POW = 1_16
+       DO I = 1, SD
+          IF (SGN * RS(I) < 0) THEN
+             SGN = -SGN
+             RKEY = INT(ABS(RS(I)), 16) * POW - RKEY
+          ELSE
+             RKEY = INT(ABS(RS(I)), 16) * POW + RKEY
+          ENDIF
+          POW = POW * BASE
+       ENDDO
+       REACTIONKEY(J) = RKEY
+       RKEYSIGN(J) = SGN
+    ENDDO
+  END SUBROUTINE COMPUTE_RKEY
+
 END MODULE STATESPACE

@@ -302,3 +302,40 @@ def test_cme_solve_adaptive_fsp(dump, tmp_path, fixture, case):
     if same_traj:
         assert np.array_equal(d["state"], g["state"])
         assert np.abs(d["vector"] - g["vector"]).sum() < 1e-9
+
+
+def test_compute_rkey_returns_the_reference_key_changes(tmp_path):
+    """COMPUTE_RKEY (StateSpace.f90:635-669) of our STATESPACE: for every reaction of the Goutsias
+    model the integers the reference's big-integer routine returns (restated here with Python
+    integers), and its defining property key(x + nu_j) = key(x) + RKEYSIGN(j) * REACTIONKEY(j) for
+    the positional key of HashTable.f90:39-59."""
+    exe = os.path.join(FDIR, "_build", "kfsp_replay")
+    if not os.path.exists(exe):
+        from krylovfspssa_amd import build
+        build.build_lib()
+        subprocess.run(["make", "-s", "-C", FDIR, "_build/kfsp_replay"], check=True)
+    out = str(tmp_path / "rk.txt")
+    subprocess.run([exe, "rkey", "goutsias", out], cwd=MODELS, check=True, stdout=subprocess.DEVNULL)
+    got = [tuple(int(v) for v in line.split()) for line in open(out)]
+    asm = np.load(os.path.join(GOLDEN, "assembly_goutsias_k5.npz"))
+    nr = asm["adj"].shape[1]
+    nu = [None] * nr
+    for i, row in enumerate(asm["adj"]):
+        for r, j in enumerate(row):
+            if j > 0 and nu[r] is None:
+                nu[r] = (asm["state"][j - 1] - asm["state"][i]).tolist()
+    base = 10001                                      # MAXNUMBERMOLECULES + 1, StateSpace.f90:11
+    want = []
+    for v in nu:
+        sgn, rkey = 1, 0
+        for i, s in enumerate(v):
+            if sgn * s < 0:
+                sgn, rkey = -sgn, abs(s) * base ** i - rkey
+            else:
+                rkey = abs(s) * base ** i + rkey
+        want.append((sgn, rkey))
+    assert got == want
+    key = lambda x: 2 + sum(int(c) * base ** i for i, c in enumerate(x))
+    x = [3, 7, 2, 2, 1, 1]
+    for v, (sgn, rk) in zip(nu, got):
+        assert key([a + b for a, b in zip(x, v)]) == key(x) + sgn * rk
