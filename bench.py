@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c3x", "c4", "c5s", "tiny"])
-    ap.add_argument("--variant", type=int, default=0, help="SpMV kernel variant (0 auto: DIA/SELL, 1 CSR-stream, 2 SELL)")
+    ap.add_argument("--variant", type=int, default=0, choices=[0, 2], help="SpMV kernel variant (0 auto: DIA/SELL, 2 SELL-64)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-expv", action="store_true")
     ap.add_argument("--expv-steps", type=int, default=10)
@@ -159,8 +159,6 @@ def main():
     for kv in args.opt:
         k, v = kv.split("=")
         ctx.set_option(k, int(v))
-    if args.variant == 1:
-        ctx.set_option("build_csr", 1)
     if world == 1 and args.force_comm:
         ctx.comm_init(1, 0, KfspContext.unique_id())
     if world > 1:
@@ -256,7 +254,7 @@ def main():
 
     # bytes the kernel's own layout moves per launch (kfsp_matrix_bytes) and, when this run is the
     # profiled configuration, the HBM bytes rocprofv3 counted for it (profiles/, NOT this run)
-    real_bytes = ctx.matrix_bytes(force_sell=(args.variant == 2)) if args.variant != 1 else None
+    real_bytes = ctx.matrix_bytes(force_sell=(args.variant == 2))
     traffic, traffic_src = None, None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     plain_run = world == 1 and not args.opt and not args.force_comm and args.variant in (0, 2)
@@ -288,7 +286,7 @@ def main():
             "nnz_total": int(nnz_global), "alg_bytes_per_launch_total": int(b_alg_global),
             "partition": f"rows x{world}" if world > 1 else "single GPU",
             "exchange": exchange,
-            "kernel_variant": {0: "auto (banded DIA when the rows allow it, else SELL-64)", 1: "csr_stream", 2: "sell64"}[args.variant],
+            "kernel_variant": {0: "auto (banded DIA when the rows allow it, else SELL-64)", 2: "sell64"}[args.variant],
             "stored_slots_local": info["slots"],
         },
         "self_check": {"ok": bool(check_ok), "max_rel_err": check_err,
@@ -299,8 +297,8 @@ def main():
             "kernel": "k_spmv", "avg_launch_ms": round(kern_ms, 5),
             "alg_bytes_per_launch": int(b_alg_local),
             "real_bytes_per_launch": real_bytes,
-            "real_GBps": None if real_bytes is None else round(real_bytes / (kern_ms * 1e-3) / 1e9, 2),
-            "frac_traffic": None if real_bytes is None else round(real_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "real_GBps": round(real_bytes / (kern_ms * 1e-3) / 1e9, 2),
+            "frac_traffic": round(real_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "note": "achieved/frac: per-GPU algorithmic bytes (CSR figure 12 nnz + 20 N, SURVEY 8d) / HIP-event time of "
                     "the timed launches.  The banded kernel stores no column indices, so it moves fewer bytes than "
                     "that: real_bytes_per_launch is the layout's own byte count (generator as stored + 24 B/row), "

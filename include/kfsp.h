@@ -284,8 +284,7 @@ int kfsp_expv_fixed(kfsp_ctx *ctx, int m, double tau, int nsteps, double *wsums)
  * stream, bracketed by HIP events: *ms_total = elapsed GPU time.  With
  * nranks > 1 every launch is preceded by the all-gather of the source slab,
  * as in the solver.  variant: 0 = the format the library chose (banded DIA when
- * the rows allow it, else SELL-64), 1 = CSR-stream (needs option build_csr=1
- * before the matrix is set), 2 = SELL-64 even when DIA is active. */
+ * the rows allow it, else SELL-64), 2 = SELL-64 even when DIA is active. */
 int kfsp_spmv_bench(kfsp_ctx *ctx, int reps, int variant, float *ms_total);
 
 /* diagnostics: reps launches that read exactly nbytes from a scratch buffer
@@ -305,7 +304,7 @@ int kfsp_get_timers(kfsp_ctx *ctx, double *ms /* [KFSP_T_COUNT] */, int reset);
 int kfsp_add_timer(kfsp_ctx *ctx, int phase, double ms);
 
 /* tuning knobs (name/value); unknown name -> -2: "grid_blocks",
- * "vec_grid_blocks", "nt_loads", "build_csr", "format", "fused_ortho",
+ * "vec_grid_blocks", "nt_loads", "format", "fused_ortho",
  * "host_build", "halo", "overlap", "small_kernel", "small_lds", "dia_mask", "state_order" (1: use
  * kfsp_set_state_coords; default 0), "state_order_min" (smallest generator that is
  * reordered, default 32768), "state_order_products" (products the previous

@@ -522,46 +522,6 @@ int maybe_upload_dia(kfsp_ctx *ctx, const HostSell &S, const std::vector<int32_t
     return kfsp::build_dia_mask(ctx);
 }
 
-// CSR copy (off-diagonal entries, row order) + tiles of whole rows for the
-// CSR-stream kernel, derived from the SELL image.
-int upload_csr_from_sell(kfsp_ctx *ctx, const HostSell &S, const std::vector<int32_t> &cnt)
-{
-    const int64_t nloc = ctx->nloc;
-    std::vector<int64_t> rowptr((size_t)nloc + 1, 0);
-    for (int64_t r = 0; r < nloc; ++r) rowptr[(size_t)r + 1] = rowptr[(size_t)r] + cnt[(size_t)r];
-    std::vector<int32_t> col((size_t)rowptr[(size_t)nloc]);
-    std::vector<double> val(col.size());
-    for (int64_t r = 0; r < nloc; ++r) {
-        const int64_t c = r / kChunk, l = r % kChunk, o = S.off[(size_t)c];
-        for (int k = 0; k < cnt[(size_t)r]; ++k) {
-            col[(size_t)(rowptr[(size_t)r] + k)] = S.col[(size_t)(o + (int64_t)k * kChunk + l)];
-            val[(size_t)(rowptr[(size_t)r] + k)] = S.val[(size_t)(o + (int64_t)k * kChunk + l)];
-        }
-    }
-    std::vector<int32_t> tile{0};
-    int64_t r = 0;
-    while (r < nloc) {
-        int64_t e = r;
-        while (e < nloc && e - r < kBlock && rowptr[(size_t)e + 1] - rowptr[(size_t)r] <= 2048) ++e;
-        if (e == r) return fail(ctx, -2, "row longer than a CSR-stream tile");
-        tile.push_back((int32_t)e);
-        r = e;
-    }
-    ctx->ntiles = (int64_t)tile.size() - 1;
-    HIP_TRY(ctx->d_rowptr.reserve(rowptr.size(), false));
-    HIP_TRY(ctx->d_ccol.reserve(std::max<size_t>(col.size(), 64), false));
-    HIP_TRY(ctx->d_cval.reserve(std::max<size_t>(val.size(), 64), false));
-    HIP_TRY(ctx->d_tile.reserve(tile.size(), false));
-    HIP_TRY(hipMemcpy(ctx->d_rowptr.p, rowptr.data(), rowptr.size() * sizeof(int64_t), hipMemcpyHostToDevice));
-    if (!col.empty()) {
-        HIP_TRY(hipMemcpy(ctx->d_ccol.p, col.data(), col.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(ctx->d_cval.p, val.data(), val.size() * sizeof(double), hipMemcpyHostToDevice));
-    }
-    HIP_TRY(hipMemcpy(ctx->d_tile.p, tile.data(), tile.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    ctx->have_csr = true;
-    return 0;
-}
-
 // Host array (caller's state order) -> device vector (internal order) and back.
 // Without an internal order these are plain copies.
 int upload_states(kfsp_ctx *ctx, const double *host, double *dev, int64_t count)
@@ -653,7 +613,6 @@ int kfsp_destroy(kfsp_ctx *ctx)
     if (ctx->ev_halo) (void)hipEventDestroy(ctx->ev_halo);
     if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);
     ctx->d_off.release(); ctx->d_col.release(); ctx->d_val.release(); ctx->d_diag.release();
-    ctx->d_rowptr.release(); ctx->d_ccol.release(); ctx->d_cval.release(); ctx->d_tile.release();
     ctx->d_V.release(); ctx->d_w.release(); ctx->d_xg.release(); ctx->d_tmp.release();
     ctx->d_part.release(); ctx->d_stage.release(); ctx->d_H.release(); ctx->d_sq.release();
     ctx->d_y.release(); ctx->d_flag.release(); ctx->d_g.release(); ctx->d_dia.release();
@@ -800,21 +759,20 @@ int kfsp_set_matrix_ell(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, const 
         if (int rc = resize(ctx, n)) return rc;
         const int64_t row0 = ctx->row0, nloc = ctx->nloc;
         // coordinates handed over for exactly this generator switch the internal order on
-        ctx->perm_on = ctx->perm_pending_n == n && !ctx->use_comm && !ctx->opt_host_build && !ctx->want_csr;
+        ctx->perm_on = ctx->perm_pending_n == n && !ctx->use_comm && !ctx->opt_host_build;
         ctx->perm_pending_n = 0;
         ctx->prod_last = ctx->prod_count;
         ctx->prod_count = 0;
 
-        if (!ctx->opt_host_build && !ctx->want_csr) {
+        if (!ctx->opt_host_build) {
             // the arrays go to HBM verbatim and are transposed there (kfsp_build.hip)
             int rc = build_from_ell_device(ctx, n, bw, ld, adj, offdiag, diag);
             if (!rc) rc = setup_exchange(ctx);
-            ctx->have_csr = false;
             ctx->t_ms[KFSP_T_UPLOAD] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             return rc;
         }
 
-        // host transpose (kept for A/B checks of the device build and for the CSR copy)
+        // host transpose (kept for A/B checks of the device build)
         // in-degree of every local row
         std::vector<int32_t> cnt((size_t)std::max<int64_t>(nloc, 1), 0);
         for (int64_t i = 0; i < n; ++i) {
@@ -854,9 +812,6 @@ int kfsp_set_matrix_ell(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, const 
         if (int rc = upload_sell(ctx, S)) return rc;
         if (int rc = maybe_upload_dia(ctx, S, cnt)) return rc;
         if (int rc = setup_exchange(ctx)) return rc;
-        ctx->have_csr = false;
-        if (ctx->want_csr)
-            if (int rc = upload_csr_from_sell(ctx, S, cnt)) return rc;
         ctx->t_ms[KFSP_T_UPLOAD] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         return 0;
     });
@@ -912,9 +867,6 @@ int kfsp_set_matrix_csr(kfsp_ctx *ctx, int64_t n, int64_t row0, int64_t nrows, c
         if (int rc = upload_sell(ctx, S)) return rc;
         if (int rc = maybe_upload_dia(ctx, S, cnt)) return rc;
         if (int rc = setup_exchange(ctx)) return rc;
-        ctx->have_csr = false;
-        if (ctx->want_csr)
-            if (int rc = upload_csr_from_sell(ctx, S, cnt)) return rc;
         ctx->t_ms[KFSP_T_UPLOAD] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         return 0;
     });
@@ -1370,8 +1322,7 @@ int kfsp_spmv_bench(kfsp_ctx *ctx, int reps, int variant, float *ms_total)
     if (!ctx) return -1;
     if (ctx->ldv == 0) return fail(ctx, -1, "no matrix set");
     if (reps < 1) return fail(ctx, -2, "reps < 1");
-    if (variant < 0 || variant > 2) return fail(ctx, -3, "unknown variant (0 auto, 1 CSR-stream, 2 SELL)");
-    if (variant == 1 && !ctx->have_csr) return fail(ctx, -3, "CSR variant needs option build_csr=1 before the matrix is set");
+    if (variant != 0 && variant != 2) return fail(ctx, -3, "unknown variant (0 auto, 2 SELL)");
     if (variant == 2 && !ctx->have_sell) return fail(ctx, -3, "no SELL image resident (banded matrix built on the device)");
     if (!ms_total) return fail(ctx, -4, "null ms_total");
     HIP_TRY(hipSetDevice(ctx->device));
@@ -1380,15 +1331,7 @@ int kfsp_spmv_bench(kfsp_ctx *ctx, int reps, int variant, float *ms_total)
     double *dst = vcol(ctx, 1);
     HIP_TRY(hipEventRecord(ctx->ev0, st));
     for (int r = 0; r < reps; ++r) {
-        if (variant != 1) {
-            if (int rc = spmv_plain(ctx, src, false, dst, variant == 2)) return rc;
-        } else {
-            const double *xg = nullptr;
-            if (int rc = gather_source(ctx, src, &xg)) return rc;
-            CsrDev A{ctx->nloc, ctx->d_rowptr.p, ctx->d_ccol.p, ctx->d_cval.p, ctx->d_diag.p, ctx->d_tile.p, ctx->ntiles};
-            const int g = (int)std::min<int64_t>(ctx->ntiles, kMaxGrid);
-            launch_spmv_csr_stream(std::max(g, 1), A, xg, ctx->row0, dst, st);
-        }
+        if (int rc = spmv_plain(ctx, src, false, dst, variant == 2)) return rc;
     }
     HIP_TRY(hipEventRecord(ctx->ev1, st));
     HIP_TRY(hipEventSynchronize(ctx->ev1));
@@ -1442,7 +1385,6 @@ int kfsp_set_option(kfsp_ctx *ctx, const char *name, int64_t value)
     if (k == "grid_blocks") ctx->opt_grid = value;
     else if (k == "vec_grid_blocks") ctx->opt_vgrid = value;
     else if (k == "nt_loads") ctx->opt_nt = value;
-    else if (k == "build_csr") ctx->want_csr = value != 0;
     else if (k == "format") ctx->opt_format = value;
     else if (k == "fused_ortho") ctx->opt_fused = value;
     else if (k == "host_build") ctx->opt_host_build = value;

@@ -146,12 +146,6 @@ struct kfsp_ctx {
     int64_t perm_pending_n = 0;            // coordinates received for a generator of this size
     bool perm_on = false;                  // the current generator and vectors are permuted
     int64_t prod_count = 0, prod_last = 0; // products on the current / the previous generator
-    // optional CSR copy for the CSR-stream kernel variant
-    DevBuf<int64_t> d_rowptr;
-    DevBuf<int32_t> d_ccol, d_tile;
-    DevBuf<double> d_cval;
-    int64_t ntiles = 0;
-    bool want_csr = false, have_csr = false;
 
     // vectors
     DevBuf<double> d_V;    // (kMMax+2) columns, stride ldv, unnormalised basis

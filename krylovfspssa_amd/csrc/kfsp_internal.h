@@ -51,18 +51,6 @@ struct DiaDev {
     const double *zero;
 };
 
-// Same rows in plain CSR (off-diagonal entries only), for the LDS-staged
-// CSR-stream kernel variant.
-struct CsrDev {
-    int64_t nrows;
-    const int64_t *rowptr;  // [nrows + 1]
-    const int32_t *col;
-    const double *val;
-    const double *diag;
-    const int32_t *tile_row;  // [ntiles + 1] first row of every nnz tile
-    int64_t ntiles;
-};
-
 // A scalar that is the sum of n doubles at p (block partials of the producing
 // kernel, or one finished / all-reduced value).  Consumers sum it themselves in
 // a fixed order: no atomics, no extra launch, bit-reproducible.
@@ -163,7 +151,6 @@ int launch_arnoldi_small(const SmallArnoldiArgs &a, bool dia, int64_t lds_limit,
 // fmt: 0 SELL-64, 1 banded, 2 banded with group masks
 void launch_spmv(int mode, int grid, const SpmvArgs &a, bool nontemporal, int fmt, hipStream_t s);
 void launch_ortho2(int grid, const Ortho2Args &a, hipStream_t s);
-void launch_spmv_csr_stream(int grid, const CsrDev &A, const double *xg, int64_t row0, double *y, hipStream_t s);
 void launch_ortho(int grid, const OrthoArgs &a, hipStream_t s);
 void launch_combine(int grid, const CombineArgs &a, hipStream_t s);
 // u1 = w, partial = sum w^2

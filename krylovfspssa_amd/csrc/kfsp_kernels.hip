@@ -345,38 +345,6 @@ void launch_spmv(int mode, int grid, const SpmvArgs &a, bool nt, int fmt, hipStr
     }
 }
 
-// CSR-stream variant: a workgroup owns a run of whole rows holding <= kTile
-// off-diagonal entries, streams their (col,val) tile with full-width
-// contiguous reads, parks val*x[col] in LDS and lets one lane per row add its
-// few products.  No padding bytes at all; costs an 8-B row pointer per row.
-constexpr int kTile = 2048;
-__global__ __launch_bounds__(kBlock) void k_spmv_csr_stream(CsrDev A, const double *__restrict__ xg,
-                                                            int64_t row0, double *__restrict__ y)
-{
-    __shared__ double prod[kTile];
-    for (int64_t t = blockIdx.x; t < A.ntiles; t += gridDim.x) {
-        const int rbeg = A.tile_row[t], rend = A.tile_row[t + 1];
-        const int64_t pbeg = A.rowptr[rbeg], pend = A.rowptr[rend];
-        const int cnt = (int)(pend - pbeg);
-        for (int i = threadIdx.x; i < cnt; i += kBlock)
-            prod[i] = A.val[pbeg + i] * xg[A.col[pbeg + i]];
-        __syncthreads();
-        const int r = rbeg + threadIdx.x;
-        if (r < rend) {
-            const int lo = (int)(A.rowptr[r] - pbeg), hi = (int)(A.rowptr[r + 1] - pbeg);
-            double sum = -A.diag[r] * xg[row0 + r];
-            for (int i = lo; i < hi; ++i) sum += prod[i];
-            y[r] = sum;
-        }
-        __syncthreads();
-    }
-}
-
-void launch_spmv_csr_stream(int grid, const CsrDev &A, const double *xg, int64_t row0, double *y, hipStream_t st)
-{
-    hipLaunchKernelGGL(k_spmv_csr_stream, dim3(grid), dim3(kBlock), 0, st, A, xg, row0, y);
-}
-
 // --------------------------------------------------- orthogonalisation step
 // h = (u_i . w) s_i ;  w -= h s_i u_i ;  partial = unext . w  (or w . w)
 __global__ __launch_bounds__(kBlock) void k_ortho(OrthoArgs a)

@@ -1,0 +1,137 @@
+"""BASELINE.json configs 4 and 5 at their stated per-GPU sizes through the C ABI, and a
+6-species network small enough for the oracle.
+
+  config 4  goutsias_model.input propensities on M, D, RNA in [0,150)^3 x the 6 conserved DNA
+            configurations: N = 2.025e7 states, nnz = 1.81e8 (the row block of ONE GPU; its
+            2- and 4-rank partitions run in tests/test_gpu_loopback.py on a reduced box)
+  config 5  synthetic 6-species birth-death network, the per-GPU slab 22^5 x 3 of the 22^6 box:
+            N = 1.55e7 states, 12 reactions
+
+At these sizes the oracle's scatter loop is no longer a seconds-scale check, so the generator
+product is pinned by size-independent properties (linearity, the mass-balance identity
+1^T A x = colsum . x, determinism, banded == SELL, masked == unmasked) and by sampled rows
+against numpy; the same model classes are checked against the oracle at small sizes."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import oracle as O
+    return O
+
+
+def _properties(ctx, mdl, rowptr, col, val, seed):
+    rng = np.random.default_rng(seed)
+    n = mdl.n
+    x, z = rng.random(n), rng.random(n)
+    ax, az = ctx.spmv(x), ctx.spmv(z)
+    mag = np.abs(ax).max()
+    assert np.abs(ctx.spmv(2.0 * x - 3.0 * z) - (2.0 * ax - 3.0 * az)).max() <= 1e-9 * mag
+    colsum = np.bincount(col, weights=val, minlength=n)
+    assert abs(ax.sum() - colsum @ x) <= 1e-7 * np.abs(ax).sum()
+    assert np.array_equal(ax, ctx.spmv(x))
+    rows = np.unique(np.concatenate([np.arange(512), np.arange(n - 512, n), rng.integers(0, n, 8192)]))
+    ref = np.array([val[rowptr[r]:rowptr[r + 1]] @ x[col[rowptr[r]:rowptr[r + 1]]] for r in rows])
+    scale = np.array([np.abs(val[rowptr[r]:rowptr[r + 1]]) @ x[col[rowptr[r]:rowptr[r + 1]]] for r in rows])
+    assert np.all(np.abs(ax[rows] - ref) <= 1e-13 * scale)
+    return x, ax, mag
+
+
+def test_config4_at_full_size():
+    from krylovfspssa_amd import KfspContext, synth
+    mdl = synth.GoutsiasConserved(150, 150, 150)
+    assert mdl.n == 20_250_000
+    rowptr, col, val = mdl.csr_rows()
+    assert rowptr[-1] == mdl.nnz() and rowptr[-1] > 1.8e8
+    with KfspContext(0) as c:
+        c.set_matrix_csr(mdl.n, rowptr, col, val)
+        info = c.matrix_info()
+        assert info["slots"] % mdl.n == 0 or info["slots"] >= 10 * mdl.n      # banded: ten stored diagonals
+        x, ax, mag = _properties(c, mdl, rowptr, col, val, 41)
+        masked_bytes = c.matrix_bytes()
+        c.set_option("dia_mask", 0)                       # same diagonals without the empty-segment masks
+        c.set_matrix_csr(mdl.n, rowptr, col, val)
+        assert np.array_equal(c.spmv(x), ax)
+        assert c.matrix_bytes() > masked_bytes * 1.1      # the masks skip > 10 % of the stored bytes here
+        c.set_option("format", 1)                         # SELL-64 on the same rows
+        c.set_matrix_csr(mdl.n, rowptr, col, val)
+        assert np.abs(c.spmv(x) - ax).max() <= 1e-12 * mag
+    # a few fixed steps from the reference's initial state keep mass and sign
+    with KfspContext(0) as c:
+        c.set_matrix_csr(mdl.n, rowptr, col, val)
+        p0 = np.zeros(mdl.n)
+        p0[2 + 150 * (6 + 150 * 0)] = 1.0                # (M, D, RNA) = (2, 6, 0), two free DNA copies
+        c.set_vector(p0)
+        ws = c.expv_fixed(20, 0.05, 2)
+        w = c.get_vector()
+        assert np.all(w >= 0) and 0.999 < ws[-1] <= 1.0 + 1e-12
+        assert ws[-1] == pytest.approx(w.sum(), rel=1e-13)
+
+
+def test_config5_slab_at_full_size():
+    from krylovfspssa_amd import KfspContext, synth
+    mdl = synth.birth_death((22, 22, 22, 22, 22, 3))
+    assert mdl.n == 15_460_896 and mdl.R == 12
+    rowptr, col, val = mdl.csr_rows()
+    assert rowptr[-1] == mdl.nnz()
+    with KfspContext(0) as c:
+        c.set_matrix_csr(mdl.n, rowptr, col, val)
+        x, ax, mag = _properties(c, mdl, rowptr, col, val, 42)
+        c.set_option("format", 1)
+        c.set_matrix_csr(mdl.n, rowptr, col, val)
+        assert np.abs(c.spmv(x) - ax).max() <= 1e-12 * mag
+    with KfspContext(0) as c:
+        c.set_matrix_csr(mdl.n, rowptr, col, val)
+        p0 = synth.poisson_p0(mdl, 4.0)
+        c.set_vector(p0)
+        ws = c.expv_fixed(30, 0.01, 2)
+        w = c.get_vector()
+        # the slab is three planes thick: births of the sixth species leave it, so mass only decreases
+        assert np.all(w >= 0) and 0.5 < ws[1] < ws[0] < 1.0
+        assert ws[-1] == pytest.approx(w.sum(), rel=1e-13)
+
+
+@pytest.mark.parametrize("dims", [(5, 5, 5, 5, 5, 5), (7, 6, 5, 4, 3, 3)])
+def test_six_species_network_matches_the_oracle(oracle, dims):
+    """config 5's model (6 species, 12 reactions, 12 diagonals) at 5^6 = 15 625 and 7 560 states:
+    product, Arnoldi pass and fixed-(m, tau) expv against the oracle, banded and SELL forms, through
+    both upload routes (gather rows and the reference's column layout)."""
+    from krylovfspssa_amd import KfspContext, synth
+    mdl = synth.birth_death(dims)
+    adj, off, diag = mdl.ell()
+    A = oracle.EllMatrix(adj, off, diag)
+    rng = np.random.default_rng(6)
+    x = rng.random(mdl.n)
+    yref = oracle.spmv_ell(A, x)
+    scale = oracle.spmv_ell(oracle.EllMatrix(adj, np.abs(off), -np.abs(diag)), np.abs(x))
+    p0 = synth.poisson_p0(mdl, 1.5)
+    m, tau, nsteps = 25, 0.02, 3
+    wref, wsref = oracle.expv_fixed(A, p0, m, tau, nsteps)
+    V, Href, mb, k1, av = oracle.arnoldi(A, p0 / np.sqrt((p0 * p0).sum()), m)
+    for fmt in (0, 1):
+        for route in ("csr", "ell"):
+            with KfspContext(0) as c:
+                c.set_option("format", fmt)
+                c.set_option("small_kernel", 0)
+                if route == "csr":
+                    c.set_matrix_csr(mdl.n, *mdl.csr_rows())
+                else:
+                    c.set_matrix_ell(adj, off, diag)
+                y = c.spmv(x)
+                assert np.all(np.abs(y - yref) <= 1e-13 * np.abs(scale) + 1e-300), (fmt, route)
+                c.set_vector(p0)
+                c.begin_step()
+                H, mb2, k12, av2 = c.arnoldi(m)
+                assert (mb2, k12) == (mb, k1)
+                # IOP(2) amplifies rounding differences from column to column (tests/test_lockstep.py):
+                # the leading columns agree to rounding, the whole pass to 1e-6, the solution to 1e-10
+                assert np.abs(H[:11, :10] - Href[:11, :10]).max() <= 1e-11 * np.abs(Href).max()
+                assert np.abs(H[:m + 1, :m] - Href[:m + 1, :m]).max() <= 1e-6 * np.abs(Href).max()
+                assert abs(av2 - av) <= 1e-6 * av
+                c.set_vector(p0)
+                ws = c.expv_fixed(m, tau, nsteps)
+                assert np.abs(c.get_vector() - wref).sum() < 1e-10
+                assert np.abs(ws - wsref).max() < 1e-12
