@@ -148,6 +148,25 @@ int kfsp_spmv(kfsp_ctx *ctx, const double *x, double *y);
 /* y = A w for the resident w (DROP_STATES, StateSpace.f90:486), local rows */
 int kfsp_spmv_w(kfsp_ctx *ctx, double *y);
 
+/* ---- DROP_STATES on the device (StateSpace.f90:398-427, :470-546) ---------------- */
+/* The decision on the resident w and generator, without moving either to the host:
+ *   droptol    FIND_DROPTOL's threshold (:416-426): the first of 1e-8, 1e-9, ... (the reference's
+ *              own divisions by 10) whose sum of the entries 0 < w < threshold is below dsum; all
+ *              thresholds of a pass are summed in ONE sweep over w (same entries per threshold as the
+ *              reference's sweeps; fixed reduction order, reproducible run to run)
+ *   drop_count the reference's DROP_COUNT (:476-495) = #(w < droptol) - #((A w) > 1e-8), its
+ *              counting quirk included: the caller compacts iff drop_count / n > 0.1 (:497)
+ *   n_flagged  states actually flagged: w < droptol and not (A w) > 1e-8
+ * The flags stay on the device for the two calls below.  Single context only (-9 with a communicator). */
+int kfsp_drop_plan(kfsp_ctx *ctx, double dsum, double *droptol, int64_t *drop_count, int64_t *n_flagged);
+/* the flags of the last plan, one byte per state in the caller's order (1 = dropped) */
+int kfsp_drop_flags(kfsp_ctx *ctx, int64_t n, uint8_t *dropped);
+/* Compacts the resident w by those flags (kept entries keep their order, :500-546 for W); *n_new =
+ * n - n_flagged.  The context then WAITS for the generator of the compacted FSP: the next
+ * kfsp_set_matrix_ell / _csr must have n_new states and makes the compacted vector its w (do not
+ * call kfsp_set_vector in between, it would replace it). */
+int kfsp_drop_compact(kfsp_ctx *ctx, int64_t *n_new);
+
 /* single reductions over the resident w (tests; FIND_DROPTOL-style sums) */
 int kfsp_nrm2_w(kfsp_ctx *ctx, double *out);
 int kfsp_asum_w(kfsp_ctx *ctx, double *out);

@@ -378,6 +378,7 @@ int setup_exchange(kfsp_ctx *ctx)
         // + 128: the banded kernel works on 128-row groups, whose padded rows read up
         // to one group beyond the block end
         ctx->margin = round_up(H + H / 4 + 2 * kChunk, 64);
+        ctx->relayout = true;
         if (int rc = resize(ctx, ctx->n)) return rc;
     }
     HIP_TRY(ctx->d_strip.reserve((size_t)(2 * H) * (size_t)(ctx->nranks + 1), true));
@@ -398,17 +399,21 @@ int resize(kfsp_ctx *ctx, int64_t n)
     if (ctx->L == 0) ctx->L = kChunk;
     ctx->row0 = (int64_t)ctx->rank * ctx->L;
     ctx->nloc = std::max<int64_t>(0, std::min<int64_t>(ctx->L, n - ctx->row0));
-    const int64_t ldv = round_up(ctx->L + 2 * ctx->margin, 256);
-    if (ldv > ctx->ldv || (size_t)ldv * kNumCols > ctx->d_V.cap) {
-        // grow with head room: the FSP usually keeps growing
-        const int64_t cap = round_up(ldv + ldv / 2, 256);
-        HIP_TRY(ctx->d_V.reserve((size_t)cap * kNumCols, false));
-        HIP_TRY(ctx->d_w.reserve((size_t)cap, false));
-        HIP_TRY(ctx->d_tmp.reserve((size_t)cap, false));
-    }
-    if (ldv != ctx->ldv) {
+    // The column stride only ever grows (with head room: the FSP usually keeps growing, and a drop
+    // is followed by expansions): a changed stride would re-lay all 105 columns, and zero-filling
+    // them (0.8 GB at 10^6 rows) on every FSP change is pure overhead - every pass rewrites the
+    // rows [0, nchunks*64) of each column it uses, rows beyond them are never read, and w is
+    // cleared by kfsp_set_vector.  Only fresh memory is zeroed.
+    const int64_t need = round_up(ctx->L + 2 * ctx->margin, 256);
+    int64_t ldv = ctx->ldv;
+    if (need > ctx->ldv || ctx->relayout) {
+        if (ctx->w_pending) return fail(ctx, -2, "the FSP grew between kfsp_drop_compact and the next generator");
+        ldv = ctx->relayout ? need : round_up(need + need / 2, 256);
+        ctx->relayout = false;
+        HIP_TRY(ctx->d_V.reserve((size_t)ldv * kNumCols, false));
+        HIP_TRY(ctx->d_w.reserve((size_t)ldv, false));
+        HIP_TRY(ctx->d_tmp.reserve((size_t)ldv, false));
         ctx->ldv = ldv;
-        // padding rows must read as zero in every kernel
         HIP_TRY(hipMemsetAsync(ctx->d_V.p, 0, (size_t)ldv * kNumCols * sizeof(double), ctx->stream));
         HIP_TRY(hipMemsetAsync(ctx->d_w.p, 0, (size_t)ldv * sizeof(double), ctx->stream));
         HIP_TRY(hipMemsetAsync(ctx->d_tmp.p, 0, (size_t)ldv * sizeof(double), ctx->stream));
@@ -550,6 +555,22 @@ int download_states(kfsp_ctx *ctx, const double *dev, double *host, int64_t coun
     return 0;
 }
 
+// A vector compacted on the device (kfsp_drop_compact) becomes the resident w of the generator
+// that was just set: caller's order -> the order the device keeps this generator in.
+int adopt_pending_vector(kfsp_ctx *ctx)
+{
+    if (!ctx->w_pending) return 0;
+    ctx->w_pending = false;
+    if (ctx->w_pending_n != ctx->n) return fail(ctx, -2, "generator size does not match the vector compacted by kfsp_drop_compact");
+    HIP_TRY(hipMemsetAsync(ctx->d_w.p, 0, (size_t)ctx->ldv * sizeof(double), ctx->stream));
+    if (ctx->perm_on)
+        kfsp::launch_gather_index(ctx->n, ctx->d_perm.p, ctx->d_tmp.p, ctx->d_w.p, ctx->stream);
+    else
+        HIP_TRY(hipMemcpyAsync(ctx->d_w.p, ctx->d_tmp.p, (size_t)ctx->n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
 // stream, events and the fixed-size buffers of a fresh context
 int init_context(kfsp_ctx *ctx)
 {
@@ -618,6 +639,7 @@ int kfsp_destroy(kfsp_ctx *ctx)
     ctx->d_y.release(); ctx->d_flag.release(); ctx->d_g.release(); ctx->d_dia.release();
     ctx->d_ell_adj.release(); ctx->d_ell_off.release(); ctx->d_ell_diag.release(); ctx->d_cnt.release();
     ctx->d_ticket.release(); ctx->d_slot.release(); ctx->d_scan.release(); ctx->d_strip.release();
+    ctx->d_dropflag.release(); ctx->d_dropcnt.release();
     ctx->d_perm.release(); ctx->d_iperm.release(); ctx->d_coords.release(); ctx->d_ell_adj2.release();
     ctx->d_ell_off2.release(); ctx->d_ell_diag2.release(); ctx->d_pstage.release(); ctx->d_keys.release();
     ctx->d_sortidx.release(); ctx->d_sorttmp.release(); ctx->d_gmask.release(); ctx->d_zero.release();
@@ -672,7 +694,7 @@ int kfsp_comm_init(kfsp_ctx *ctx, int nranks, int rank, const void *id_bytes)
             HIP_TRY(hipEventCreateWithFlags(&ctx->ev_halo, hipEventDisableTiming));
         }
     }
-    ctx->ldv = 0;   // force re-layout on the next matrix
+    ctx->relayout = true;   // new margins / block length: re-lay the basis on the next matrix
     ctx->use_halo = false;
     return 0;
 }
@@ -717,7 +739,7 @@ int kfsp_comm_init_loopback(kfsp_ctx *ctx, void *group, int rank)
         HIP_TRY(hipEventCreateWithFlags(&ctx->ev_src, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&ctx->ev_halo, hipEventDisableTiming));
     }
-    ctx->ldv = 0;   // force re-layout on the next matrix
+    ctx->relayout = true;   // new margins / block length: re-lay the basis on the next matrix
     ctx->use_halo = false;
     return 0;
 }
@@ -768,6 +790,7 @@ int kfsp_set_matrix_ell(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, const 
             // the arrays go to HBM verbatim and are transposed there (kfsp_build.hip)
             int rc = build_from_ell_device(ctx, n, bw, ld, adj, offdiag, diag);
             if (!rc) rc = setup_exchange(ctx);
+            if (!rc) rc = adopt_pending_vector(ctx);
             ctx->t_ms[KFSP_T_UPLOAD] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             return rc;
         }
@@ -812,6 +835,7 @@ int kfsp_set_matrix_ell(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, const 
         if (int rc = upload_sell(ctx, S)) return rc;
         if (int rc = maybe_upload_dia(ctx, S, cnt)) return rc;
         if (int rc = setup_exchange(ctx)) return rc;
+        if (int rc = adopt_pending_vector(ctx)) return rc;
         ctx->t_ms[KFSP_T_UPLOAD] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         return 0;
     });
@@ -867,6 +891,7 @@ int kfsp_set_matrix_csr(kfsp_ctx *ctx, int64_t n, int64_t row0, int64_t nrows, c
         if (int rc = upload_sell(ctx, S)) return rc;
         if (int rc = maybe_upload_dia(ctx, S, cnt)) return rc;
         if (int rc = setup_exchange(ctx)) return rc;
+        if (int rc = adopt_pending_vector(ctx)) return rc;
         ctx->t_ms[KFSP_T_UPLOAD] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         return 0;
     });
@@ -946,6 +971,8 @@ int kfsp_set_vector(kfsp_ctx *ctx, int64_t nlocal, const double *w)
     if (nlocal != ctx->nloc) return fail(ctx, -2, "nlocal is not this rank's block size");
     if (!w && nlocal > 0) return fail(ctx, -3, "null w");
     HIP_TRY(hipSetDevice(ctx->device));
+    ctx->w_pending = false;
+    ctx->drop_planned = false;
     HIP_TRY(hipMemsetAsync(ctx->d_w.p, 0, (size_t)ctx->ldv * sizeof(double), ctx->stream));
     if (int rc = upload_states(ctx, w, ctx->d_w.p, nlocal)) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -969,6 +996,8 @@ int kfsp_begin_step(kfsp_ctx *ctx, double *beta)
     if (ctx->ldv == 0) return fail(ctx, -1, "no matrix set");
     if (!beta) return fail(ctx, -2, "null beta");
     PhaseTimer timer(ctx, KFSP_T_BEGIN);
+    static const bool trace = std::getenv("KFSP_TRACE_BEGIN") != nullptr;   // diagnostics: profiles/begin_step_trace.sh
+    const auto t0 = std::chrono::steady_clock::now();
     HIP_TRY(hipSetDevice(ctx->device));
     double *part = next_partial(ctx);
     const int g = vec_grid(ctx);
@@ -978,8 +1007,15 @@ int kfsp_begin_step(kfsp_ctx *ctx, double *beta)
     double *hb = ctx->d_H.p + (size_t)kMH * kMH;   // scratch pair behind the H image
     launch_finalize(s, ctx->d_sq.p + 1, hb, ctx->stream);
     HIP_TRY(hipMemcpyAsync(ctx->h_pin, hb, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    const auto t1 = std::chrono::steady_clock::now();
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     *beta = ctx->h_pin[0];
+    if (trace) {
+        const auto t2 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "KFSP_TRACE_BEGIN n=%lld enqueue_us=%.1f sync_us=%.1f\n", (long long)ctx->n,
+                     std::chrono::duration<double, std::micro>(t1 - t0).count(),
+                     std::chrono::duration<double, std::micro>(t2 - t1).count());
+    }
     return 0;
 }
 
@@ -1248,6 +1284,98 @@ int kfsp_spmv_w(kfsp_ctx *ctx, double *y)
     if (int rc = spmv_plain(ctx, src, false, ctx->d_tmp.p)) return rc;
     if (int rc = download_states(ctx, ctx->d_tmp.p, y, ctx->nloc)) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int kfsp_drop_plan(kfsp_ctx *ctx, double dsum, double *droptol, int64_t *drop_count, int64_t *n_flagged)
+{
+    if (!ctx) return -1;
+    if (ctx->ldv == 0) return fail(ctx, -1, "no matrix set");
+    if (!(dsum > 0.0)) return fail(ctx, -2, "dsum must be positive (FIND_DROPTOL would not terminate)");
+    if (!droptol || !drop_count || !n_flagged) return fail(ctx, -3, "null output");
+    if (ctx->use_comm) return fail(ctx, -9, "kfsp_drop_* is not available with a communicator");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int64_t n = ctx->n;
+    ctx->drop_planned = false;
+    // FIND_DROPTOL: thresholds 1e-8, /10, /10, ... (the same divisions, so the same doubles), sixteen per pass
+    double *part = ctx->d_part.p;                       // kDropLevels * grid partials: the rotating buffers are idle between steps
+    const int grid = (int)std::min<int64_t>(vec_grid(ctx), (int64_t)kNumPartial * kMaxGrid / kfsp::kDropLevels);
+    double *sums_dev = ctx->d_H.p;                      // scratch: the H image is rewritten by the next pass anyway
+    double tol = 1.0e-8, found = -1.0;
+    for (int batch = 0; batch < 64 && found < 0.0; ++batch) {
+        kfsp::DropLevels L;
+        for (int k = 0; k < kfsp::kDropLevels; ++k) {
+            L.tol[k] = tol;
+            tol = tol / 10.0;
+        }
+        kfsp::launch_drop_sums(grid, act_pairs(ctx), ctx->d_w.p, L, part, sums_dev, st);
+        HIP_TRY(hipMemcpyAsync(ctx->h_pin, sums_dev, kfsp::kDropLevels * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        for (int k = 0; k < kfsp::kDropLevels; ++k)
+            if (ctx->h_pin[k] < dsum) {
+                found = L.tol[k];
+                break;
+            }
+    }
+    if (found < 0.0) return fail(ctx, -2, "no threshold satisfies the mass bound");
+    *droptol = found;
+    // A w into a basis column nobody needs between two steps, then the flags
+    double *aw = vcol(ctx, 1);
+    if (int rc = spmv_plain(ctx, ctx->d_w.p, false, aw)) return rc;
+    HIP_TRY(ctx->d_dropflag.reserve(2 * (size_t)(n + 256), false));
+    HIP_TRY(ctx->d_dropcnt.reserve(8, true));
+    HIP_TRY(hipMemsetAsync(ctx->d_dropcnt.p, 0, 4 * sizeof(unsigned long long), st));
+    kfsp::launch_drop_flags(n, ctx->d_w.p, aw, found, ctx->perm_on ? ctx->d_perm.p : nullptr, ctx->d_dropflag.p,
+                            ctx->d_dropcnt.p, st);
+    unsigned long long cnt[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(cnt, ctx->d_dropcnt.p, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *drop_count = (int64_t)cnt[0] - (int64_t)cnt[1];     // the reference's DROP_COUNT (:476-495)
+    *n_flagged = (int64_t)cnt[2];
+    ctx->drop_planned = true;
+    ctx->drop_n = n;
+    ctx->drop_flagged = (int64_t)cnt[2];
+    return 0;
+}
+
+int kfsp_drop_flags(kfsp_ctx *ctx, int64_t n, uint8_t *dropped)
+{
+    if (!ctx) return -1;
+    if (!ctx->drop_planned || ctx->drop_n != ctx->n) return fail(ctx, -1, "no drop plan for the current FSP");
+    if (n != ctx->n) return fail(ctx, -2, "n is not the size of the planned FSP");
+    if (!dropped) return fail(ctx, -3, "null flags");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpyAsync(dropped, ctx->d_dropflag.p, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int kfsp_drop_compact(kfsp_ctx *ctx, int64_t *n_new)
+{
+    if (!ctx) return -1;
+    if (!ctx->drop_planned || ctx->drop_n != ctx->n) return fail(ctx, -1, "no drop plan for the current FSP");
+    if (!n_new) return fail(ctx, -2, "null n_new");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int64_t n = ctx->n;
+    const double *src = ctx->d_w.p;
+    if (ctx->perm_on) {                                  // back to the caller's order first
+        HIP_TRY(ctx->d_pstage.reserve((size_t)n, false));
+        kfsp::launch_gather_index(n, ctx->d_iperm.p, ctx->d_w.p, ctx->d_pstage.p, st);
+        src = ctx->d_pstage.p;
+    }
+    HIP_TRY(hipMemsetAsync(ctx->d_tmp.p, 0, (size_t)ctx->ldv * sizeof(double), st));
+    int *nk_dev = reinterpret_cast<int *>(ctx->d_dropcnt.p + 3);
+    if (int rc = kfsp::drop_compact_vector(ctx, n, src, ctx->d_tmp.p, nk_dev)) return fail(ctx, rc, "device compaction failed");
+    int nk = 0;
+    HIP_TRY(hipMemcpyAsync(&nk, nk_dev, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if ((int64_t)nk != n - ctx->drop_flagged) return fail(ctx, 4000, "compaction count does not match the plan");
+    ctx->drop_planned = false;
+    ctx->w_pending = true;
+    ctx->w_pending_n = nk;
+    *n_new = nk;
     return 0;
 }
 

@@ -49,6 +49,12 @@ struct DevBuf {
 
 inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 
+// thresholds of one FIND_DROPTOL batch (StateSpace.f90:416-426: 1e-8, then /10 per sweep)
+constexpr int kDropLevels = 16;
+struct DropLevels {
+    double tol[kDropLevels];
+};
+
 // Loop-back transport: the ranks of a row partition are contexts of ONE process, each
 // driven by its own host thread, and "collectives" are host barriers around plain device
 // copies.  Everything above the collective itself - packing the strips, dropping the
@@ -111,7 +117,8 @@ struct kfsp_ctx {
     int64_t L = 0;        // rows per rank (padded block length), multiple of 64
     int64_t row0 = 0;     // first global row of this rank
     int64_t nloc = 0;     // rows owned
-    int64_t ldv = 0;      // column stride of the basis, multiple of 256
+    int64_t ldv = 0;      // column stride of the basis, multiple of 256; grows with head room, never shrinks
+    bool relayout = false;   // the partition changed: re-lay (and clear) the basis with the next generator
 
     // generator
     DevBuf<int64_t> d_off;
@@ -146,6 +153,16 @@ struct kfsp_ctx {
     int64_t perm_pending_n = 0;            // coordinates received for a generator of this size
     bool perm_on = false;                  // the current generator and vectors are permuted
     int64_t prod_count = 0, prod_last = 0; // products on the current / the previous generator
+
+    // DROP_STATES on the device (kfsp_drop.hip): one flag byte per state in the caller's order
+    // (+ the inverted copy the compaction needs), three counters, and the plan they belong to
+    DevBuf<uint8_t> d_dropflag;
+    DevBuf<unsigned long long> d_dropcnt;
+    bool drop_planned = false;
+    int64_t drop_n = 0, drop_flagged = 0;
+    // the compacted w (caller's order) waits in d_tmp for the generator of the compacted FSP
+    bool w_pending = false;
+    int64_t w_pending_n = 0;
 
     // vectors
     DevBuf<double> d_V;    // (kMMax+2) columns, stride ldv, unnormalised basis
@@ -197,4 +214,9 @@ int build_dia_mask(kfsp_ctx *ctx);
 int state_order_from_coords(kfsp_ctx *ctx, int32_t n, int32_t ns, int32_t ld, const int32_t *state, bool *ok);
 // dst[i'] = src[perm[i']] (host order -> device order) and dst[i] = src[iperm[i]] (back)
 void launch_gather_index(int64_t n, const int32_t *index, const double *src, double *dst, hipStream_t st);
+// DROP_STATES pieces (kfsp_drop.hip)
+void launch_drop_sums(int grid, int64_t npairs, const double *w, const DropLevels &L, double *partial, double *out, hipStream_t st);
+void launch_drop_flags(int64_t n, const double *w, const double *aw, double droptol, const int32_t *perm, uint8_t *flag,
+                       unsigned long long *cnt, hipStream_t st);
+int drop_compact_vector(kfsp_ctx *ctx, int64_t n, const double *src, double *dst, int *n_keep_dev);
 }  // namespace kfsp

@@ -51,6 +51,7 @@ MODULE KRYLOVSOLVER
   TYPE(FINITE_STATE_PROJECTION), POINTER, SAVE, PRIVATE :: CUR_FSP => NULL()
   TYPE(CME_MODEL), POINTER, SAVE, PRIVATE :: CUR_MODEL => NULL()
   INTEGER, SAVE, PRIVATE :: CUR_TRACE = 0
+  LOGICAL, SAVE, PRIVATE :: HOST_DROP = .FALSE.      ! KFSP_HOST_DROP=1: DROP_STATES decided on the host
   ! wall seconds spent in the host state-space code of the current solve:
   ! (1) DROP_STATES decision + compaction, (2) SSA_EXTENDER, (3) ONESTEP_EXTENDER,
   ! (4) uploads of the changed FSP
@@ -212,6 +213,8 @@ CONTAINS
        READ(ENV(1:L), *, IOSTAT=STAT) V8
        IF (STAT == 0) RC = KFSP_SET_OPTION(CTX, 'state_order' // C_NULL_CHAR, V8)
     ENDIF
+    CALL GET_ENVIRONMENT_VARIABLE('KFSP_HOST_DROP', ENV, L, STAT)
+    HOST_DROP = (STAT == 0 .AND. L > 0 .AND. ENV(1:1) /= '0')
     ! any other library option (kfsp_set_option, include/kfsp.h): KFSP_OPTIONS="name=value,name=value"
     CALL GET_ENVIRONMENT_VARIABLE('KFSP_OPTIONS', OPTS, L, STAT)
     IF (STAT == 0 .AND. L > 0) THEN
@@ -245,9 +248,10 @@ CONTAINS
   END SUBROUTINE CHECK
 
   ! generator columns + probability vector of the current FSP -> device
-  SUBROUTINE UPLOAD_FSP(FSP, MODEL)
+  SUBROUTINE UPLOAD_FSP(FSP, MODEL, WITH_VECTOR)
     TYPE(FINITE_STATE_PROJECTION), INTENT(IN) :: FSP
     TYPE(CME_MODEL), INTENT(IN) :: MODEL
+    LOGICAL, INTENT(IN), OPTIONAL :: WITH_VECTOR      ! .FALSE.: the device already holds the vector
     INTEGER(C_INT) :: RC
     ! the species counts let the device keep its own, locality-preserving state
     ! order if that was asked for (nothing changes on this side of the boundary)
@@ -257,21 +261,58 @@ CONTAINS
     RC = KFSP_SET_MATRIX_ELL(CTX, INT(FSP%SIZE, C_INT32_T), INT(MODEL%NREACTIONS, C_INT32_T), &
          INT(SIZE(FSP%MATRIX%ADJ, 1), C_INT32_T), FSP%MATRIX%ADJ, FSP%MATRIX%OFFDIAG, FSP%MATRIX%DIAG)
     CALL CHECK(RC, 'kfsp_set_matrix_ell')
+    IF (PRESENT(WITH_VECTOR)) THEN
+       IF (.NOT. WITH_VECTOR) RETURN
+    ENDIF
     RC = KFSP_SET_VECTOR(CTX, INT(FSP%SIZE, C_INT64_T), FSP%VECTOR)
     CALL CHECK(RC, 'kfsp_set_vector')
   END SUBROUTINE UPLOAD_FSP
 
-  ! DROP_STATES seam: the derivative guard's product A*w comes from the device
+  ! DROP_STATES seam (StateSpace.f90:431-548).  The decision - FIND_DROPTOL's threshold sums, the
+  ! marks, the derivative guard on A*w, DROP_COUNT and the 10 % rule - is taken on the device on
+  ! the resident vector (kfsp_drop_plan); nothing moves unless a compaction is due.  Then the flags
+  ! come over (one byte per state), the host compacts ITS lists with them, the device compacts w
+  ! where it lives, and only the generator of the compacted FSP is uploaded.
+  ! KFSP_HOST_DROP=1 keeps the round-1 path (w and A*w to the host, decision there).
   FUNCTION CB_DROP(USER, DSUM, N_NEW) BIND(C) RESULT(RC)
     TYPE(C_PTR), VALUE :: USER
     REAL(C_DOUBLE), VALUE :: DSUM
     INTEGER(C_INT64_T) :: N_NEW
     INTEGER(C_INT) :: RC
     DOUBLE PRECISION, ALLOCATABLE :: WLOC(:), AW(:)
+    INTEGER(C_INT8_T), ALLOCATABLE :: FLAGS(:)
     DOUBLE PRECISION :: D, T0
+    REAL(C_DOUBLE) :: DROPTOL
+    INTEGER(C_INT64_T) :: CNT, NFLAG, NKEEP
     LOGICAL :: CHANGED
     INTEGER :: N
     N = CUR_FSP%SIZE
+    IF (.NOT. HOST_DROP) THEN
+       T0 = WALL()
+       RC = KFSP_DROP_PLAN(CTX, DSUM, DROPTOL, CNT, NFLAG)
+       IF (RC /= 0) RETURN
+       HOST_SEC(1) = HOST_SEC(1) + (WALL() - T0)
+       N_NEW = N
+       IF (DBLE(CNT) * 1.0D0 / (DBLE(N) * 1.0D0) <= 0.1D0) RETURN          ! :497
+       T0 = WALL()
+       ALLOCATE(FLAGS(N))
+       RC = KFSP_DROP_FLAGS(CTX, INT(N, C_INT64_T), FLAGS)
+       IF (RC /= 0) RETURN
+       RC = KFSP_DROP_COMPACT(CTX, NKEEP)
+       IF (RC /= 0) RETURN
+       CALL DROP_APPLY_FLAGS(CUR_FSP, CUR_MODEL, FLAGS)
+       HOST_SEC(1) = HOST_SEC(1) + (WALL() - T0)
+       IF (CUR_FSP%SIZE /= NKEEP) THEN
+          RC = 4000
+          RETURN
+       ENDIF
+       T0 = WALL()
+       CALL UPLOAD_FSP(CUR_FSP, CUR_MODEL, .FALSE.)
+       HOST_SEC(4) = HOST_SEC(4) + (WALL() - T0)
+       N_NEW = CUR_FSP%SIZE
+       RC = 0
+       RETURN
+    ENDIF
     ALLOCATE(WLOC(N), AW(N))
     RC = KFSP_GET_VECTOR(CTX, INT(N, C_INT64_T), WLOC)
     IF (RC /= 0) RETURN

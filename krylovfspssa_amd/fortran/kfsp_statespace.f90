@@ -779,19 +779,13 @@ CONTAINS
     LOGICAL, INTENT(OUT) :: CHANGED
     LOGICAL, ALLOCATABLE :: DROP(:)
     LOGICAL :: MARK
-    INTEGER, ALLOCATABLE :: NEWIDX(:)
     DOUBLE PRECISION :: DROPTOL
-    INTEGER :: I, J, K, Q, N, CNT, SD, PD, NT, JF, NMOVE
+    INTEGER :: I, N, CNT, NT
     INTEGER(8) :: TCLK
-    DOUBLE PRECISION, ALLOCATABLE :: SCRD(:, :)
-    INTEGER, ALLOCATABLE :: SCRI(:, :)
-    INTEGER(8), ALLOCATABLE :: SCRK(:)
-    SD = MODEL%NSPECIES
-    PD = MODEL%NREACTIONS
     N = FSP%SIZE
     CHANGED = .FALSE.
     CALL TICK(0, TCLK)
-    CALL FIND_DROPTOL(SD, N, W, DROPTOL, DSUM)
+    CALL FIND_DROPTOL(MODEL%NSPECIES, N, W, DROPTOL, DSUM)
     ALLOCATE(DROP(N))
     NT = HOST_THREADS(N, 65536)
     CNT = 0
@@ -808,7 +802,44 @@ CONTAINS
     !$OMP END PARALLEL DO
     CALL TICK(6, TCLK)
     IF (CNT * 1.0D0 / (N * 1.0D0) <= 0.1D0) RETURN
+    CALL DROP_COMPACT(FSP, MODEL, DROP, W)
+    CHANGED = .TRUE.
+  END SUBROUTINE DROP_STATES_CORE
 
+  ! The same compaction when the decision was taken elsewhere (on the device, kfsp_drop_plan):
+  ! DROPPED(i) /= 0 marks the states to remove; the probability vector is compacted where it lives.
+  SUBROUTINE DROP_APPLY_FLAGS(FSP, MODEL, DROPPED)
+    TYPE(FINITE_STATE_PROJECTION) :: FSP
+    TYPE(CME_MODEL), INTENT(IN) :: MODEL
+    INTEGER(1), INTENT(IN) :: DROPPED(:)
+    LOGICAL, ALLOCATABLE :: DROP(:)
+    INTEGER(8) :: TCLK
+    CALL TICK(0, TCLK)
+    ALLOCATE(DROP(FSP%SIZE))
+    DROP = DROPPED(1:FSP%SIZE) /= 0_1
+    CALL TICK(6, TCLK)
+    CALL DROP_COMPACT(FSP, MODEL, DROP)
+  END SUBROUTINE DROP_APPLY_FLAGS
+
+  ! remove the states marked in DROP from the list, the columns and (when given) W; list order is
+  ! kept, links are renumbered, the table is rebuilt (StateSpace.f90:500-546)
+  SUBROUTINE DROP_COMPACT(FSP, MODEL, DROP, W)
+    TYPE(FINITE_STATE_PROJECTION) :: FSP
+    TYPE(CME_MODEL), INTENT(IN) :: MODEL
+    LOGICAL, INTENT(IN) :: DROP(:)
+    DOUBLE PRECISION, OPTIONAL :: W(:)
+    INTEGER, ALLOCATABLE :: NEWIDX(:)
+    INTEGER :: I, J, K, Q, N, SD, PD, NT, JF, NMOVE
+    INTEGER(8) :: TCLK
+    DOUBLE PRECISION, ALLOCATABLE :: SCRD(:, :)
+    INTEGER, ALLOCATABLE :: SCRI(:, :)
+    INTEGER(8), ALLOCATABLE :: SCRK(:)
+    LOGICAL :: HAVE_W
+    HAVE_W = PRESENT(W)
+    SD = MODEL%NSPECIES
+    PD = MODEL%NREACTIONS
+    N = FSP%SIZE
+    CALL TICK(0, TCLK)
     ! new numbers of the states that stay (list order is kept, :500-546)
     ALLOCATE(NEWIDX(N))
     Q = 0
@@ -852,7 +883,7 @@ CONTAINS
           I = NEWIDX(J) - JF + 1
           IF (I > 0) THEN
              SCRD(1, I) = FSP%MATRIX%DIAG(J)
-             SCRD(2, I) = W(J)
+             IF (HAVE_W) SCRD(2, I) = W(J)
              SCRI(1:SD, I) = FSP%STATE(1:SD, J)
           ENDIF
        ENDDO
@@ -860,14 +891,14 @@ CONTAINS
        !$OMP DO SCHEDULE(STATIC)
        DO I = 1, NMOVE
           FSP%MATRIX%DIAG(JF + I - 1) = SCRD(1, I)
-          W(JF + I - 1) = SCRD(2, I)
+          IF (HAVE_W) W(JF + I - 1) = SCRD(2, I)
           FSP%STATE(1:SD, JF + I - 1) = SCRI(1:SD, I)
        ENDDO
        !$OMP END DO
        !$OMP END PARALLEL
        DEALLOCATE(SCRD, SCRI, SCRK)
     ENDIF
-    W(Q + 1:N) = 0.0D0
+    IF (HAVE_W) W(Q + 1:N) = 0.0D0
     FSP%SIZE = Q
     FSP%MATRIX%SIZE = Q
     CALL TICK(7, TCLK)
@@ -882,8 +913,7 @@ CONTAINS
     CALL TICK(8, TCLK)
     CALL REBUILD_TABLE(FSP)
     CALL TICK(9, TCLK)
-    CHANGED = .TRUE.
-  END SUBROUTINE DROP_STATES_CORE
+  END SUBROUTINE DROP_COMPACT
 
   ! reference signature: FMATVEC(X, Y, MATRIX) computes Y = A X
   SUBROUTINE DROP_STATES(W, FSP, MODEL, DSUM, FMATVEC)

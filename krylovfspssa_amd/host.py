@@ -56,6 +56,9 @@ def load_library():
         "kfsp_matrix_info": [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)],
         "kfsp_matrix_bytes": [vp, C.c_int, C.POINTER(i64)],
         "kfsp_num_states": [vp, C.POINTER(i64)],
+        "kfsp_drop_plan": [vp, dbl, C.POINTER(dbl), C.POINTER(i64), C.POINTER(i64)],
+        "kfsp_drop_flags": [vp, i64, vp],
+        "kfsp_drop_compact": [vp, C.POINTER(i64)],
         "kfsp_dgexpv": [vp, dbl, dbl, dbl, C.c_int, vp, vp],
         "kfsp_set_vector": [vp, i64, vp],
         "kfsp_get_vector": [vp, i64, vp],
@@ -282,6 +285,22 @@ class KfspContext:
         return dict(rows=a.value, slots=b.value, nnz=c.value)
 
     # -- vectors
+    def drop_plan(self, dsum):
+        """DROP_STATES decision on the device -> (droptol, drop_count, n_flagged)."""
+        tol, cnt, nf = C.c_double(0.0), C.c_int64(0), C.c_int64(0)
+        self._chk(self._lib.kfsp_drop_plan(self._h, float(dsum), C.byref(tol), C.byref(cnt), C.byref(nf)), "kfsp_drop_plan")
+        return tol.value, cnt.value, nf.value
+
+    def drop_flags(self):
+        f = np.zeros(self.n, dtype=np.uint8)
+        self._chk(self._lib.kfsp_drop_flags(self._h, int(self.n), _p(f)), "kfsp_drop_flags")
+        return f
+
+    def drop_compact(self):
+        n = C.c_int64(0)
+        self._chk(self._lib.kfsp_drop_compact(self._h, C.byref(n)), "kfsp_drop_compact")
+        return n.value
+
     def matrix_bytes(self, force_sell=False):
         b = C.c_int64(0)
         self._chk(self._lib.kfsp_matrix_bytes(self._h, int(bool(force_sell)), C.byref(b)), "kfsp_matrix_bytes")

@@ -67,12 +67,24 @@ CONTAINS
     END SELECT
   END SUBROUTINE LOAD_INPUT_MODEL
 
+  ! capacity of the FSPs the solve cases create: TABLEN, or the (prime) number in the environment
+  ! variable KFSP_CASE_CAPACITY for runs that outgrow it (Goutsias at T = 300 reaches 1.03e6 states;
+  ! 2097169 and 6291469 = NMAX, StateSpace.f90:10, are primes)
+  INTEGER FUNCTION CASE_CAPACITY()
+    CHARACTER(LEN=32) :: ENV
+    INTEGER :: L, STAT
+    CASE_CAPACITY = TABLEN
+    CALL GET_ENVIRONMENT_VARIABLE('KFSP_CASE_CAPACITY', ENV, L, STAT)
+    IF (STAT == 0 .AND. L > 0) READ(ENV(1:L), *, IOSTAT=STAT) CASE_CAPACITY
+    IF (CASE_CAPACITY < 16) CASE_CAPACITY = TABLEN
+  END FUNCTION CASE_CAPACITY
+
   SUBROUTINE SEED_POINT(MODEL, FSP_IN, FSP, X0)
     TYPE(CME_MODEL), INTENT(IN) :: MODEL
     TYPE(FINITE_STATE_PROJECTION), INTENT(INOUT) :: FSP_IN, FSP
     INTEGER, INTENT(IN) :: X0(:)
-    CALL FSP_IN%CREATE(MODEL, TABLEN)
-    CALL FSP%CREATE(MODEL, TABLEN)
+    CALL FSP_IN%CREATE(MODEL, CASE_CAPACITY())
+    CALL FSP%CREATE(MODEL, CASE_CAPACITY())
     FSP_IN%SIZE = 1
     FSP_IN%STATE(:, 1) = X0
     FSP_IN%VECTOR = 0.0D0
