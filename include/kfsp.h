@@ -85,14 +85,14 @@ int kfsp_set_matrix_ell(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld,
  * (species 1 fastest), so that the gathers of a product coalesce (2x on the
  * product at 10^6 discovery-ordered states).  Nothing changes at the boundary:
  * every array handed in or out stays in the caller's order.
- * OFF unless option state_order = 1: rows are then summed in the internal
- * column order instead of FMATVEC's (KrylovSolver.f90:598-604), i.e. results
- * differ from the default path at rounding level.  When on it applies to the
- * next kfsp_set_matrix_ell with the same n only, and not below option
- * state_order_min states, with a communicator, or while generators are
- * short-lived (the one being replaced saw fewer than option
- * state_order_products products: reordering costs about 20 of them at 10^6
- * states). */
+ * Every row is still summed in FMATVEC's order (KrylovSolver.f90:598-604: its entries are
+ * kept sorted by the CALLER's column index), so products are bit-identical to the plain path;
+ * only the reductions over states (dot products, norms, WSUM) add their terms in another
+ * order.  ON by default (option state_order = 0 switches it off); it applies to the next
+ * kfsp_set_matrix_ell with the same n only, and not below option state_order_min states
+ * (default 32768), with a communicator, or while generators are short-lived (the one being
+ * replaced saw fewer than option state_order_products products, default 48: reordering costs
+ * about 20 of them at 10^6 states). */
 int kfsp_set_state_coords(kfsp_ctx *ctx, int32_t n, int32_t ns, int32_t ld, const int32_t *state);
 /* 1 if the generator last set is held in the internal state order */
 int kfsp_state_order_active(const kfsp_ctx *ctx, int *active);
@@ -325,7 +325,7 @@ int kfsp_add_timer(kfsp_ctx *ctx, int phase, double ms);
 /* tuning knobs (name/value); unknown name -> -2: "grid_blocks",
  * "vec_grid_blocks", "nt_loads", "format", "fused_ortho",
  * "host_build", "halo", "overlap", "small_kernel", "small_lds", "dia_mask", "state_order" (1: use
- * kfsp_set_state_coords; default 0), "state_order_min" (smallest generator that is
+ * kfsp_set_state_coords, the default; 0: never), "state_order_min" (smallest generator that is
  * reordered, default 32768), "state_order_products" (products the previous
  * generator must have seen, default 48) ... see DESIGN.md */
 int kfsp_set_option(kfsp_ctx *ctx, const char *name, int64_t value);

@@ -315,10 +315,12 @@ __global__ __launch_bounds__(kBlock) void k_sell_fill(int64_t n, int bw, int ld,
 }
 
 // each row's entries ascending by (source, value): deterministic, and the order
-// in which the reference's scatter loop adds them
+// in which the reference's scatter loop adds them.  Under the internal state order the key is the
+// CALLER's index of the source (perm: internal -> caller), so that a row is summed in FMATVEC's
+// order (KrylovSolver.f90:598-604) whatever order the device keeps the states in.
 __global__ __launch_bounds__(kBlock) void k_sell_sort_rows(int64_t nloc, const int32_t *__restrict__ cnt,
                                                            const int64_t *__restrict__ off, int32_t *__restrict__ col,
-                                                           double *__restrict__ val)
+                                                           double *__restrict__ val, const int32_t *__restrict__ perm)
 {
     const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (r >= nloc) return;
@@ -328,11 +330,13 @@ __global__ __launch_bounds__(kBlock) void k_sell_sort_rows(int64_t nloc, const i
     for (int a = 1; a < m; ++a) {                          // insertion sort, m <= #reactions
         const int32_t ca = col[base + (int64_t)a * kChunk];
         const double va = val[base + (int64_t)a * kChunk];
+        const int32_t ka = perm ? perm[ca] : ca;
         int b = a - 1;
         while (b >= 0) {
             const int32_t cb = col[base + (int64_t)b * kChunk];
             const double vb = val[base + (int64_t)b * kChunk];
-            if (cb < ca || (cb == ca && vb <= va)) break;
+            const int32_t kb = perm ? perm[cb] : cb;
+            if (kb < ka || (kb == ka && vb <= va)) break;
             col[base + (int64_t)(b + 1) * kChunk] = cb;
             val[base + (int64_t)(b + 1) * kChunk] = vb;
             --b;
@@ -485,7 +489,8 @@ int build_from_ell_device(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, cons
         hipLaunchKernelGGL(k_sell_fill, dim3(gsrc), dim3(kBlock), 0, st, (int64_t)n, (int)bw, (int)ld, ell_adj,
                            ell_off, row0, nloc, ctx->d_off.p, ctx->d_ticket.p, ctx->d_col.p, ctx->d_val.p);
         hipLaunchKernelGGL(k_sell_sort_rows, dim3((int)((nloc + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, nloc,
-                           ctx->d_cnt.p, ctx->d_off.p, ctx->d_col.p, ctx->d_val.p);
+                           ctx->d_cnt.p, ctx->d_off.p, ctx->d_col.p, ctx->d_val.p,
+                           ctx->perm_on ? ctx->d_perm.p : (const int32_t *)nullptr);
     }
     HIP_TRY_B(hipStreamSynchronize(st));
     ctx->have_sell = true;

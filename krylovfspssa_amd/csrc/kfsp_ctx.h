@@ -196,7 +196,7 @@ struct kfsp_ctx {
     int64_t opt_small_lds = 1;            // 0: the one-launch Arnoldi kernel reads the generator from global memory
     int64_t lds_per_block = 65536;        // device limit (hipDeviceAttributeMaxSharedMemoryPerBlock)
     int64_t opt_dia_mask = 1;             // 0: never skip empty diagonal segments
-    int64_t opt_state_order = 0;          // 1: use kfsp_set_state_coords (off: sums stay in the reference's order)
+    int64_t opt_state_order = 1;          // 1: use kfsp_set_state_coords for large, long-lived generators (0: never)
     int64_t opt_state_order_min = 32768;  // smallest generator that is reordered
     int64_t opt_state_order_products = 48;   // ... and only if its predecessor saw this many products
     double t_ms[KFSP_T_COUNT] = {0, 0, 0, 0, 0, 0};
