@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--no-expv", action="store_true")
     ap.add_argument("--expv-steps", type=int, default=10)
     ap.add_argument("--opt", action="append", default=[], help="library option name=value")
+    ap.add_argument("--matrix-free", action="store_true",
+                    help="box workloads: no stored generator, propensities from factor tables in the kernel (kfsp_set_matrix_box)")
     ap.add_argument("--force-comm", action="store_true",
                     help="create the RCCL communicator even with one rank (exercises the collective path on one GPU)")
     return ap.parse_args()
@@ -177,7 +179,10 @@ def main():
     rowptr, col, val = mdl.csr_rows(row0, nrows)
     t_gen = time.time() - t0
     nnz_global = mdl.nnz()
-    ctx.set_matrix_csr(mdl.n, rowptr, col, val)
+    if args.matrix_free:
+        ctx.set_matrix_box(mdl)
+    else:
+        ctx.set_matrix_csr(mdl.n, rowptr, col, val)
     nnz_local = int(rowptr[-1])
     x = np.random.default_rng(12345 + rank).random(nrows)
     ctx.set_vector(x)
@@ -232,7 +237,10 @@ def main():
             if check_err < 1e-12:
                 break
             ctx.set_option(opt, 0)
-            ctx.set_matrix_csr(mdl.n, rowptr, col, val)
+            if args.matrix_free:
+                ctx.set_matrix_box(mdl)
+            else:
+                ctx.set_matrix_csr(mdl.n, rowptr, col, val)
             ctx.set_vector(x)
             ctx.begin_step()
             exchange = label
@@ -257,7 +265,7 @@ def main():
     real_bytes = ctx.matrix_bytes(force_sell=(args.variant == 2))
     traffic, traffic_src = None, None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    plain_run = world == 1 and not args.opt and not args.force_comm and args.variant in (0, 2)
+    plain_run = world == 1 and not args.opt and not args.force_comm and args.variant in (0, 2) and not args.matrix_free
     if plain_run and os.path.exists(tpath):
         try:
             key = args.workload + ("_sell64" if args.variant == 2 else "")
@@ -286,7 +294,8 @@ def main():
             "nnz_total": int(nnz_global), "alg_bytes_per_launch_total": int(b_alg_global),
             "partition": f"rows x{world}" if world > 1 else "single GPU",
             "exchange": exchange,
-            "kernel_variant": {0: "auto (banded DIA when the rows allow it, else SELL-64)", 2: "sell64"}[args.variant],
+            "kernel_variant": "matrix-free box (no stored generator; factor tables in LDS)" if args.matrix_free else
+                              {0: "auto (banded DIA when the rows allow it, else SELL-64)", 2: "sell64"}[args.variant],
             "stored_slots_local": info["slots"],
         },
         "self_check": {"ok": bool(check_ok), "max_rel_err": check_err,

@@ -101,6 +101,24 @@ int kfsp_state_order_active(const kfsp_ctx *ctx, int *active);
  * as an ordinary (negative) entry.  rowptr has nrows+1 entries starting at 0. */
 int kfsp_set_matrix_csr(kfsp_ctx *ctx, int64_t n, int64_t row0, int64_t nrows,
                         const int64_t *rowptr, const int32_t *col, const double *val);
+/* Matrix-free generator of a lexicographic BOX [0,dims[0]) x ... x [0,dims[ns-1]) (species 1
+ * fastest; n = prod dims states, state index = sum x_s stride_s) for propensities that are products
+ * of one-species factors, a_k(x) = prod_{i < ndep[k]} T_{k,i}[x_{dep_species[k][i]}] - mass action,
+ * Hill functions of one species, ...: the kernel stores NO generator entries, it rebuilds every row
+ * of FMATVEC (KrylovSolver.f90:577-607) on the FSP = the box from the row index and the factor
+ * tables (DIAG = the sum of ALL propensities, StateSpace.f90:207-212), moving 16 B per state
+ * (x once, y once) instead of 8 B per stored entry + 24 B.  The tables are made on the host with
+ * the model's own propensity code (ModelModule.f90:163-199 evaluated at every population count),
+ * so a propensity with one factor has exactly the stored value.
+ *   stoich       [nr][ns] state change of each reaction
+ *   ndep         [nr]     factors of each propensity, 1..3
+ *   dep_species  [nr][3]  0-based species of each factor (unused entries ignored)
+ *   tables       the factors, concatenated reaction by reaction, factor by factor; factor (k, i) has
+ *                dims[dep_species[k][i]] entries (a constant propensity is one table of equal entries)
+ * Works with a communicator like a banded generator (halo strips).  ns <= 8, nr <= 16, every reaction
+ * changes <= 3 species, all tables together <= 6000 entries. */
+int kfsp_set_matrix_box(kfsp_ctx *ctx, int32_t ns, const int32_t *dims, int32_t nr, const int32_t *stoich,
+                        const int32_t *ndep, const int32_t *dep_species, const double *tables);
 /* what the device holds: rows (local), stored off-diagonal slots incl. padding,
  * true nonzeros incl. diagonal (local rows) */
 int kfsp_matrix_info(const kfsp_ctx *ctx, int64_t *nrows, int64_t *slots, int64_t *nnz);
@@ -324,7 +342,8 @@ int kfsp_add_timer(kfsp_ctx *ctx, int phase, double ms);
 
 /* tuning knobs (name/value); unknown name -> -2: "grid_blocks",
  * "vec_grid_blocks", "nt_loads", "format", "fused_ortho",
- * "host_build", "halo", "overlap", "small_kernel", "small_lds", "dia_mask", "state_order" (1: use
+ * "host_build", "halo", "overlap", "small_kernel", "small_lds", "dia_mask", "box_generic" (1: matrix-free boxes take
+ * the run-time interpreted kernel even when the single-factor fast path applies), "state_order" (1: use
  * kfsp_set_state_coords, the default; 0: never), "state_order_min" (smallest generator that is
  * reordered, default 32768), "state_order_products" (products the previous
  * generator must have seen, default 48) ... see DESIGN.md */

@@ -139,6 +139,10 @@ void set_matrix_args(const kfsp_ctx *c, SpmvArgs &a)
     a.D.n = c->n;
     a.D.gmask = c->dia_masked ? c->d_gmask.p : nullptr;
     a.D.zero = c->d_zero.p;
+    if (c->use_box) a.B = c->box;
+    else a.B.ns = a.B.nr = a.B.ntab = 0;
+    a.box_tab = c->d_box.p;
+    a.box_fast = reinterpret_cast<const BoxFast *>(c->d_box.p + (c->box_lds_bytes / sizeof(double)));
     a.udot2 = nullptr;
     a.partial2 = nullptr;
 }
@@ -261,7 +265,7 @@ int run_product(kfsp_ctx *ctx, int mode, SpmvArgs a, const double *src, bool src
         a.trip_split = INT64_MAX;
         a.trip_jump = 0;
         const int g = trips_grid(trips, cap);
-        launch_spmv(mode, g, a, nt, dia ? (ctx->dia_masked ? 2 : 1) : 0, st);
+        launch_spmv(mode, g, a, nt, (ctx->use_box && dia) ? (ctx->box_fast && !ctx->opt_box_generic ? 4 : 3) : (dia ? (ctx->dia_masked ? 2 : 1) : 0), st, ctx->box_lds_bytes);
         if (p1) *p1 = Pending{P1, g};
         if (p2) *p2 = Pending{P2, g};
         return 0;
@@ -282,7 +286,7 @@ int run_product(kfsp_ctx *ctx, int mode, SpmvArgs a, const double *src, bool src
         a.trip_end = e;
         a.trip_split = split;
         a.trip_jump = jump;
-        launch_spmv(mode, g, a, nt, ctx->dia_masked ? 2 : 1, st);
+        launch_spmv(mode, g, a, nt, ctx->use_box ? (ctx->box_fast && !ctx->opt_box_generic ? 4 : 3) : (ctx->dia_masked ? 2 : 1), st, ctx->box_lds_bytes);
         used += g;
     };
     launch_range(lo, hi, INT64_MAX, 0, std::min<int64_t>(cap, kMaxGrid - 512));   // interior: no halo row is read
@@ -639,7 +643,7 @@ int kfsp_destroy(kfsp_ctx *ctx)
     ctx->d_y.release(); ctx->d_flag.release(); ctx->d_g.release(); ctx->d_dia.release();
     ctx->d_ell_adj.release(); ctx->d_ell_off.release(); ctx->d_ell_diag.release(); ctx->d_cnt.release();
     ctx->d_ticket.release(); ctx->d_slot.release(); ctx->d_scan.release(); ctx->d_strip.release();
-    ctx->d_dropflag.release(); ctx->d_dropcnt.release();
+    ctx->d_dropflag.release(); ctx->d_dropcnt.release(); ctx->d_box.release();
     ctx->d_perm.release(); ctx->d_iperm.release(); ctx->d_coords.release(); ctx->d_ell_adj2.release();
     ctx->d_ell_off2.release(); ctx->d_ell_diag2.release(); ctx->d_pstage.release(); ctx->d_keys.release();
     ctx->d_sortidx.release(); ctx->d_sorttmp.release(); ctx->d_gmask.release(); ctx->d_zero.release();
@@ -778,6 +782,8 @@ int kfsp_set_matrix_ell(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, const 
         if (!diag) return fail(ctx, -7, "null diag");
         HIP_TRY(hipSetDevice(ctx->device));
         auto t0 = std::chrono::steady_clock::now();
+        ctx->use_box = false;
+        ctx->box_lds_bytes = 0;
         if (int rc = resize(ctx, n)) return rc;
         const int64_t row0 = ctx->row0, nloc = ctx->nloc;
         // coordinates handed over for exactly this generator switch the internal order on
@@ -852,6 +858,8 @@ int kfsp_set_matrix_csr(kfsp_ctx *ctx, int64_t n, int64_t row0, int64_t nrows, c
         ctx->perm_pending_n = 0;
         ctx->prod_last = ctx->prod_count;
         ctx->prod_count = 0;
+        ctx->use_box = false;
+        ctx->box_lds_bytes = 0;
         if (int rc = resize(ctx, n)) return rc;
         if (row0 != std::min(ctx->row0, n)) return fail(ctx, -3, "row0 is not this rank's block start (kfsp_row_block)");
         if (nrows != ctx->nloc) return fail(ctx, -4, "nrows is not this rank's block size (kfsp_row_block)");
@@ -897,6 +905,173 @@ int kfsp_set_matrix_csr(kfsp_ctx *ctx, int64_t n, int64_t row0, int64_t nrows, c
     });
 }
 
+int kfsp_set_matrix_box(kfsp_ctx *ctx, int32_t ns, const int32_t *dims, int32_t nr, const int32_t *stoich,
+                        const int32_t *ndep, const int32_t *dep_species, const double *tables)
+{
+    return no_throw(ctx, [&]() -> int {
+        if (!ctx) return -1;
+        if (ns < 1 || ns > kfsp::kBoxMaxS) return fail(ctx, -2, "1 <= ns <= 8");
+        if (!dims) return fail(ctx, -3, "null dims");
+        if (nr < 1 || nr > kfsp::kBoxMaxR) return fail(ctx, -4, "1 <= nr <= 16");
+        if (!stoich || !ndep || !dep_species) return fail(ctx, -5, "null reaction description");
+        if (!tables) return fail(ctx, -8, "null tables");
+        int64_t n = 1, stride[kfsp::kBoxMaxS];
+        for (int s = 0; s < ns; ++s) {
+            if (dims[s] < 1) return fail(ctx, -3, "dims must be positive");
+            stride[s] = n;
+            n *= dims[s];
+            if (n > 2147483647LL - 512) return fail(ctx, -3, "box has more than 2^31 states");
+        }
+        if (n < 2) return fail(ctx, -3, "box has fewer than 2 states");
+        HIP_TRY(hipSetDevice(ctx->device));
+        auto t0 = std::chrono::steady_clock::now();
+        ctx->perm_on = false;
+        ctx->perm_pending_n = 0;
+        ctx->prod_last = ctx->prod_count;
+        ctx->prod_count = 0;
+        if (int rc = resize(ctx, n)) return rc;
+        // reactions sorted by the column offset of their entry (ascending, like the stored diagonals)
+        struct R { int64_t delta; int k; };
+        std::vector<R> order((size_t)nr);
+        for (int k = 0; k < nr; ++k) {
+            int64_t d = 0;
+            for (int s = 0; s < ns; ++s) d -= (int64_t)stoich[(size_t)k * ns + s] * stride[s];
+            order[(size_t)k] = R{d, k};
+        }
+        std::stable_sort(order.begin(), order.end(), [](const R &a, const R &b) { return a.delta < b.delta; });
+        kfsp::BoxDev B;
+        std::memset(&B, 0, sizeof(B));
+        B.ns = ns;
+        B.nr = nr;
+        for (int s = 0; s < ns; ++s) {
+            B.dims[s] = dims[s];
+            B.inv_dim[s] = 1.0 / (double)dims[s];
+        }
+        // table offsets in the order the caller concatenated them: reaction by reaction, factor by factor
+        std::vector<int32_t> toff((size_t)nr * kfsp::kBoxMaxDep, 0);
+        int64_t ntab = 0;
+        for (int k = 0; k < nr; ++k) {
+            if (ndep[k] < 1 || ndep[k] > kfsp::kBoxMaxDep) return fail(ctx, -6, "1 <= ndep <= 3 factors per propensity");
+            for (int i = 0; i < ndep[k]; ++i) {
+                const int s = dep_species[(size_t)k * kfsp::kBoxMaxDep + i];
+                if (s < 0 || s >= ns) return fail(ctx, -7, "factor species out of range");
+                toff[(size_t)k * kfsp::kBoxMaxDep + i] = (int32_t)ntab;
+                ntab += dims[s];
+            }
+        }
+        if (ntab + dims[0] > 6000) return fail(ctx, -8, "factor tables exceed the 48 KB they may take in LDS");
+        B.ntab = (int32_t)ntab;
+        for (int p = 0; p < nr; ++p) {
+            const int k = order[(size_t)p].k;
+            B.delta[p] = (int32_t)order[(size_t)p].delta;
+            B.ndep[p] = (int8_t)ndep[k];
+            for (int i = 0; i < ndep[k]; ++i) {
+                const int s = dep_species[(size_t)k * kfsp::kBoxMaxDep + i];
+                B.dep_s[p][i] = (int8_t)s;
+                B.dep_nu[p][i] = (int8_t)stoich[(size_t)k * ns + s];
+                B.dep_off[p][i] = toff[(size_t)k * kfsp::kBoxMaxDep + i];
+            }
+            int nm = 0;
+            for (int s = 0; s < ns; ++s) {
+                const int v = stoich[(size_t)k * ns + s];
+                if (v == 0) continue;
+                if (nm == kfsp::kBoxMaxDep) return fail(ctx, -5, "a reaction changes more than 3 species");
+                if (v < -100 || v > 100) return fail(ctx, -5, "stoichiometry out of range");
+                B.mov_s[p][nm] = (int8_t)s;
+                B.mov_nu[p][nm] = (int8_t)v;
+                B.mov_dim[p][nm] = dims[s];
+                ++nm;
+            }
+            B.nmov[p] = (int8_t)nm;
+            B.dorder[k] = p;                               // original reaction k sits at sorted position p
+        }
+        // single-factor fast form: every propensity one factor, no species changes by more than 2, at
+        // most kBoxFastPer propensities per species
+        kfsp::BoxFast F;
+        std::memset(&F, 0, sizeof(F));
+        bool fast = ns <= kfsp::kBoxFastS;
+        int per_species[kfsp::kBoxMaxS] = {0};
+        for (int k = 0; k < nr && fast; ++k) {
+            fast = ndep[k] == 1;
+            for (int s = 0; s < ns; ++s) fast = fast && std::abs(stoich[(size_t)k * ns + s]) <= 2;
+            if (fast) fast = ++per_species[dep_species[(size_t)k * kfsp::kBoxMaxDep]] <= kfsp::kBoxFastPer;
+        }
+        if (fast) {
+            int per = 2;
+            for (int s = 0; s < ns; ++s) per = std::max(per, per_species[s]);
+            if (per > 2) per = kfsp::kBoxFastPer;
+            // instantiations (launch_spmv): 2, 3 or 6 species with 2 slots each, else 6 species with 4 slots
+            const int ns_inst = (per == 2 && ns <= 2) ? 2 : (per == 2 && ns == 3) ? 3 : kfsp::kBoxFastS;
+            F.ns = ns_inst;
+            F.per = per;
+            for (int s = 0; s < kfsp::kBoxFastS; ++s) {
+                F.dims[s] = s < ns ? dims[s] : 1;                 // missing species: one population count, 0
+                F.inv_dim[s] = 1.0 / (double)F.dims[s];
+                for (int j = 0; j < kfsp::kBoxFastPer; ++j) F.need[s][j] = 0x80000000u;   // padding: never inside the box
+            }
+            int fill[kfsp::kBoxFastS] = {0};
+            for (int p = 0; p < nr; ++p) {                        // ascending column offset within a species
+                const int k = order[(size_t)p].k;
+                const int s = dep_species[(size_t)k * kfsp::kBoxMaxDep];
+                const int j = fill[s]++;
+                F.off[s][j] = toff[(size_t)k * kfsp::kBoxMaxDep];
+                F.nu[s][j] = stoich[(size_t)k * ns + s];
+                F.delta[s][j] = (int32_t)order[(size_t)p].delta;
+                uint32_t need = 0;
+                for (int t = 0; t < ns; ++t) {
+                    const int v = stoich[(size_t)k * ns + t];     // source coordinate = x_t - v
+                    if (v == 1) need |= 1u << (4 * t);
+                    if (v == 2) need |= 2u << (4 * t);
+                    if (v == -1) need |= 4u << (4 * t);
+                    if (v == -2) need |= 8u << (4 * t);
+                }
+                F.need[s][j] = need;
+            }
+            B.pad = ns_inst * 16 + per;
+        }
+        // dims[0] zeros behind the tables: the factor of the padded entries
+        const int64_t ntab_real = ntab;
+        ntab += dims[0];
+        F.zoff = (int32_t)ntab_real;
+        if (fast)
+            for (int s = 0; s < kfsp::kBoxFastS; ++s)
+                for (int j = 0; j < kfsp::kBoxFastPer; ++j)
+                    if (F.need[s][j] == 0x80000000u) F.off[s][j] = (int32_t)ntab_real;
+        B.ntab = (int32_t)ntab;
+        const size_t fwords = (sizeof(kfsp::BoxFast) + 7) / 8;
+        std::vector<double> image((size_t)ntab + fwords, 0.0);
+        std::memcpy(image.data(), tables, (size_t)ntab_real * sizeof(double));
+        std::memcpy(image.data() + ntab, &F, sizeof(F));
+        HIP_TRY(ctx->d_box.reserve(image.size() + 8, false));
+        HIP_TRY(hipMemcpy(ctx->d_box.p, image.data(), image.size() * sizeof(double), hipMemcpyHostToDevice));
+        ctx->box = B;
+        ctx->box_fast = fast;
+        ctx->box_lds_bytes = (size_t)ntab * sizeof(double);
+        // the same bookkeeping as a banded generator with one diagonal per reaction
+        ctx->nchunks = (ctx->nloc + kChunk - 1) / kChunk;
+        ctx->slots = 0;
+        int64_t nnz = n;
+        for (int k = 0; k < nr; ++k) {
+            int64_t c = 1;
+            for (int s = 0; s < ns; ++s) c *= std::max<int64_t>(0, dims[s] - std::abs(stoich[(size_t)k * ns + s]));
+            nnz += c;
+        }
+        ctx->nnz = ctx->nranks == 1 ? nnz : 0;             // (per-rank counts are not tracked for boxes)
+        ctx->use_dia = true;
+        ctx->use_box = true;
+        ctx->dia_masked = false;
+        ctx->have_sell = false;
+        ctx->nd = nr;
+        for (int p = 0; p < nr; ++p) ctx->delta[p] = B.delta[p];
+        ctx->dia_ld = round_up(ctx->nchunks * kChunk, 2 * kChunk);
+        HIP_TRY(ctx->d_diag.reserve((size_t)ctx->dia_ld + 2 * kChunk, true));
+        if (int rc = setup_exchange(ctx)) return rc;
+        if (int rc = adopt_pending_vector(ctx)) return rc;
+        ctx->t_ms[KFSP_T_UPLOAD] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return 0;
+    });
+}
+
 int kfsp_set_state_coords(kfsp_ctx *ctx, int32_t n, int32_t ns, int32_t ld, const int32_t *state)
 {
     return no_throw(ctx, [&]() -> int {
@@ -934,7 +1109,7 @@ int kfsp_matrix_info(const kfsp_ctx *ctx, int64_t *nrows, int64_t *slots, int64_
 {
     if (!ctx) return -1;
     if (nrows) *nrows = ctx->nloc;
-    if (slots) *slots = ctx->use_dia ? (int64_t)ctx->nd * ctx->dia_ld : ctx->slots;
+    if (slots) *slots = ctx->use_box ? 0 : (ctx->use_dia ? (int64_t)ctx->nd * ctx->dia_ld : ctx->slots);
     if (nnz) *nnz = ctx->nnz;
     return 0;
 }
@@ -946,7 +1121,9 @@ int kfsp_matrix_bytes(const kfsp_ctx *ctx, int force_sell, int64_t *bytes)
     if (ctx->ldv == 0) return -1;
     const int64_t rows = ctx->nchunks * kChunk;
     int64_t b = rows * 24;                                    // diag, x (once), y
-    if (ctx->use_dia && !force_sell) {
+    if (ctx->use_box && !force_sell) {
+        b = rows * 16 + (int64_t)ctx->box_lds_bytes;          // x once, y; the tables are read once per workgroup from cache
+    } else if (ctx->use_dia && !force_sell) {
         b += (int64_t)ctx->nd * ctx->dia_ld * 8;
         if (ctx->dia_masked) b += (ctx->dia_ld >> 7) * 4 - ctx->dia_empty_segments * 128 * 8;
     } else {
@@ -1047,7 +1224,7 @@ int kfsp_arnoldi(kfsp_ctx *ctx, int m, int jold, int qiop, double break_tol, dou
     double *gfin = ctx->d_g.p;
     // small state spaces: the whole pass in one launch of one workgroup
     const bool small = fused && !ctx->use_comm && ctx->opt_small != 0 && ctx->nchunks * kChunk <= kSmallRows &&
-                       (ctx->use_dia || ctx->have_sell);
+                       (ctx->use_dia || ctx->have_sell) && !ctx->use_box;
     if (small) {
         SmallArnoldiArgs sa;
         SpmvArgs tmp;
@@ -1517,6 +1694,7 @@ int kfsp_set_option(kfsp_ctx *ctx, const char *name, int64_t value)
     else if (k == "fused_ortho") ctx->opt_fused = value;
     else if (k == "host_build") ctx->opt_host_build = value;
     else if (k == "dia_mask") ctx->opt_dia_mask = value;
+    else if (k == "box_generic") ctx->opt_box_generic = value;
     else if (k == "small_lds") ctx->opt_small_lds = value;
     else if (k == "state_order") ctx->opt_state_order = value;
     else if (k == "state_order_min") ctx->opt_state_order_min = value;

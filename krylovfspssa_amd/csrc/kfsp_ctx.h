@@ -136,6 +136,13 @@ struct kfsp_ctx {
     DevBuf<uint32_t> d_gmask;
     DevBuf<double> d_zero;   // 128 zeros, the stand-in for an empty segment
     bool dia_masked = false;
+    // matrix-free box generator (kfsp_set_matrix_box): descriptor (host copy, passed as a kernel
+    // argument) and the factor tables in device memory
+    kfsp::BoxDev box;
+    DevBuf<double> d_box;
+    bool use_box = false;
+    bool box_fast = false;        // the single-factor form (BoxFast) sits behind the tables
+    size_t box_lds_bytes = 0;
     int64_t dia_empty_segments = 0;   // (diagonal, 128-row group) pairs without entries
     // device-side build from the reference layout (kfsp_build.hip)
     DevBuf<int32_t> d_ell_adj, d_cnt, d_ticket;
@@ -196,6 +203,7 @@ struct kfsp_ctx {
     int64_t opt_small_lds = 1;            // 0: the one-launch Arnoldi kernel reads the generator from global memory
     int64_t lds_per_block = 65536;        // device limit (hipDeviceAttributeMaxSharedMemoryPerBlock)
     int64_t opt_dia_mask = 1;             // 0: never skip empty diagonal segments
+    int64_t opt_box_generic = 0;          // 1: matrix-free boxes always take the run-time interpreted kernel
     int64_t opt_state_order = 1;          // 1: use kfsp_set_state_coords for large, long-lived generators (0: never)
     int64_t opt_state_order_min = 32768;  // smallest generator that is reordered
     int64_t opt_state_order_products = 48;   // ... and only if its predecessor saw this many products

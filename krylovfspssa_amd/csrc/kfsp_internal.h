@@ -51,6 +51,48 @@ struct DiaDev {
     const double *zero;
 };
 
+// Matrix-free generator of a lexicographic box [0,d_1) x ... x [0,d_ns) (species 1 fastest): no
+// stored entries at all.  Propensities are products of one-species factors,
+//   a_k(x) = prod_i T_{k,i}[x_{s(k,i)}]   (mass action, Hill functions of one species, ...),
+// tabulated on the host with the model's own propensity code; the tables (a few KB) live in LDS and
+// the kernel rebuilds every row from the row index: y_r = -(sum_k a_k(x)) x_r + sum_k a_k(x - nu_k) x_{r + delta_k}
+// for the sources x - nu_k inside the box (FMATVEC on the FSP = the box, KrylovSolver.f90:577-607, with
+// DIAG = the sum of ALL propensities, StateSpace.f90:207-212).  HBM traffic: x once, y once.
+constexpr int kBoxMaxS = 8, kBoxMaxR = 16, kBoxMaxDep = 3;
+struct BoxDev {
+    int32_t ns, nr, ntab, pad;
+    int32_t dims[kBoxMaxS];
+    double inv_dim[kBoxMaxS];
+    int32_t delta[kBoxMaxR];                  // x index of reaction k's source state relative to the row (ascending)
+    int32_t dorder[kBoxMaxR];                 // reactions in the model's own order (the order DIAG is summed in)
+    int8_t ndep[kBoxMaxR], nmov[kBoxMaxR];
+    int8_t dep_s[kBoxMaxR][kBoxMaxDep];       // species a_k depends on
+    int8_t dep_nu[kBoxMaxR][kBoxMaxDep];      // stoichiometry of that species (source coordinate = x - nu)
+    int32_t dep_off[kBoxMaxR][kBoxMaxDep];    // offset of its factor table in the table image
+    int8_t mov_s[kBoxMaxR][kBoxMaxDep];       // species the reaction changes
+    int8_t mov_nu[kBoxMaxR][kBoxMaxDep];
+    int32_t mov_dim[kBoxMaxR][kBoxMaxDep];    // dims[mov_s]: keeps every index into this struct a compile-time constant
+};
+
+// The same generator when every propensity has ONE factor and no reaction changes a species by
+// more than 2 (all benchmark boxes): the entries are grouped by the species their factor depends
+// on, kBoxPer... slots per species (padded with entries whose factor is 0), so that in the kernel
+// both the species and the slot of an entry are compile-time constants: straight-line code on
+// coordinate registers, all gathers of a row in flight together.  Whether the source state of an
+// entry lies inside the box is one AND against a per-row flag word (4 bits per species:
+// x >= 1, x >= 2, x <= d-2, x <= d-3).  Lives in device memory behind the tables; uniform, read
+// with scalar loads.
+constexpr int kBoxFastS = 6, kBoxFastPer = 4;
+struct BoxFast {
+    int32_t ns, per, zoff, pad1;              // species (padded with dimension 1), slots per species, offset of a 0.0
+    int32_t dims[kBoxFastS];
+    double inv_dim[kBoxFastS];
+    int32_t off[kBoxFastS][kBoxFastPer];      // offset of the entry's factor table (zoff for padding)
+    int32_t nu[kBoxFastS][kBoxFastPer];       // stoichiometry of its own species (source coordinate = x - nu)
+    int32_t delta[kBoxFastS][kBoxFastPer];    // x index of the source state relative to the row
+    uint32_t need[kBoxFastS][kBoxFastPer];    // flag bits that must be set for the source to be inside the box
+};
+
 // A scalar that is the sum of n doubles at p (block partials of the producing
 // kernel, or one finished / all-reduced value).  Consumers sum it themselves in
 // a fixed order: no atomics, no extra launch, bit-reproducible.
@@ -62,6 +104,9 @@ struct Pending {
 struct SpmvArgs {
     SellDev A;
     DiaDev D;             // used instead of A by the banded kernels
+    BoxDev B;             // matrix-free box generator (format 3): the descriptor, by value (uniform kernel argument)
+    const double *box_tab;   // ... and its factor tables (device memory, staged to LDS by the kernel)
+    const BoxFast *box_fast; // format 4: the single-factor form of the same box (device memory)
     const double *xg;     // gather source, global indexing
     int64_t row0;         // global index of local row 0
     double *y;            // local rows
@@ -148,8 +193,9 @@ struct SmallArnoldiArgs {
 int launch_arnoldi_small(const SmallArnoldiArgs &a, bool dia, int64_t lds_limit, hipStream_t s);
 
 // kernel launchers (kfsp_kernels.hip)
-// fmt: 0 SELL-64, 1 banded, 2 banded with group masks
-void launch_spmv(int mode, int grid, const SpmvArgs &a, bool nontemporal, int fmt, hipStream_t s);
+// fmt: 0 SELL-64, 1 banded, 2 banded with group masks, 3 matrix-free box (lds_bytes = size of the factor tables),
+// 4 matrix-free box, single-factor fast path
+void launch_spmv(int mode, int grid, const SpmvArgs &a, bool nontemporal, int fmt, hipStream_t s, size_t lds_bytes = 0);
 void launch_ortho2(int grid, const Ortho2Args &a, hipStream_t s);
 void launch_ortho(int grid, const OrthoArgs &a, hipStream_t s);
 void launch_combine(int grid, const CombineArgs &a, hipStream_t s);

@@ -219,16 +219,257 @@ __device__ __forceinline__ d2 rows_dia(const DiaDev &D, const double *__restrict
     return sum;
 }
 
-// FMT: 0 SELL-64, 1 banded, 2 banded with group masks
-template <int MODE, bool NT, int FMT>
+// Matrix-free box generator, two consecutive rows per lane like the banded form.  The descriptor B
+// is a kernel argument (uniform: scalar loads), the factor tables sit in LDS, the coordinates of a
+// row in registers (NS compile-time for the benchmark models; species picked by select chains, a
+// register array indexed by run-time data would spill).  NS = 0 / NR = 0: run-time sizes.
+template <int NS>
+__device__ __forceinline__ int box_pick(const int *x, int s)
+{
+    constexpr int N = NS ? NS : kBoxMaxS;
+    int v = x[0];
+#pragma unroll
+    for (int i = 1; i < N; ++i) v = (s == i) ? x[i] : v;
+    return v;
+}
+
+template <int NS, int NR>
+__device__ __forceinline__ double row_box(const BoxDev &B, const double *tab, const int *x, const double *__restrict__ xg,
+                                          int64_t g)
+{
+    constexpr int RMAX = NR ? NR : kBoxMaxR;
+    const int nr = NR ? NR : B.nr;
+    // a_k at x itself, reaction by reaction in sorted position
+    double ax[RMAX];
+#pragma unroll
+    for (int k = 0; k < RMAX; ++k) {
+        ax[k] = 0.0;
+        if (k < nr) {
+            double a = tab[B.dep_off[k][0] + box_pick<NS>(x, B.dep_s[k][0])];
+#pragma unroll
+            for (int i = 1; i < kBoxMaxDep; ++i)
+                if (i < B.ndep[k]) a *= tab[B.dep_off[k][i] + box_pick<NS>(x, B.dep_s[k][i])];
+            ax[k] = a;
+        }
+    }
+    // DIAG = sum of all propensities at x, in the model's reaction order (StateSpace.f90:207-212)
+    double dsum = 0.0;
+#pragma unroll
+    for (int q = 0; q < RMAX; ++q) {
+        if (q < nr) {
+            const int k = B.dorder[q];
+            double a = ax[0];
+#pragma unroll
+            for (int j = 1; j < RMAX; ++j) a = (k == j) ? ax[j] : a;
+            dsum += a;
+        }
+    }
+    double sum = -dsum * xg[g];
+#pragma unroll
+    for (int k = 0; k < RMAX; ++k) {                    // ascending column offset, as the banded kernel
+        if (k < nr) {
+            bool in = true;
+            bool same = true;                           // the source state has the same factors as x itself
+#pragma unroll
+            for (int i = 0; i < kBoxMaxDep; ++i) {
+                if (i < B.nmov[k]) {
+                    const int s = B.mov_s[k][i];
+                    const int v = box_pick<NS>(x, s) - B.mov_nu[k][i];
+                    in = in && v >= 0 && v < B.mov_dim[k][i];
+                }
+                if (i < B.ndep[k]) same = same && B.dep_nu[k][i] == 0;
+            }
+            double a = ax[k];
+            if (!same) {                                // uniform branch: B is the same for every lane
+                a = 0.0;
+                if (in) {
+                    a = tab[B.dep_off[k][0] + box_pick<NS>(x, B.dep_s[k][0]) - B.dep_nu[k][0]];
+#pragma unroll
+                    for (int i = 1; i < kBoxMaxDep; ++i)
+                        if (i < B.ndep[k]) a *= tab[B.dep_off[k][i] + box_pick<NS>(x, B.dep_s[k][i]) - B.dep_nu[k][i]];
+                }
+            }
+            sum += (in ? a : 0.0) * xg[in ? g + B.delta[k] : g];
+        }
+    }
+    return sum;
+}
+
+template <int NS, int NR>
+__device__ __forceinline__ d2 rows_box(const BoxDev &B, const double *tab, const double *__restrict__ xg,
+                                       int64_t row0, int64_t nloc, int64_t c, int lane)
+{
+    constexpr int SMAX = NS ? NS : kBoxMaxS;
+    const int ns = NS ? NS : B.ns;
+    d2 sum = {0.0, 0.0};
+    // rows beyond this rank's block read as zero rows (with more ranks the last 128-row group of a
+    // block may reach into the next rank's rows, which are real states of the box)
+    const int64_t r0 = (c << 7) + 2 * lane;
+    if (r0 >= nloc) return sum;
+    const int64_t g = row0 + r0;
+    // coordinates of row g: successive division by the box dimensions (exact: g < 2^31, one correction step)
+    int x[SMAX];
+    uint32_t q = (uint32_t)g;
+#pragma unroll
+    for (int s = 0; s < SMAX; ++s) {
+        x[s] = 0;
+        if (s + 1 < ns) {
+            const int d = B.dims[s];
+            uint32_t t = (uint32_t)((double)q * B.inv_dim[s]);
+            int r = (int)(q - t * (uint32_t)d);
+            if (r < 0) {
+                --t;
+                r += d;
+            } else if (r >= d) {
+                ++t;
+                r -= d;
+            }
+            x[s] = r;
+            q = t;
+        } else if (s + 1 == ns) {
+            x[s] = (int)q;
+        }
+    }
+    sum.x = row_box<NS, NR>(B, tab, x, xg, g);
+    if (r0 + 1 < nloc) {
+        bool carry = true;                               // next row: +1 with carry
+#pragma unroll
+        for (int s = 0; s < SMAX; ++s) {
+            if (s < ns && carry) {
+                const int v = x[s] + 1;
+                carry = v >= B.dims[s] && s + 1 < ns;
+                x[s] = carry ? 0 : v;
+            }
+        }
+        sum.y = row_box<NS, NR>(B, tab, x, xg, g + 1);
+    }
+    return sum;
+}
+
+// Single-factor fast path (BoxFast): NS species with PER entry slots each, both compile-time, so the
+// species and slot of every entry are constants: straight-line code, no coordinate array, no
+// branches (an entry outside the box reads the 0.0 behind the tables and x of the row itself), all
+// gathers of x, table look-ups and (uniform, scalar) descriptor loads of a row in flight together.
+__device__ __forceinline__ unsigned box_flag4(int v, int d)
+{
+    return (unsigned)(v >= 1) | (unsigned)(v >= 2) << 1 | (unsigned)(v <= d - 2) << 2 | (unsigned)(v <= d - 3) << 3;
+}
+
+template <int S, int PER>
+__device__ __forceinline__ void box_species(const BoxFast *__restrict__ F, const double *tab, int xs, unsigned flags,
+                                            const double *__restrict__ xg, int64_t g, double &dsum, double &acc)
+{
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        // uniform descriptor words first, unconditionally: left inside the selects below the compiler
+        // wraps every one of them in its own exec-masked block (load, wait, branch) and serialises the row
+        // (readfirstlane is convergent: it cannot be sunk into a divergent branch)
+        const int off = __builtin_amdgcn_readfirstlane(F->off[S][j]), nu = __builtin_amdgcn_readfirstlane(F->nu[S][j]);
+        const int delta = __builtin_amdgcn_readfirstlane(F->delta[S][j]), zoff = __builtin_amdgcn_readfirstlane(F->zoff);
+        const unsigned need = (unsigned)__builtin_amdgcn_readfirstlane((int)F->need[S][j]);
+        const bool in = (flags & need) == need;
+        const double a0 = tab[off + xs];                          // a_k at x: part of DIAG (StateSpace.f90:207-212)
+        const double a1 = tab[in ? off + xs - nu : zoff];         // a_k at the source state x - nu_k, or 0
+        const double xv = xg[g + (in ? (int64_t)delta : 0)];
+        dsum += a0;
+        acc += a1 * xv;
+    }
+}
+
+template <int NS, int PER>
+__device__ __forceinline__ double row_box1(const BoxFast *__restrict__ F, const double *tab, int c0, int c1, int c2, int c3,
+                                           int c4, int c5, const double *__restrict__ xg, int64_t g)
+{
+    unsigned flags = box_flag4(c0, F->dims[0]);
+    if (NS > 1) flags |= box_flag4(c1, F->dims[1]) << 4;
+    if (NS > 2) flags |= box_flag4(c2, F->dims[2]) << 8;
+    if (NS > 3) flags |= box_flag4(c3, F->dims[3]) << 12;
+    if (NS > 4) flags |= box_flag4(c4, F->dims[4]) << 16;
+    if (NS > 5) flags |= box_flag4(c5, F->dims[5]) << 20;
+    const double xd = xg[g];
+    double dsum = 0.0, acc = 0.0;
+    box_species<0, PER>(F, tab, c0, flags, xg, g, dsum, acc);
+    if (NS > 1) box_species<1, PER>(F, tab, c1, flags, xg, g, dsum, acc);
+    if (NS > 2) box_species<2, PER>(F, tab, c2, flags, xg, g, dsum, acc);
+    if (NS > 3) box_species<3, PER>(F, tab, c3, flags, xg, g, dsum, acc);
+    if (NS > 4) box_species<4, PER>(F, tab, c4, flags, xg, g, dsum, acc);
+    if (NS > 5) box_species<5, PER>(F, tab, c5, flags, xg, g, dsum, acc);
+    return acc - dsum * xd;
+}
+
+template <int NS, int PER>
+__device__ __forceinline__ d2 rows_box1(const BoxFast *__restrict__ F, const double *tab, const double *__restrict__ xg,
+                                        int64_t row0, int64_t nloc, int64_t c, int lane)
+{
+    d2 sum = {0.0, 0.0};
+    const int64_t r0 = (c << 7) + 2 * lane;
+    if (r0 >= nloc) return sum;
+    const int64_t g = row0 + r0;
+    // coordinates of row g: successive division by the box dimensions (exact: g < 2^31, one correction step)
+    int c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
+    uint32_t q = (uint32_t)g;
+#define KFSP_BOX_DEC(S, VAR)                                             \
+    if (NS > S + 1) {                                                    \
+        const int d = F->dims[S];                                        \
+        uint32_t t = (uint32_t)((double)q * F->inv_dim[S]);              \
+        int r = (int)(q - t * (uint32_t)d);                              \
+        const int lo = r < 0, hi = r >= d;                               \
+        t = t - lo + hi;                                                 \
+        r = r + (lo ? d : 0) - (hi ? d : 0);                             \
+        VAR = r;                                                         \
+        q = t;                                                           \
+    } else if (NS == S + 1) {                                            \
+        VAR = (int)q;                                                    \
+    }
+    KFSP_BOX_DEC(0, c0)
+    KFSP_BOX_DEC(1, c1)
+    KFSP_BOX_DEC(2, c2)
+    KFSP_BOX_DEC(3, c3)
+    KFSP_BOX_DEC(4, c4)
+    KFSP_BOX_DEC(5, c5)
+#undef KFSP_BOX_DEC
+    sum.x = row_box1<NS, PER>(F, tab, c0, c1, c2, c3, c4, c5, xg, g);
+    if (r0 + 1 < nloc) {
+        // next row: +1 with carry (the last species never wraps: g + 1 < n)
+        int carry = 1;
+#define KFSP_BOX_INC(S, VAR)                                             \
+    if (NS > S) {                                                        \
+        const int v = VAR + carry;                                       \
+        const int wrap = (NS > S + 1) && v >= F->dims[S];                \
+        VAR = wrap ? 0 : v;                                              \
+        carry = wrap;                                                    \
+    }
+        KFSP_BOX_INC(0, c0)
+        KFSP_BOX_INC(1, c1)
+        KFSP_BOX_INC(2, c2)
+        KFSP_BOX_INC(3, c3)
+        KFSP_BOX_INC(4, c4)
+        KFSP_BOX_INC(5, c5)
+#undef KFSP_BOX_INC
+        sum.y = row_box1<NS, PER>(F, tab, c0, c1, c2, c3, c4, c5, xg, g + 1);
+    }
+    return sum;
+}
+
+// FMT: 0 SELL-64, 1 banded, 2 banded with group masks, 3 matrix-free box (descriptor interpreted at run time),
+// 4 matrix-free box, single-factor fast path with NS species and NE entry slots per species
+template <int MODE, bool NT, int FMT, int NS = 0, int NE = 0>
 __global__ __launch_bounds__(kBlock) void k_spmv(SpmvArgs a)
 {
     constexpr bool DIA = FMT != 0;
+    constexpr bool BOX = FMT == 3 || FMT == 4;
     __shared__ double red[12];
+    extern __shared__ double box_lds[];                   // FMT 3: the factor tables
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (MODE != 0) {
         if (*a.brk_flag) return;
+    }
+    const double *tab = nullptr;
+    if (BOX) {
+        for (int i = threadIdx.x; i < a.B.ntab; i += kBlock) box_lds[i] = a.box_tab[i];
+        __syncthreads();
+        tab = box_lds;
     }
 
     // SELL: one 64-row chunk per wavefront trip; DIA: one 128-row group
@@ -248,7 +489,9 @@ __global__ __launch_bounds__(kBlock) void k_spmv(SpmvArgs a)
     unsigned gm = 0xFFFFFFFFu;                              // group mask of the trip about to be computed
     if (FMT == 2 && c < cend) gm = __builtin_amdgcn_readfirstlane(a.D.gmask[ct]);
     if (c < cend) {
-        if (DIA) sum = rows_dia<NT, FMT == 2>(a.D, a.xg, a.row0, ct, lane, gm);
+        if (FMT == 4) sum = rows_box1<(NS ? NS : 1), (NE ? NE : 1)>(a.box_fast, tab, a.xg, a.row0, a.A.nrows, ct, lane);
+        else if (BOX) sum = rows_box<0, 0>(a.B, tab, a.xg, a.row0, a.A.nrows, ct, lane);
+        else if (DIA) sum = rows_dia<NT, FMT == 2>(a.D, a.xg, a.row0, ct, lane, gm);
         else sum.x = row_sell<NT>(a.A, a.xg, a.row0, ct, lane);
     }
 
@@ -305,7 +548,9 @@ __global__ __launch_bounds__(kBlock) void k_spmv(SpmvArgs a)
         c = cn;
         ct = ctn;
         if (c < cend) {
-            if (DIA) sum = rows_dia<NT, FMT == 2>(a.D, a.xg, a.row0, ct, lane, gm);
+            if (FMT == 4) sum = rows_box1<(NS ? NS : 1), (NE ? NE : 1)>(a.box_fast, tab, a.xg, a.row0, a.A.nrows, ct, lane);
+        else if (BOX) sum = rows_box<0, 0>(a.B, tab, a.xg, a.row0, a.A.nrows, ct, lane);
+            else if (DIA) sum = rows_dia<NT, FMT == 2>(a.D, a.xg, a.row0, ct, lane, gm);
             else sum.x = row_sell<NT>(a.A, a.xg, a.row0, ct, lane);
         }
     }
@@ -323,17 +568,40 @@ __global__ __launch_bounds__(kBlock) void k_spmv(SpmvArgs a)
 }
 
 template <bool NT, int FMT>
-static void launch_spmv_mode(int mode, dim3 g, dim3 b, const SpmvArgs &a, hipStream_t st)
+static void launch_spmv_mode(int mode, dim3 g, dim3 b, const SpmvArgs &a, hipStream_t st, size_t lds = 0)
 {
-    if (mode == 0) hipLaunchKernelGGL((k_spmv<0, NT, FMT>), g, b, 0, st, a);
-    else if (mode == 1) hipLaunchKernelGGL((k_spmv<1, NT, FMT>), g, b, 0, st, a);
-    else if (mode == 2) hipLaunchKernelGGL((k_spmv<2, NT, FMT>), g, b, 0, st, a);
-    else hipLaunchKernelGGL((k_spmv<3, NT, FMT>), g, b, 0, st, a);
+    if (mode == 0) hipLaunchKernelGGL((k_spmv<0, NT, FMT>), g, b, lds, st, a);
+    else if (mode == 1) hipLaunchKernelGGL((k_spmv<1, NT, FMT>), g, b, lds, st, a);
+    else if (mode == 2) hipLaunchKernelGGL((k_spmv<2, NT, FMT>), g, b, lds, st, a);
+    else hipLaunchKernelGGL((k_spmv<3, NT, FMT>), g, b, lds, st, a);
 }
 
-void launch_spmv(int mode, int grid, const SpmvArgs &a, bool nt, int fmt, hipStream_t st)
+template <int FMT, int NS, int NE>
+static void launch_box_mode(int mode, dim3 g, dim3 b, const SpmvArgs &a, hipStream_t st, size_t lds)
+{
+    if (mode == 0) hipLaunchKernelGGL((k_spmv<0, false, FMT, NS, NE>), g, b, lds, st, a);
+    else if (mode == 1) hipLaunchKernelGGL((k_spmv<1, false, FMT, NS, NE>), g, b, lds, st, a);
+    else if (mode == 2) hipLaunchKernelGGL((k_spmv<2, false, FMT, NS, NE>), g, b, lds, st, a);
+    else hipLaunchKernelGGL((k_spmv<3, false, FMT, NS, NE>), g, b, lds, st, a);
+}
+
+void launch_spmv(int mode, int grid, const SpmvArgs &a, bool nt, int fmt, hipStream_t st, size_t lds_bytes)
 {
     dim3 g(grid), b(kBlock);
+    if (fmt == 3) {
+        launch_box_mode<3, 0, 0>(mode, g, b, a, st, lds_bytes);
+        return;
+    }
+    if (fmt == 4) {
+        // a.B.pad = species count of the instantiation * 16 + slots per species (kfsp_set_matrix_box)
+        switch (a.B.pad) {
+        case 2 * 16 + 2: launch_box_mode<4, 2, 2>(mode, g, b, a, st, lds_bytes); break;
+        case 3 * 16 + 2: launch_box_mode<4, 3, 2>(mode, g, b, a, st, lds_bytes); break;
+        case 6 * 16 + 2: launch_box_mode<4, 6, 2>(mode, g, b, a, st, lds_bytes); break;
+        default: launch_box_mode<4, 6, 4>(mode, g, b, a, st, lds_bytes); break;
+        }
+        return;
+    }
     if (nt) {
         if (fmt == 2) launch_spmv_mode<true, 2>(mode, g, b, a, st);
         else if (fmt == 1) launch_spmv_mode<true, 1>(mode, g, b, a, st);

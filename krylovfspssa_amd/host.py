@@ -52,6 +52,7 @@ def load_library():
         "kfsp_set_matrix_ell": [vp, i32, i32, i32, vp, vp, vp],
         "kfsp_set_matrix_csr": [vp, i64, i64, i64, vp, vp, vp],
         "kfsp_set_state_coords": [vp, i32, i32, i32, vp],
+        "kfsp_set_matrix_box": [vp, i32, vp, i32, vp, vp, vp, vp],
         "kfsp_state_order_active": [vp, C.POINTER(C.c_int)],
         "kfsp_matrix_info": [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)],
         "kfsp_matrix_bytes": [vp, C.c_int, C.POINTER(i64)],
@@ -278,6 +279,19 @@ class KfspContext:
                   "kfsp_set_matrix_csr")
         self.n = int(n)
         self.row0, self.nloc = r0, nr
+
+    def set_matrix_box(self, model):
+        """Matrix-free generator of a synth.BoxModel with separable propensities (model.factors())."""
+        dims = np.ascontiguousarray(model.dims, dtype=np.int32)
+        stoich = np.ascontiguousarray(np.asarray(model.stoich).T, dtype=np.int32)      # [nr][ns]
+        ndep, deps, tables = model.factors()
+        ndep = np.ascontiguousarray(ndep, dtype=np.int32)
+        deps = np.ascontiguousarray(deps, dtype=np.int32)
+        tables = np.ascontiguousarray(tables, dtype=np.float64)
+        self._chk(self._lib.kfsp_set_matrix_box(self._h, len(dims), _p(dims), stoich.shape[0], _p(stoich), _p(ndep),
+                                                _p(deps), _p(tables)), "kfsp_set_matrix_box")
+        self.n = int(model.n)
+        self.row0, self.nloc = self.row_block(self.n)
 
     def matrix_info(self):
         a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)

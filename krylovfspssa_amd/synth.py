@@ -26,8 +26,11 @@ class BoxModel:
     """stoich: (d, R) integer array; prop(r, X) -> propensity of reaction r at the
     coordinate arrays X[0..d-1] (float64 arrays of equal shape)."""
 
-    def __init__(self, name, dims, stoich, prop):
+    def __init__(self, name, dims, stoich, prop, deps=None):
         self.name = name
+        # deps[r]: the species propensity r depends on (it must be a product of one-species factors);
+        # None = unknown, no matrix-free form
+        self.deps = deps
         self.dims = tuple(int(x) for x in dims)
         self.stoich = np.asarray(stoich, dtype=np.int64)
         self.prop = prop
@@ -96,6 +99,43 @@ class BoxModel:
         rowptr = np.concatenate(([0], np.cumsum(valid.sum(axis=1)))).astype(np.int64)
         return rowptr, cols[valid].astype(np.int32), vals[valid]
 
+    # ---- matrix-free form ---------------------------------------------------
+    def factors(self):
+        """(ndep[R], dep_species[R][3], tables) for kfsp_set_matrix_box: propensity r as a product of
+        one-species factor tables, made with self.prop itself.  A propensity of one species IS its
+        table (same bits as the stored entries); for several species the first factor carries the
+        constant, the others are normalised by the value at population 1.  Separability is verified."""
+        assert self.deps is not None, f"{self.name}: no dependency list, no matrix-free form"
+        ndep = np.zeros(self.R, dtype=np.int32)
+        dep = np.zeros((self.R, 3), dtype=np.int32)
+        tabs = []
+        rng = np.random.default_rng(0)
+        for r in range(self.R):
+            sp = tuple(self.deps[r]) or (0,)
+            assert 1 <= len(sp) <= 3
+            ndep[r] = len(sp)
+            dep[r, :len(sp)] = sp
+            ref = [np.ones(1) for _ in range(self.d)]                 # all other populations at 1
+            base = float((self.prop(r, ref) * np.ones(1))[0])
+            mine = []
+            for i, s in enumerate(sp):
+                X = [np.ones(self.dims[s]) for _ in range(self.d)]
+                X[s] = np.arange(self.dims[s], dtype=np.float64)
+                t = np.asarray(self.prop(r, X), dtype=np.float64) * np.ones(self.dims[s])
+                if i > 0:
+                    t = t / base
+                mine.append(t)
+            # check on random states of the box
+            idx = rng.integers(0, self.n, 2000)
+            C = self.coords(idx)
+            want = self.prop(r, [x.astype(np.float64) for x in C]) * np.ones(len(idx))
+            got = np.ones(len(idx))
+            for i, s in enumerate(sp):
+                got = got * mine[i][C[s]]
+            assert np.all(np.abs(got - want) <= 4e-16 * np.abs(want) * len(sp)), f"{self.name}: propensity {r} is not separable"
+            tabs += mine
+        return ndep, dep, np.concatenate(tabs)
+
     def nnz(self):
         """true nonzeros incl. the diagonal"""
         nnz = self.n
@@ -137,7 +177,7 @@ def toggle(n1=1000, n2=1000, params=(1.0, 100.0, 1.0, 1.0, 100.0, 1.0)):
         if r == 2:
             return by + ky / (1.0 + 0.5 * x ** 1.5)
         return dy * y
-    return BoxModel("toggle", (n1, n2), st, prop)
+    return BoxModel("toggle", (n1, n2), st, prop, deps=[(1,), (0,), (0,), (1,)])
 
 
 def repressilator(n=171, params=(100.0, 100.0, 100.0, 1.0, 1.0, 1.0), dims=None):
@@ -153,7 +193,8 @@ def repressilator(n=171, params=(100.0, 100.0, 100.0, 1.0, 1.0, 1.0), dims=None)
         if r == 2:
             return a3 / (1.0 + s2 ** 1.5)
         return (b1 * s1, b2 * s2, b3 * s3)[r - 3]
-    return BoxModel("repressilator", dims if dims is not None else (n, n, n), st, prop)
+    return BoxModel("repressilator", dims if dims is not None else (n, n, n), st, prop,
+                    deps=[(2,), (0,), (1,), (0,), (1,), (2,)])
 
 
 def birth_death(dims, k=None, g=None):
@@ -170,7 +211,7 @@ def birth_death(dims, k=None, g=None):
     def prop(r, X):
         i = r // 2
         return np.full_like(X[i], k[i]) if r % 2 == 0 else g[i] * X[i]
-    return BoxModel("birth_death", dims, st, prop)
+    return BoxModel("birth_death", dims, st, prop, deps=[(r // 2,) for r in range(2 * d)])
 
 
 GOUTSIAS_PARAMS = (0.043, 0.0007, 0.0715, 0.0039, 0.0199264663575241, 0.4791,
@@ -198,7 +239,9 @@ def goutsias_box(dims, params=GOUTSIAS_PARAMS):
         m, d_, rna, dna, dnad, dna2d = X
         return (c[0] * rna, c[1] * m, c[2] * dnad, c[3] * rna, c[4] * dna * d_, c[5] * dnad,
                 c[6] * dnad * d_, c[7] * dna2d, c[8] * m * (m - 1) / 2.0, c[9] * d_)[r]
-    return BoxModel("goutsias", dims, st, prop)
+    M_, D_, RNA_, DNA_, DNAD_, DNA2D_ = range(6)
+    return BoxModel("goutsias", dims, st, prop,
+                    deps=[(RNA_,), (M_,), (DNAD_,), (RNA_,), (DNA_, D_), (DNAD_,), (DNAD_, D_), (DNA2D_,), (M_,), (D_,)])
 
 
 class GoutsiasConserved:

@@ -1,0 +1,109 @@
+"""Matrix-free generator of a lexicographic box (kfsp_set_matrix_box): the
+kernel stores no generator entries and rebuilds FMATVEC's rows (KrylovSolver.f90:577-607) from the row
+index and one-species factor tables of the propensities (ModelModule.f90:163-199 evaluated on the host
+at every population count)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import oracle as O
+    return O
+
+
+def _models():
+    from krylovfspssa_amd import synth
+    return {
+        "toggle": synth.toggle(97, 61),                          # 2 species, Hill factors
+        "repressilator": synth.repressilator(dims=(31, 23, 19)),  # 3 species
+        "birth_death6": synth.birth_death((5, 6, 4, 5, 3, 4)),    # 6 species, 12 reactions (config 5's model)
+        "goutsias": synth.goutsias_box((9, 8, 7, 3, 3, 3)),       # two-factor propensities, a reaction that moves 3 species
+        "line": synth.birth_death((1000,)),                       # one species
+    }
+
+
+@pytest.mark.parametrize("generic", [0, 1])
+@pytest.mark.parametrize("name", list(_models()))
+def test_matrix_free_product_equals_the_stored_generator(oracle, name, generic):
+    """generic = 1 forces the run-time interpreted kernel also where the single-factor fast path
+    applies (all models here except goutsias, whose propensities have two factors)."""
+    from krylovfspssa_amd import KfspContext
+    mdl = _models()[name]
+    adj, off, diag = mdl.ell()
+    A = oracle.EllMatrix(adj, off, diag)
+    rng = np.random.default_rng(2)
+    x = rng.random(mdl.n)
+    yref = oracle.spmv_ell(A, x)
+    scale = oracle.spmv_ell(oracle.EllMatrix(adj, np.abs(off), -np.abs(diag)), np.abs(x))
+    with KfspContext(0) as c, KfspContext(0) as b:
+        c.set_option("box_generic", generic)
+        c.set_matrix_box(mdl)
+        b.set_matrix_csr(mdl.n, *mdl.csr_rows())                  # the stored (banded) form of the same rows
+        info = c.matrix_info()
+        assert info["slots"] == 0 and info["nnz"] == mdl.nnz()
+        if mdl.n > 10000:
+            assert c.matrix_bytes() < 0.6 * b.matrix_bytes()
+        y = c.spmv(x)
+        assert np.all(np.abs(y - yref) <= 1e-13 * np.abs(scale) + 1e-300)
+        yb = b.spmv(x)
+        if generic and max(len(d) for d in mdl.deps) == 1:
+            # one factor per propensity: the table entries ARE the stored entries, and the interpreted
+            # kernel sums a row in the banded kernel's order -> same bits (the fast path groups the
+            # entries by species: same values, other order)
+            assert np.array_equal(y, yb)
+        assert np.all(np.abs(y - yb) <= 1e-13 * np.abs(scale) + 1e-300)
+        # the whole path on it: Arnoldi pass and fixed-(m, tau) steps against the oracle
+        p0 = rng.random(mdl.n)
+        p0 /= p0.sum()
+        m, tau, nsteps = 16, 0.003, 2
+        for ctx in (c, b):
+            ctx.set_option("small_kernel", 0)
+            ctx.set_vector(p0)
+        wref, wsref = oracle.expv_fixed(A, p0, m, tau, nsteps)
+        ws = c.expv_fixed(m, tau, nsteps)
+        assert np.abs(c.get_vector() - wref).sum() < 1e-10 and np.abs(ws - wsref).max() < 1e-12
+        V, Href, mb, k1, av = oracle.arnoldi(A, p0 / np.sqrt((p0 * p0).sum()), m)
+        c.set_vector(p0)
+        c.begin_step()
+        H, mb2, k12, av2 = c.arnoldi(m)
+        assert (mb2, k12) == (mb, k1)
+        assert np.abs(H[:9, :8] - Href[:9, :8]).max() <= 1e-11 * np.abs(Href).max()
+
+
+@pytest.mark.parametrize("P", [2, 3])
+def test_matrix_free_rows_are_partitioned_like_banded_ones(oracle, P):
+    from krylovfspssa_amd import host, synth
+    mdl = synth.repressilator(dims=(31, 23, 19))
+    adj, off, diag = mdl.ell()
+    A = oracle.EllMatrix(adj, off, diag)
+    x = np.random.default_rng(4).random(mdl.n)
+
+    def body(ctx, rank):
+        ctx.set_matrix_box(mdl)
+        r0, nr = ctx.row_block(mdl.n)
+        ctx.set_vector(x[r0:r0 + nr])
+        y = ctx.spmv_w()
+        ctx.begin_step()
+        H, mb, k1, av = ctx.arnoldi(10)
+        return y, H.copy()
+
+    res = host.run_loopback_ranks(P, body)
+    y = np.concatenate([r[0] for r in res])
+    scale = oracle.spmv_ell(oracle.EllMatrix(adj, np.abs(off), -np.abs(diag)), np.abs(x))
+    assert np.all(np.abs(y - oracle.spmv_ell(A, x)) <= 1e-13 * np.abs(scale) + 1e-300)
+    V, Href, mb, k1, av = oracle.arnoldi(A, x / np.sqrt((x * x).sum()), 10)
+    assert np.abs(res[0][1][:11, :10] - Href[:11, :10]).max() <= 1e-11 * np.abs(Href).max()
+
+
+def test_bad_boxes_are_rejected():
+    from krylovfspssa_amd import KfspContext, KfspError, synth
+    with KfspContext(0) as c:
+        mdl = synth.birth_death((3,) * 9)                        # nine species
+        with pytest.raises(KfspError):
+            c.set_matrix_box(mdl)
+        big = synth.toggle(4000, 3000)                           # 7000 table entries
+        with pytest.raises(KfspError):
+            c.set_matrix_box(big)
