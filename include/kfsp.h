@@ -185,6 +185,24 @@ int kfsp_drop_flags(kfsp_ctx *ctx, int64_t n, uint8_t *dropped);
  * call kfsp_set_vector in between, it would replace it). */
 int kfsp_drop_compact(kfsp_ctx *ctx, int64_t *n_new);
 
+/* ---- ONESTEP_EXTENDER on the device (StateSpace.f90:347-396 with ADD_STATE :136-246) ---- */
+/* The integer work of one reachability sweep over the listed states state[0..n) (ns counts each,
+ * leading dimension ld_state) with link array adj (nr links each, leading dimension ld_adj; the
+ * reference's encoding: 1-based index, 0 = target not listed, -1 = negative target): every open
+ * link is followed; the DISTINCT unlisted targets become new states n+1.. in the order in which
+ * the reference's double loop (state by state, reaction by reaction) meets them first; all links
+ * of old and new states are completed.  Out: *n_new = new number of states; state_new = the
+ * appended states (leading dimension ld_state, room for capacity - n of them); adj_out = the
+ * complete link array of all *n_new states (leading dimension ld_adj, room for capacity states).
+ * stoich is [nr][ns]; max_count = MAXNUMBERMOLECULES (StateSpace.f90:11): targets above it are not
+ * states.  Propensities (OFFDIAG, DIAG) of the new states and the caller's own look-up structures
+ * stay with the caller.  Everything is host memory; deterministic (sorts, no hash table).
+ * returns -9 when the packed state keys need more than 63 bits (the caller keeps its own sweep),
+ * -11 when capacity is too small (the reference STOPs with 'FSP SIZE EXCEEDS MEMORY LIMIT'). */
+int kfsp_onestep(kfsp_ctx *ctx, int32_t ns, int32_t nr, const int32_t *stoich, int32_t n, const int32_t *state,
+                 int32_t ld_state, const int32_t *adj, int32_t ld_adj, int32_t max_count, int32_t capacity, int32_t *n_new,
+                 int32_t *state_new, int32_t *adj_out);
+
 /* single reductions over the resident w (tests; FIND_DROPTOL-style sums) */
 int kfsp_nrm2_w(kfsp_ctx *ctx, double *out);
 int kfsp_asum_w(kfsp_ctx *ctx, double *out);

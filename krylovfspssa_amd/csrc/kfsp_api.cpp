@@ -643,7 +643,7 @@ int kfsp_destroy(kfsp_ctx *ctx)
     ctx->d_y.release(); ctx->d_flag.release(); ctx->d_g.release(); ctx->d_dia.release();
     ctx->d_ell_adj.release(); ctx->d_ell_off.release(); ctx->d_ell_diag.release(); ctx->d_cnt.release();
     ctx->d_ticket.release(); ctx->d_slot.release(); ctx->d_scan.release(); ctx->d_strip.release();
-    ctx->d_dropflag.release(); ctx->d_dropcnt.release(); ctx->d_box.release();
+    ctx->d_dropflag.release(); ctx->d_dropcnt.release(); ctx->d_box.release(); ctx->d_os1.release(); ctx->d_os2.release();
     ctx->d_perm.release(); ctx->d_iperm.release(); ctx->d_coords.release(); ctx->d_ell_adj2.release();
     ctx->d_ell_off2.release(); ctx->d_ell_diag2.release(); ctx->d_pstage.release(); ctx->d_keys.release();
     ctx->d_sortidx.release(); ctx->d_sorttmp.release(); ctx->d_gmask.release(); ctx->d_zero.release();
@@ -1462,6 +1462,30 @@ int kfsp_spmv_w(kfsp_ctx *ctx, double *y)
     if (int rc = download_states(ctx, ctx->d_tmp.p, y, ctx->nloc)) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return 0;
+}
+
+int kfsp_onestep(kfsp_ctx *ctx, int32_t ns, int32_t nr, const int32_t *stoich, int32_t n, const int32_t *state, int32_t ld_state,
+                 const int32_t *adj, int32_t ld_adj, int32_t max_count, int32_t capacity, int32_t *n_new, int32_t *state_new,
+                 int32_t *adj_out)
+{
+    return no_throw(ctx, [&]() -> int {
+        if (!ctx) return -1;
+        if (ns < 1 || ns > 16) return fail(ctx, -2, "1 <= ns <= 16");
+        if (nr < 1 || nr > 64) return fail(ctx, -3, "1 <= nr <= 64");
+        if (!stoich) return fail(ctx, -4, "null stoich");
+        if (n < 1) return fail(ctx, -5, "n < 1");
+        if (!state || ld_state < ns) return fail(ctx, -6, "bad state / ld_state");
+        if (!adj || ld_adj < nr) return fail(ctx, -8, "bad adj / ld_adj");
+        if (max_count < 1) return fail(ctx, -10, "max_count < 1");
+        if (capacity < n) return fail(ctx, -11, "capacity < n");
+        if (!n_new || !state_new || !adj_out) return fail(ctx, -12, "null output");
+        HIP_TRY(hipSetDevice(ctx->device));
+        const auto t0 = std::chrono::steady_clock::now();
+        const int rc = kfsp::onestep_device(ctx, ns, nr, stoich, n, state, ld_state, adj, ld_adj, max_count, capacity, n_new,
+                                            state_new, adj_out);
+        ctx->t_ms[KFSP_T_CALLBACKS] += 0.0 * std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return rc;
+    });
 }
 
 int kfsp_drop_plan(kfsp_ctx *ctx, double dsum, double *droptol, int64_t *drop_count, int64_t *n_flagged)

@@ -171,6 +171,9 @@ struct kfsp_ctx {
     bool w_pending = false;
     int64_t w_pending_n = 0;
 
+    // ONESTEP_EXTENDER on the device (kfsp_onestep.hip): two scratch arenas
+    DevBuf<char> d_os1, d_os2;
+
     // vectors
     DevBuf<double> d_V;    // (kMMax+2) columns, stride ldv, unnormalised basis
     DevBuf<double> d_w;    // probability vector, ldv
@@ -227,4 +230,8 @@ void launch_drop_sums(int grid, int64_t npairs, const double *w, const DropLevel
 void launch_drop_flags(int64_t n, const double *w, const double *aw, double droptol, const int32_t *perm, uint8_t *flag,
                        unsigned long long *cnt, hipStream_t st);
 int drop_compact_vector(kfsp_ctx *ctx, int64_t n, const double *src, double *dst, int *n_keep_dev);
+// ONESTEP_EXTENDER's integer work (kfsp_onestep.hip); all arrays are host memory
+int onestep_device(kfsp_ctx *ctx, int32_t ns, int32_t nr, const int32_t *stoich, int32_t n, const int32_t *state, int32_t lds,
+                   const int32_t *adj, int32_t lda, int32_t max_count, int32_t cap, int32_t *n_out, int32_t *state_new,
+                   int32_t *adj_out);
 }  // namespace kfsp

@@ -57,6 +57,7 @@ def load_library():
         "kfsp_matrix_info": [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)],
         "kfsp_matrix_bytes": [vp, C.c_int, C.POINTER(i64)],
         "kfsp_num_states": [vp, C.POINTER(i64)],
+        "kfsp_onestep": [vp, i32, i32, vp, i32, vp, i32, vp, i32, i32, i32, C.POINTER(i32), vp, vp],
         "kfsp_drop_plan": [vp, dbl, C.POINTER(dbl), C.POINTER(i64), C.POINTER(i64)],
         "kfsp_drop_flags": [vp, i64, vp],
         "kfsp_drop_compact": [vp, C.POINTER(i64)],
@@ -299,6 +300,24 @@ class KfspContext:
         return dict(rows=a.value, slots=b.value, nnz=c.value)
 
     # -- vectors
+    def onestep(self, stoich, state, adj, max_count=10000, capacity=None):
+        """ONESTEP_EXTENDER's integer work on the device: (state [n][ns], adj [n][nr]) -> (state', adj')
+        of the extended FSP (new states appended in the reference's order, all links completed)."""
+        state = np.ascontiguousarray(state, dtype=np.int32)
+        adj = np.ascontiguousarray(adj, dtype=np.int32)
+        stoich = np.ascontiguousarray(stoich, dtype=np.int32)          # [nr][ns]
+        n, ns = state.shape
+        nr = adj.shape[1]
+        assert stoich.shape == (nr, ns)
+        cap = int(capacity) if capacity else n * (nr + 1) + 16
+        n_new = C.c_int32(0)
+        st_new = np.zeros((cap - n + 1, ns), dtype=np.int32)
+        adj_out = np.zeros((cap, nr), dtype=np.int32)
+        self._chk(self._lib.kfsp_onestep(self._h, ns, nr, _p(stoich), n, _p(state), ns, _p(adj), nr, int(max_count), cap,
+                                         C.byref(n_new), _p(st_new), _p(adj_out)), "kfsp_onestep")
+        m = n_new.value
+        return np.concatenate([state, st_new[:m - n]]), adj_out[:m].copy()
+
     def drop_plan(self, dsum):
         """DROP_STATES decision on the device -> (droptol, drop_count, n_flagged)."""
         tol, cnt, nf = C.c_double(0.0), C.c_int64(0), C.c_int64(0)

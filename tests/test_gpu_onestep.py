@@ -1,0 +1,56 @@
+"""ONESTEP_EXTENDER on the device (kfsp_onestep) against the reference's
+own assemblies: starting from the FSP of k one-step sweeps (fixture assembly_*_k<k>), further
+sweeps on the device must give the state list and the link array of the reference's k' > k sweeps,
+bit for bit (StateSpace.f90:136-246, 347-396)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CASES = [("toggle", 5, 10), ("toggle", 10, 20), ("repressilator", 5, 10), ("goutsias", 5, 10), ("goutsias", 10, 16)]
+
+
+def _stoich(a):
+    """reaction vectors from a reference assembly: successor - state of any linked pair"""
+    nr = a["adj"].shape[1]
+    nu = [None] * nr
+    for i, row in enumerate(a["adj"]):
+        for r, j in enumerate(row):
+            if j > 0 and nu[r] is None:
+                nu[r] = a["state"][j - 1] - a["state"][i]
+    assert all(v is not None for v in nu)
+    return np.array(nu, dtype=np.int32)
+
+
+@pytest.mark.parametrize("name,k0,k1", CASES)
+def test_device_sweeps_reproduce_the_reference_assembly(golden_dir, name, k0, k1):
+    from krylovfspssa_amd import KfspContext
+    a = np.load(os.path.join(golden_dir, f"assembly_{name}_k{k0}.npz"))
+    b = np.load(os.path.join(golden_dir, f"assembly_{name}_k{k1}.npz"))
+    nu = _stoich(b)
+    state, adj = a["state"], a["adj"]
+    with KfspContext(0) as c:
+        for _ in range(k1 - k0):
+            state, adj = c.onestep(nu, state, adj)
+    assert state.shape == b["state"].shape
+    assert np.array_equal(state, b["state"])
+    assert np.array_equal(adj, b["adj"])
+
+
+def test_population_cap_and_capacity(golden_dir):
+    """targets above MAXNUMBERMOLECULES are not states (their links stay 0); a capacity that is too
+    small is reported like the reference's STOP"""
+    from krylovfspssa_amd import KfspContext, KfspError
+    a = np.load(os.path.join(golden_dir, "assembly_toggle_k5.npz"))
+    nu = _stoich(np.load(os.path.join(golden_dir, "assembly_toggle_k10.npz")))
+    cap = int(a["state"].max())
+    with KfspContext(0) as c:
+        state, adj = c.onestep(nu, a["state"], a["adj"], max_count=cap)
+        assert state.max() == cap                       # nothing beyond the cap was added
+        assert len(state) > len(a["state"])
+        top = np.where((state == cap).any(axis=1))[0]
+        assert (adj[top] == 0).any()
+        with pytest.raises(KfspError):
+            c.onestep(nu, a["state"], a["adj"], capacity=len(a["state"]) + 1)
