@@ -57,7 +57,7 @@ MODULE KRYLOVSOLVER
   ! (4) uploads of the changed FSP
   DOUBLE PRECISION, SAVE, PRIVATE :: HOST_SEC(4) = 0.0D0
 
-  PRIVATE :: ENSURE_CONTEXT, UPLOAD_FSP, CHECK, CB_DROP, CB_EXPAND, CB_LOG, WALL
+  PRIVATE :: ENSURE_CONTEXT, UPLOAD_FSP, CHECK, CB_DROP, CB_EXPAND, CB_LOG, WALL, DEVICE_ONESTEP
 
 CONTAINS
 
@@ -194,6 +194,8 @@ CONTAINS
        PRINT *, 'KFSP: NO USABLE HIP DEVICE (kfsp_create returned', RC, '); THE SOLVER HAS NO CPU PATH.'
        STOP 2
     ENDIF
+    ! from now on ONESTEP_EXTENDER has a device for the integer work of its sweeps
+    ONESTEP_DEVICE => DEVICE_ONESTEP
     ! KFSP_STATE_ORDER=1 lets the device keep large, long-lived FSPs in its own state
     ! order (off by default: it changes the order of the sums); KFSP_STATE_ORDER_MIN:
     ! smallest FSP that is reordered (library default 32768), KFSP_STATE_ORDER_PRODUCTS:
@@ -246,6 +248,21 @@ CONTAINS
     PRINT *, 'KFSP: ', WHAT, ' FAILED WITH CODE ', RC, ': ', KFSP_ERROR_TEXT(CTX)
     STOP 3
   END SUBROUTINE CHECK
+
+  ! STATESPACE's hook: kfsp_onestep on this module's context; the appended states and the
+  ! completed links are written behind / into the caller's own arrays
+  INTEGER FUNCTION DEVICE_ONESTEP(NS, NR, STOICH, N, STATE, ADJ, MAXCOUNT, CAP, NNEW)
+    INTEGER, INTENT(IN) :: NS, NR, N, MAXCOUNT, CAP
+    INTEGER, INTENT(IN) :: STOICH(NS, NR)
+    INTEGER, INTENT(INOUT) :: STATE(NS, *), ADJ(NR, *)
+    INTEGER, INTENT(OUT) :: NNEW
+    INTEGER(C_INT32_T) :: NN
+    NN = N
+    DEVICE_ONESTEP = KFSP_ONESTEP(CTX, INT(NS, C_INT32_T), INT(NR, C_INT32_T), STOICH, INT(N, C_INT32_T), STATE, &
+         INT(NS, C_INT32_T), ADJ, INT(NR, C_INT32_T), INT(MAXCOUNT, C_INT32_T), INT(CAP, C_INT32_T), NN, &
+         STATE(1:NS, N + 1:CAP), ADJ)
+    NNEW = NN
+  END FUNCTION DEVICE_ONESTEP
 
   ! generator columns + probability vector of the current FSP -> device
   SUBROUTINE UPLOAD_FSP(FSP, MODEL, WITH_VECTOR)

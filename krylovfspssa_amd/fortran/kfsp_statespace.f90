@@ -65,7 +65,7 @@ MODULE STATESPACE
      PROCEDURE :: INDEX => INDEX_STATE
   END TYPE FINITE_STATE_PROJECTION
 
-  PRIVATE :: SSA_STREAMS_REQUESTED, SSA_EXTENDER_STREAMS, STREAM_PATH, TICK, STATE_HASH, LOOKUP, PROBE, INSERT_RANGE, APPEND_CANDIDATES, CUSTOMPROP_IS_PURE, TABLE_INSERT, REBUILD_TABLE, LEGAL, RESERVE_TABLE, APPEND_STATE, &
+  PRIVATE :: ONESTEP_ON_DEVICE, SSA_STREAMS_REQUESTED, SSA_EXTENDER_STREAMS, STREAM_PATH, TICK, STATE_HASH, LOOKUP, PROBE, INSERT_RANGE, APPEND_CANDIDATES, CUSTOMPROP_IS_PURE, TABLE_INSERT, REBUILD_TABLE, LEGAL, RESERVE_TABLE, APPEND_STATE, &
        LINK_ONE, LINK_NEW, HOST_THREADS
 
   INTEGER(8), PARAMETER, PRIVATE :: LOW32 = 4294967295_8
@@ -87,6 +87,21 @@ MODULE STATESPACE
   ! 1-3 ONESTEP_EXTENDER scan / append / link, 4-5 SSA_EXTENDER walk / link,
   ! 6-9 DROP_STATES threshold+flags / compaction / renumbering / table
   DOUBLE PRECISION, SAVE :: STATESPACE_SEC(9) = 0.0D0
+
+  ! ONESTEP_EXTENDER's integer work on the device (kfsp_onestep, include/kfsp.h): set by the solver
+  ! module once it holds a device context; used for lists of at least ONESTEP_DEVICE_MIN states
+  ! (environment KFSP_DEVICE_ONESTEP_MIN, default 20000; KFSP_DEVICE_ONESTEP=0 switches it off).
+  ! Returns 0, -9 (state keys need more than 63 bits: the host sweep runs instead) or -11 (capacity).
+  ABSTRACT INTERFACE
+     INTEGER FUNCTION ONESTEP_DEVICE_FN(NS, NR, STOICH, N, STATE, ADJ, MAXCOUNT, CAP, NNEW)
+       INTEGER, INTENT(IN) :: NS, NR, N, MAXCOUNT, CAP
+       INTEGER, INTENT(IN) :: STOICH(NS, NR)
+       INTEGER, INTENT(INOUT) :: STATE(NS, *), ADJ(NR, *)      ! new states / completed links are written in place
+       INTEGER, INTENT(OUT) :: NNEW
+     END FUNCTION ONESTEP_DEVICE_FN
+  END INTERFACE
+  PROCEDURE(ONESTEP_DEVICE_FN), POINTER, SAVE :: ONESTEP_DEVICE => NULL()
+  INTEGER, SAVE, PRIVATE :: ONESTEP_DEVICE_MIN = -1
   INTEGER, PRIVATE, SAVE :: NTHREADS_CACHED = 0, PARALLEL_MIN = -1, SSA_STREAMS_FLAG = -1
   INTEGER, PRIVATE, SAVE :: TOUCH_SINK = 0        ! keeps the early loads of SSA_EXTENDER alive
 
@@ -618,6 +633,74 @@ CONTAINS
     !$OMP END PARALLEL DO
   END SUBROUTINE APPEND_CANDIDATES
 
+  ! The sweep with its integer work on the device: new states (in the reference's order) and the
+  ! complete link array come back in place; what stays here is what only the host can do - the
+  ! propensities of the new states (the model's own code), their hashes and table entries.
+  LOGICAL FUNCTION ONESTEP_ON_DEVICE(FSP, MODEL) RESULT(DONE)
+    TYPE(FINITE_STATE_PROJECTION) :: FSP
+    TYPE(CME_MODEL), INTENT(IN) :: MODEL
+    CHARACTER(LEN=16) :: ENV
+    INTEGER :: L, STAT, RC, N0, NNEW, SD, PD, I, K, NT
+    INTEGER(8) :: TCLK
+    DOUBLE PRECISION :: A
+    LOGICAL :: PARPROP
+    DONE = .FALSE.
+    IF (.NOT. ASSOCIATED(ONESTEP_DEVICE)) RETURN
+    IF (ONESTEP_DEVICE_MIN < 0) THEN
+       ONESTEP_DEVICE_MIN = 20000
+       CALL GET_ENVIRONMENT_VARIABLE('KFSP_DEVICE_ONESTEP_MIN', ENV, L, STAT)
+       IF (STAT == 0 .AND. L > 0) READ(ENV(1:L), *, IOSTAT=STAT) ONESTEP_DEVICE_MIN
+       CALL GET_ENVIRONMENT_VARIABLE('KFSP_DEVICE_ONESTEP', ENV, L, STAT)
+       IF (STAT == 0 .AND. L > 0) THEN
+          IF (ENV(1:1) == '0') ONESTEP_DEVICE_MIN = HUGE(1)
+       ENDIF
+    ENDIF
+    N0 = FSP%SIZE
+    IF (N0 < ONESTEP_DEVICE_MIN) RETURN
+    SD = MODEL%NSPECIES
+    PD = MODEL%NREACTIONS
+    IF (SIZE(FSP%STATE, 1) /= SD .OR. SIZE(FSP%MATRIX%ADJ, 1) /= PD) RETURN
+    CALL TICK(0, TCLK)
+    RC = ONESTEP_DEVICE(SD, PD, MODEL%STOICHIOMETRY(1:SD, 1:PD), N0, FSP%STATE, FSP%MATRIX%ADJ, MAXNUMBERMOLECULES, &
+         FSP%MAX_SIZE - 1, NNEW)
+    IF (RC == -11) STOP 'OVERFLOW ERROR: FSP SIZE EXCEEDS MEMORY LIMIT.'
+    IF (RC /= 0) RETURN                      ! (-9: keys too wide) the host sweep takes over
+    CALL TICK(1, TCLK)
+    DONE = .TRUE.
+    IF (NNEW == N0) RETURN
+    CALL RESERVE_TABLE(FSP, NNEW)
+    PARPROP = .NOT. ASSOCIATED(MODEL%CUSTOMPROP) .OR. CUSTOMPROP_IS_PURE()
+    NT = HOST_THREADS(NNEW - N0, 1024)
+    !$OMP PARALLEL DO NUM_THREADS(NT) SCHEDULE(STATIC) IF(NT > 1) PRIVATE(K, A)
+    DO I = N0 + 1, NNEW
+       FSP%KEY(I) = STATE_HASH(FSP%STATE(1:SD, I))
+       FSP%VECTOR(I) = 0.0D0
+       IF (PARPROP) THEN
+          FSP%MATRIX%DIAG(I) = 0.0D0
+          DO K = 1, PD
+             A = MODEL%PROPENSITY(FSP%STATE(1:SD, I), K)
+             FSP%MATRIX%DIAG(I) = FSP%MATRIX%DIAG(I) + A
+             FSP%MATRIX%OFFDIAG(K, I) = A
+          ENDDO
+       ENDIF
+    ENDDO
+    !$OMP END PARALLEL DO
+    IF (.NOT. PARPROP) THEN
+       DO I = N0 + 1, NNEW
+          FSP%MATRIX%DIAG(I) = 0.0D0
+          DO K = 1, PD
+             A = MODEL%PROPENSITY(FSP%STATE(1:SD, I), K)
+             FSP%MATRIX%DIAG(I) = FSP%MATRIX%DIAG(I) + A
+             FSP%MATRIX%OFFDIAG(K, I) = A
+          ENDDO
+       ENDDO
+    ENDIF
+    FSP%SIZE = NNEW
+    FSP%MATRIX%SIZE = NNEW
+    CALL INSERT_RANGE(FSP, N0 + 1, NNEW, .FALSE.)
+    CALL TICK(2, TCLK)
+  END FUNCTION ONESTEP_ON_DEVICE
+
   ! add every state one reaction away from the current list (in list order,
   ! reaction order; new states are appended and NOT revisited in this sweep).
   ! Pass 1 (parallel) resolves the open links whose target is already listed and
@@ -638,6 +721,7 @@ CONTAINS
     PD = MODEL%NREACTIONS
     N0 = FSP%SIZE
     CALL TICK(0, TCLK)
+    IF (ONESTEP_ON_DEVICE(FSP, MODEL)) RETURN
     NT = HOST_THREADS(N0, 4096)
     ALLOCATE(OFFS(0:NT), NC(0:NT))
     OFFS = 0

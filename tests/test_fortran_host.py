@@ -255,6 +255,25 @@ def test_cme_solve_with_internal_state_order(dump, tmp_path, fixture, case):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fixture,case", [("toggle_input_T05", "toggle_input"), ("toggle_example_T05", "toggle_example"),
+                                          ("repressilator_input_T1", "repressilator_input"),
+                                          ("goutsias_input_T15", "goutsias_input"), ("goutsias_input_T40", "goutsias_input")])
+def test_cme_solve_with_device_onestep(dump, tmp_path, fixture, case):
+    """The same adaptive runs with EVERY ONESTEP_EXTENDER sweep - the five at the start and the one after
+    each SSA expansion - taking its integer work from the device (kfsp_onestep; KFSP_DEVICE_ONESTEP_MIN=1
+    forces it at these sizes, by default it serves lists of >= 20000 states): new states in the
+    reference's order, links complete, so the whole trajectory, the final state list and the links
+    are the reference's bit for bit."""
+    g, d, log = _solve(dump, tmp_path, fixture, case, env={"KFSP_DEVICE_ONESTEP_MIN": "1"})
+    assert np.array_equal(log["step_n"], g["step_n"])
+    assert np.array_equal(log["step_tau"], g["step_tau"]) and np.array_equal(log["step_m"], g["step_m"])
+    assert np.array_equal(d["state"], g["state"]) and np.array_equal(d["adj"], g["adj"])
+    assert np.array_equal(d["offdiag"], g["offdiag"]) and np.array_equal(d["diag"], g["diag"])
+    assert np.abs(log["wsum"] - g["wsum"]).max() < 1e-10
+    assert np.abs(d["vector"] - g["vector"]).sum() < 1e-10
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("fixture,case", [("toggle_input", "toggle_input"), ("goutsias_input_T40", "goutsias_input"),
                                           ("repressilator_input_T1", "repressilator_input")])
 def test_cme_solve_with_independent_stream_ssa(dump, tmp_path, fixture, case):
