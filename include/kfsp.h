@@ -76,6 +76,15 @@ int kfsp_partition(int64_t n, int nranks, int rank, int64_t *row0, int64_t *nrow
  * 511, 528-529). */
 int kfsp_set_matrix_ell(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld,
                         const int32_t *adj, const double *offdiag, const double *diag);
+/* The same after the FSP GREW (ONESTEP_EXTENDER / SSA_EXTENDER, KrylovSolver.f90:528-529): the propensities
+ * of a listed state never change while it stays listed (StateSpace.f90:207-212), so the OFFDIAG / DIAG
+ * columns of the first n_unchanged states - the FSP the last kfsp_set_matrix_ell / kfsp_update_matrix_ell
+ * was given, or a leading part of it - are taken from the device's copy and only the columns behind them
+ * travel (their arguments are still the WHOLE arrays); ADJ is uploaded in full (links of old states do
+ * change).  n_unchanged is ignored (treated as 0) when the device does not hold those columns any more
+ * (another kind of generator was set in between, kfsp_drop_compact ran, ld changed). */
+int kfsp_update_matrix_ell(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, const int32_t *adj,
+                           const double *offdiag, const double *diag, int32_t n_unchanged);
 /* Optional, before kfsp_set_matrix_ell: the species counts of the n states of
  * that generator, FSP%STATE(1:ns, 1:n) (StateSpace.f90:22), leading dimension
  * ld >= ns.  The reference lists states in the order SSA_EXTENDER /

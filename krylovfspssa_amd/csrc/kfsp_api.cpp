@@ -769,8 +769,8 @@ int kfsp_row_block(const kfsp_ctx *ctx, int64_t n, int64_t *row0, int64_t *nrows
     return kfsp_partition(n, ctx->nranks, ctx->rank, row0, nrows, nullptr) ? -2 : 0;
 }
 
-int kfsp_set_matrix_ell(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, const int32_t *adj,
-                        const double *offdiag, const double *diag)
+static int set_matrix_ell_impl(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, const int32_t *adj,
+                               const double *offdiag, const double *diag, int64_t keep)
 {
     return no_throw(ctx, [&]() -> int {
         if (!ctx) return -1;
@@ -794,7 +794,7 @@ int kfsp_set_matrix_ell(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, const 
 
         if (!ctx->opt_host_build) {
             // the arrays go to HBM verbatim and are transposed there (kfsp_build.hip)
-            int rc = build_from_ell_device(ctx, n, bw, ld, adj, offdiag, diag);
+            int rc = build_from_ell_device(ctx, n, bw, ld, adj, offdiag, diag, keep);
             if (!rc) rc = setup_exchange(ctx);
             if (!rc) rc = adopt_pending_vector(ctx);
             ctx->t_ms[KFSP_T_UPLOAD] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -802,6 +802,7 @@ int kfsp_set_matrix_ell(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, const 
         }
 
         // host transpose (kept for A/B checks of the device build)
+        ctx->ell_cols = 0;
         // in-degree of every local row
         std::vector<int32_t> cnt((size_t)std::max<int64_t>(nloc, 1), 0);
         for (int64_t i = 0; i < n; ++i) {
@@ -847,6 +848,19 @@ int kfsp_set_matrix_ell(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, const 
     });
 }
 
+int kfsp_set_matrix_ell(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, const int32_t *adj,
+                        const double *offdiag, const double *diag)
+{
+    return set_matrix_ell_impl(ctx, n, bw, ld, adj, offdiag, diag, 0);
+}
+
+int kfsp_update_matrix_ell(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, const int32_t *adj,
+                           const double *offdiag, const double *diag, int32_t n_unchanged)
+{
+    if (n_unchanged < 0 || n_unchanged > n) return ctx ? fail(ctx, -8, "0 <= n_unchanged <= n") : -1;
+    return set_matrix_ell_impl(ctx, n, bw, ld, adj, offdiag, diag, n_unchanged);
+}
+
 int kfsp_set_matrix_csr(kfsp_ctx *ctx, int64_t n, int64_t row0, int64_t nrows, const int64_t *rowptr,
                         const int32_t *col, const double *val)
 {
@@ -860,6 +874,7 @@ int kfsp_set_matrix_csr(kfsp_ctx *ctx, int64_t n, int64_t row0, int64_t nrows, c
         ctx->prod_count = 0;
         ctx->use_box = false;
         ctx->box_lds_bytes = 0;
+        ctx->ell_cols = 0;
         if (int rc = resize(ctx, n)) return rc;
         if (row0 != std::min(ctx->row0, n)) return fail(ctx, -3, "row0 is not this rank's block start (kfsp_row_block)");
         if (nrows != ctx->nloc) return fail(ctx, -4, "nrows is not this rank's block size (kfsp_row_block)");
@@ -1059,6 +1074,7 @@ int kfsp_set_matrix_box(kfsp_ctx *ctx, int32_t ns, const int32_t *dims, int32_t 
         ctx->nnz = ctx->nranks == 1 ? nnz : 0;             // (per-rank counts are not tracked for boxes)
         ctx->use_dia = true;
         ctx->use_box = true;
+        ctx->ell_cols = 0;
         ctx->dia_masked = false;
         ctx->have_sell = false;
         ctx->nd = nr;
@@ -1574,6 +1590,7 @@ int kfsp_drop_compact(kfsp_ctx *ctx, int64_t *n_new)
     HIP_TRY(hipStreamSynchronize(st));
     if ((int64_t)nk != n - ctx->drop_flagged) return fail(ctx, 4000, "compaction count does not match the plan");
     ctx->drop_planned = false;
+    ctx->ell_cols = 0;                 // the columns are about to be renumbered
     ctx->w_pending = true;
     ctx->w_pending_n = nk;
     *n_new = nk;

@@ -358,7 +358,7 @@ __global__ __launch_bounds__(kBlock) void k_sell_sort_rows(int64_t nloc, const i
     } while (0)
 
 int build_from_ell_device(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, const int32_t *adj,
-                          const double *offdiag, const double *diag)
+                          const double *offdiag, const double *diag, int64_t keep)
 {
     if (bw > kMaxBw) {
         ctx->err = "more than 64 reaction slots";
@@ -370,13 +370,22 @@ int build_from_ell_device(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, cons
     const int64_t nact = nchunks * kChunk;
     const size_t nent = (size_t)n * (size_t)ld;
 
-    // the reference arrays, verbatim
+    // the reference arrays, verbatim.  Propensities of a listed state never change while it stays listed
+    // (OFFDIAG / DIAG columns are written once, StateSpace.f90:207-212): after an expansion only the
+    // columns of the appended states travel; the links (ADJ) of old states do change and travel in full.
+    if (keep > ctx->ell_cols || keep > n || ld != ctx->ell_ld) keep = 0;
+    ctx->ell_cols = 0;
     HIP_TRY_B(ctx->d_ell_adj.reserve(nent, false));
-    HIP_TRY_B(ctx->d_ell_off.reserve(nent, false));
-    HIP_TRY_B(ctx->d_ell_diag.reserve((size_t)n, false));
+    HIP_TRY_B(ctx->d_ell_off.reserve_keep(nent, (size_t)keep * (size_t)ld, st));
+    HIP_TRY_B(ctx->d_ell_diag.reserve_keep((size_t)n, (size_t)keep, st));
     HIP_TRY_B(hipMemcpyAsync(ctx->d_ell_adj.p, adj, nent * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    HIP_TRY_B(hipMemcpyAsync(ctx->d_ell_off.p, offdiag, nent * sizeof(double), hipMemcpyHostToDevice, st));
-    HIP_TRY_B(hipMemcpyAsync(ctx->d_ell_diag.p, diag, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
+    const size_t k0 = (size_t)keep * (size_t)ld;
+    if (nent > k0)
+        HIP_TRY_B(hipMemcpyAsync(ctx->d_ell_off.p + k0, offdiag + k0, (nent - k0) * sizeof(double), hipMemcpyHostToDevice, st));
+    if (n > keep)
+        HIP_TRY_B(hipMemcpyAsync(ctx->d_ell_diag.p + keep, diag + keep, (size_t)(n - keep) * sizeof(double), hipMemcpyHostToDevice, st));
+    ctx->ell_cols = n;
+    ctx->ell_ld = ld;
     const int32_t *ell_adj = ctx->d_ell_adj.p;
     const double *ell_off = ctx->d_ell_off.p, *ell_diag = ctx->d_ell_diag.p;
     if (ctx->perm_on) {

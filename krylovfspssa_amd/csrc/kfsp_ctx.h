@@ -39,6 +39,22 @@ struct DevBuf {
         if (zero) e = hipMemset(p, 0, n * sizeof(T));
         return e;
     }
+    // the same, but the first `keep` elements survive a reallocation
+    hipError_t reserve_keep(size_t n, size_t keep, hipStream_t st)
+    {
+        if (n <= cap) return hipSuccess;
+        if (keep == 0 || !p) return reserve(n, false);
+        n = std::max(n, cap + cap / 2);
+        T *q = nullptr;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&q), n * sizeof(T));
+        if (e != hipSuccess) return e;
+        e = hipMemcpyAsync(q, p, std::min(keep, cap) * sizeof(T), hipMemcpyDeviceToDevice, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        (void)hipFree(p);
+        p = q;
+        cap = n;
+        return e;
+    }
     void release()
     {
         if (p) (void)hipFree(p);
@@ -146,6 +162,9 @@ struct kfsp_ctx {
     int64_t dia_empty_segments = 0;   // (diagonal, 128-row group) pairs without entries
     // device-side build from the reference layout (kfsp_build.hip)
     DevBuf<int32_t> d_ell_adj, d_cnt, d_ticket;
+    // columns of OFFDIAG / DIAG resident from the last reference-layout upload (0: none that may be reused)
+    int64_t ell_cols = 0;
+    int32_t ell_ld = 0;
     DevBuf<double> d_ell_off, d_ell_diag;
     DevBuf<int> d_slot;
     DevBuf<char> d_scan;
@@ -215,8 +234,9 @@ struct kfsp_ctx {
 
 namespace kfsp {
 // generator build on the device from the reference layout (kfsp_build.hip)
+// keep: leading columns whose OFFDIAG / DIAG are resident and unchanged (only the rest is uploaded)
 int build_from_ell_device(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, const int32_t *adj,
-                          const double *offdiag, const double *diag);
+                          const double *offdiag, const double *diag, int64_t keep = 0);
 // after a banded generator was stored: find the empty (diagonal, 128-row group) segments and
 // switch the masked kernel variant on if they are worth skipping
 int build_dia_mask(kfsp_ctx *ctx);

@@ -265,19 +265,23 @@ CONTAINS
   END FUNCTION DEVICE_ONESTEP
 
   ! generator columns + probability vector of the current FSP -> device
-  SUBROUTINE UPLOAD_FSP(FSP, MODEL, WITH_VECTOR)
+  SUBROUTINE UPLOAD_FSP(FSP, MODEL, WITH_VECTOR, N_UNCHANGED)
     TYPE(FINITE_STATE_PROJECTION), INTENT(IN) :: FSP
     TYPE(CME_MODEL), INTENT(IN) :: MODEL
     LOGICAL, INTENT(IN), OPTIONAL :: WITH_VECTOR      ! .FALSE.: the device already holds the vector
+    INTEGER, INTENT(IN), OPTIONAL :: N_UNCHANGED      ! leading states whose propensity columns the device still holds
     INTEGER(C_INT) :: RC
+    INTEGER :: KEEP
+    KEEP = 0
+    IF (PRESENT(N_UNCHANGED)) KEEP = N_UNCHANGED
     ! the species counts let the device keep its own, locality-preserving state
     ! order if that was asked for (nothing changes on this side of the boundary)
     RC = KFSP_SET_STATE_COORDS(CTX, INT(FSP%SIZE, C_INT32_T), INT(MODEL%NSPECIES, C_INT32_T), &
          INT(SIZE(FSP%STATE, 1), C_INT32_T), FSP%STATE)
     CALL CHECK(RC, 'kfsp_set_state_coords')
-    RC = KFSP_SET_MATRIX_ELL(CTX, INT(FSP%SIZE, C_INT32_T), INT(MODEL%NREACTIONS, C_INT32_T), &
-         INT(SIZE(FSP%MATRIX%ADJ, 1), C_INT32_T), FSP%MATRIX%ADJ, FSP%MATRIX%OFFDIAG, FSP%MATRIX%DIAG)
-    CALL CHECK(RC, 'kfsp_set_matrix_ell')
+    RC = KFSP_UPDATE_MATRIX_ELL(CTX, INT(FSP%SIZE, C_INT32_T), INT(MODEL%NREACTIONS, C_INT32_T), &
+         INT(SIZE(FSP%MATRIX%ADJ, 1), C_INT32_T), FSP%MATRIX%ADJ, FSP%MATRIX%OFFDIAG, FSP%MATRIX%DIAG, INT(KEEP, C_INT32_T))
+    CALL CHECK(RC, 'kfsp_update_matrix_ell')
     IF (PRESENT(WITH_VECTOR)) THEN
        IF (.NOT. WITH_VECTOR) RETURN
     ENDIF
@@ -357,15 +361,18 @@ CONTAINS
     INTEGER(C_INT64_T) :: N_NEW
     INTEGER(C_INT) :: RC
     DOUBLE PRECISION :: TS, T0, T1, T2
+    INTEGER :: N_BEFORE
     RC = KFSP_GET_VECTOR(CTX, INT(CUR_FSP%SIZE, C_INT64_T), CUR_FSP%VECTOR)
     IF (RC /= 0) RETURN
+    N_BEFORE = CUR_FSP%SIZE
     TS = T_SSA
     T0 = WALL()
     CALL SSA_EXTENDER(TS, CUR_FSP, CUR_MODEL)
     T1 = WALL()
     CALL ONESTEP_EXTENDER(CUR_FSP, CUR_MODEL)
     T2 = WALL()
-    CALL UPLOAD_FSP(CUR_FSP, CUR_MODEL)
+    ! states only get appended here: the propensity columns of the first N_BEFORE are on the device already
+    CALL UPLOAD_FSP(CUR_FSP, CUR_MODEL, N_UNCHANGED=N_BEFORE)
     HOST_SEC(2) = HOST_SEC(2) + (T1 - T0)
     HOST_SEC(3) = HOST_SEC(3) + (T2 - T1)
     HOST_SEC(4) = HOST_SEC(4) + (WALL() - T2)

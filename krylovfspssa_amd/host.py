@@ -50,6 +50,7 @@ def load_library():
         "kfsp_row_block": [vp, i64, C.POINTER(i64), C.POINTER(i64)],
         "kfsp_partition": [i64, C.c_int, C.c_int, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)],
         "kfsp_set_matrix_ell": [vp, i32, i32, i32, vp, vp, vp],
+        "kfsp_update_matrix_ell": [vp, i32, i32, i32, vp, vp, vp, i32],
         "kfsp_set_matrix_csr": [vp, i64, i64, i64, vp, vp, vp],
         "kfsp_set_state_coords": [vp, i32, i32, i32, vp],
         "kfsp_set_matrix_box": [vp, i32, vp, i32, vp, vp, vp, vp],
@@ -253,6 +254,17 @@ class KfspContext:
         assert offdiag.shape == (n, bw) and diag.shape == (n,)
         self._chk(self._lib.kfsp_set_matrix_ell(self._h, n, bw, bw, _p(adj), _p(offdiag), _p(diag)),
                   "kfsp_set_matrix_ell")
+        self.n = n
+        self.row0, self.nloc = self.row_block(n)
+
+    def update_matrix_ell(self, adj, offdiag, diag, n_unchanged):
+        """set_matrix_ell after the FSP grew: OFFDIAG / DIAG of the first n_unchanged states stay on the device."""
+        adj = np.ascontiguousarray(adj, dtype=np.int32)
+        offdiag = np.ascontiguousarray(offdiag, dtype=np.float64)
+        diag = np.ascontiguousarray(diag, dtype=np.float64)
+        n, bw = adj.shape
+        self._chk(self._lib.kfsp_update_matrix_ell(self._h, n, bw, bw, _p(adj), _p(offdiag), _p(diag), int(n_unchanged)),
+                  "kfsp_update_matrix_ell")
         self.n = n
         self.row0, self.nloc = self.row_block(n)
 

@@ -180,3 +180,34 @@ def test_one_launch_arnoldi_with_and_without_the_generator_in_lds(golden_dir, fi
             out.append((H.copy(), av, c.get_basis(31), (mb, k1)))
     assert out[0][3] == out[1][3]
     assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1] and np.array_equal(out[0][2], out[1][2])
+
+
+def test_growing_fsp_uploads_only_the_new_propensity_columns(oracle, golden_dir):
+    """kfsp_update_matrix_ell: after an expansion the OFFDIAG / DIAG columns of the states that were
+    already listed are taken from the device's copy.  The reference's assembly after 5 sweeps is a
+    prefix of the one after 10 (states are only appended, StateSpace.f90:136-246): upload k = 5, then
+    k = 10 with the first n5 propensity columns of the HOST arrays poisoned - the product must still
+    be the true one; a stale claim (another generator in between) is ignored."""
+    import os
+    from krylovfspssa_amd import KfspContext
+    a = np.load(os.path.join(golden_dir, "assembly_goutsias_k5.npz"))
+    b = np.load(os.path.join(golden_dir, "assembly_goutsias_k10.npz"))
+    n5, n10 = a["adj"].shape[0], b["adj"].shape[0]
+    assert np.array_equal(a["offdiag"], b["offdiag"][:n5]) and np.array_equal(a["diag"], b["diag"][:n5])
+    A = oracle.EllMatrix(b["adj"], b["offdiag"], b["diag"])
+    x = np.random.default_rng(8).random(n10)
+    yref = oracle.spmv_ell(A, x)
+    scale = oracle.spmv_ell(oracle.EllMatrix(b["adj"], np.abs(b["offdiag"]), -np.abs(b["diag"])), x)
+    off_p, diag_p = b["offdiag"].copy(), b["diag"].copy()
+    off_p[:n5] = 1.0e30
+    diag_p[:n5] = -7.0
+    with KfspContext(0) as c:
+        c.set_matrix_ell(a["adj"], a["offdiag"], a["diag"])
+        c.update_matrix_ell(b["adj"], off_p, diag_p, n5)
+        assert np.all(np.abs(c.spmv(x) - yref) <= 1e-13 * scale)
+        # in between another kind of generator: the claim no longer holds and is ignored (so the poison shows)
+        c.set_matrix_csr(n10, *A.to_csr())
+        c.update_matrix_ell(b["adj"], off_p, diag_p, n5)
+        assert not np.all(np.abs(c.spmv(x) - yref) <= 1e-13 * scale)
+        c.update_matrix_ell(b["adj"], b["offdiag"], b["diag"], 0)        # everything travels again
+        assert np.all(np.abs(c.spmv(x) - yref) <= 1e-13 * scale)
