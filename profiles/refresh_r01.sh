@@ -1,4 +1,6 @@
 #!/bin/bash
+# ROUND-1 SCRIPT, kept for the record: it ran the reference's example drivers compiled against our modules on the GPU
+# box; since round 2 those binaries no longer travel (.gpurunignore) and end-to-end runs use `kfsp_dump solve` (profiles/begin_step_trace.sh).
 # Regenerates the round's measured artefacts on a GPU box (run from the repo root
 # through gpurun); outputs land in gpurun_out/ and are copied into profiles/ by hand.
 set -e

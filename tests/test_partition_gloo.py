@@ -6,7 +6,10 @@ column indices kept) is exercised with the communication pattern of the solver
 - all-gather of the source slab before every product, all-reduce of every
 scalar - and a CPU double for the local kernels (the oracle).  Each rank builds
 only its own rows, as bench.py does.  The result must equal the one-process
-oracle: this is what makes the RCCL path correct by construction."""
+oracle.  This file checks the partition ARITHMETIC and the exchange pattern on CPU
+processes; the library's own exchange code (strip packing, halo margins, rank > 0
+branches, split launches, staged scalars) runs with 2, 3 and 4 ranks on one GPU in
+tests/test_gpu_loopback.py."""
 import os
 import socket
 
