@@ -287,7 +287,47 @@ def make_sensitivity_sample(r, path):
     print(f"sensitivity sample: step {bs.index(ib)} N={F['n']} m={ps[0]['m']} t={[p['t'] for p in ps]} pade samples={k}")
 
 
+def fsp_digest(d, top=4000):
+    """What a 10^6-state result is compared by (the full list is 40 MB): size, mass, the marginal
+    distribution of every species, and the `top` most probable states with their probabilities."""
+    st, p = d["state"], d["vector"]
+    out = dict(n=np.int64(d["n"]), mass=float(p.sum()), ns=np.int32(d["ns"]))
+    for s in range(d["ns"]):
+        out[f"marginal_{s}"] = np.bincount(st[:, s], weights=p)
+    order = np.argsort(-p, kind="stable")[:top]
+    out["top_state"] = st[order]
+    out["top_prob"] = p[order]
+    return out
+
+
+def make_goutsias_T300():
+    """G8: models/goutsias_model.input over the horizon of examples/transcr6d.f90:16 (T = 300, FSPTOL 1e-6,
+    KRYTOL 1e-8; N -> 1.0e6 states, ~40 min on one core): digest of the reference's result."""
+    tmp = tempfile.mkdtemp(prefix="kfsp_golden_")
+    p = os.path.join(tmp, "g300.bin")
+    cmd = "ulimit -s unlimited && exec ../ref_dump solve goutsias_input " + p + " 300"
+    env = dict(os.environ, MKL_NUM_THREADS="1", KFSP_CASE_CAPACITY="2097169")
+    text = subprocess.run(["bash", "-c", cmd], cwd=os.path.join(REF_DIR, "models"), env=env, stdout=subprocess.PIPE,
+                          stderr=subprocess.STDOUT, check=True, text=True).stdout
+    save_goutsias_T300(p, text)
+
+
+def save_goutsias_T300(binfile, logtext):
+    d = read_fsp(binfile)
+    log = parse_log(logtext)
+    np.savez_compressed(os.path.join(GOLDEN, "digest_goutsias_input_T300.npz"), T=300.0, fsptol=1e-6, krytol=1e-8,
+                        steps=np.int32(len(log["step_no"])), n_ssa=log["n_ssa"], peak_n=np.int64(log["step_n"].max()),
+                        **fsp_digest(d))
+    print(f"goutsias T=300: N={d['n']} steps={len(log['step_no'])} mass={d['vector'].sum()!r}")
+
+
 def main():
+    if sys.argv[1:2] == ["goutsias300"]:
+        if len(sys.argv) > 3:
+            save_goutsias_T300(sys.argv[2], open(sys.argv[3]).read())      # from an existing run
+        else:
+            make_goutsias_T300()
+        return
     if sys.argv[1:2] == ["lockstep"]:
         make_lockstep(tempfile.mkdtemp(prefix="kfsp_golden_"))
         return

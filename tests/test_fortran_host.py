@@ -358,3 +358,36 @@ def test_compute_rkey_returns_the_reference_key_changes(tmp_path):
     x = [3, 7, 2, 2, 1, 1]
     for v, (sgn, rk) in zip(nu, got):
         assert key([a + b for a, b in zip(x, v)]) == key(x) + sgn * rk
+
+
+@pytest.mark.gpu
+def test_goutsias_full_horizon_agrees_with_the_reference(dump, tmp_path):
+    """models/goutsias_model.input over the horizon of the reference's own example (examples/transcr6d.f90:16:
+    T = 300, FSPTOL 1e-6, KRYTOL 1e-8; the FSP grows to ~10^6 states; ~40 min on one CPU core for the
+    reference, ~30 s here).  Over 300+ steps the two runs take different - equally valid - step and
+    expansion decisions, so the result is compared as a distribution: every species'
+    marginal and the 4000 most probable states, against the digest of the reference's result
+    (oracle/make_golden.py goutsias300), within the solver's own error budget
+    FSPTOL + 2 * DELTA * KRYTOL * T = 1e-6 + 7.2e-6."""
+    g = np.load(os.path.join(GOLDEN, "digest_goutsias_input_T300.npz"))
+    p = str(tmp_path / "g.bin")
+    text = _run(dump, ["solve", "goutsias_input", p, "300"], tmp_path, env={"KFSP_CASE_CAPACITY": "2097169"})
+    d = MG.read_fsp(p)
+    log = MG.parse_log(text)
+    budget = float(g["fsptol"]) + 2 * 1.2 * float(g["krytol"]) * float(g["T"])
+    w = d["vector"]
+    assert np.all(w >= 0) and 1.0 - w.sum() < float(g["fsptol"])
+    print(f"N={d['n']} (ref {int(g['n'])}) steps={len(log['step_no'])} (ref {int(g['steps'])}) mass={w.sum():.12f} (ref {float(g['mass']):.12f})")
+    assert 0.8 * int(g["n"]) < d["n"] < 1.25 * int(g["n"])
+    worst = 0.0
+    for s in range(int(g["ns"])):
+        ref = g[f"marginal_{s}"]
+        got = np.bincount(d["state"][:, s], weights=w)
+        k = max(len(ref), len(got))
+        diff = np.abs(np.pad(ref, (0, k - len(ref))) - np.pad(got, (0, k - len(got)))).sum()
+        worst = max(worst, diff)
+    index = {tuple(x): i for i, x in enumerate(d["state"].tolist())}
+    top = sum(abs(float(pr) - (w[index[tuple(x)]] if tuple(x) in index else 0.0))
+              for x, pr in zip(g["top_state"].tolist(), g["top_prob"].tolist()))
+    print(f"worst marginal l1 {worst:.3e}, l1 over the reference's 4000 most probable states {top:.3e} (budget {budget:.1e})")
+    assert worst < budget and top < budget
