@@ -349,56 +349,83 @@ __device__ __forceinline__ d2 rows_box(const BoxDev &B, const double *tab, const
 // Single-factor fast path (BoxFast): NS species with PER entry slots each, both compile-time, so the
 // species and slot of every entry are constants: straight-line code, no coordinate array, no
 // branches (an entry outside the box reads the 0.0 behind the tables and x of the row itself), all
-// gathers of x, table look-ups and (uniform, scalar) descriptor loads of a row in flight together.
+// gathers of x and table look-ups of a row in flight together.  The descriptor is read ONCE per
+// wavefront into registers (BoxRegs; readfirstlane makes them scalar): left as loads from F inside the
+// row code they are re-issued for every row (the stores to y may alias F as far as the compiler knows)
+// - as per-lane vector loads -, and inside selects each becomes its own exec-masked block.
+template <int NS, int PER>
+struct BoxRegs {
+    int off[NS][PER], nu[NS][PER], delta[NS][PER];
+    unsigned need[NS][PER];
+    int dims[NS];
+    double inv_dim[NS];
+    int zoff;
+};
+
+template <int NS, int PER>
+__device__ __forceinline__ void box_load(const BoxFast *__restrict__ F, BoxRegs<NS, PER> &R)
+{
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        R.dims[s] = __builtin_amdgcn_readfirstlane(F->dims[s]);
+        const double inv = F->inv_dim[s];
+        R.inv_dim[s] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(inv)),
+                                        __builtin_amdgcn_readfirstlane(__double2loint(inv)));
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            R.off[s][j] = __builtin_amdgcn_readfirstlane(F->off[s][j]);
+            R.nu[s][j] = __builtin_amdgcn_readfirstlane(F->nu[s][j]);
+            R.delta[s][j] = __builtin_amdgcn_readfirstlane(F->delta[s][j]);
+            R.need[s][j] = (unsigned)__builtin_amdgcn_readfirstlane((int)F->need[s][j]);
+        }
+    }
+    R.zoff = __builtin_amdgcn_readfirstlane(F->zoff);
+}
+
 __device__ __forceinline__ unsigned box_flag4(int v, int d)
 {
     return (unsigned)(v >= 1) | (unsigned)(v >= 2) << 1 | (unsigned)(v <= d - 2) << 2 | (unsigned)(v <= d - 3) << 3;
 }
 
-template <int S, int PER>
-__device__ __forceinline__ void box_species(const BoxFast *__restrict__ F, const double *tab, int xs, unsigned flags,
+template <int S, int NS, int PER>
+__device__ __forceinline__ void box_species(const BoxRegs<NS, PER> &R, const double *tab, int xs, unsigned flags,
                                             const double *__restrict__ xg, int64_t g, double &dsum, double &acc)
 {
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
-        // uniform descriptor words first, unconditionally: left inside the selects below the compiler
-        // wraps every one of them in its own exec-masked block (load, wait, branch) and serialises the row
-        // (readfirstlane is convergent: it cannot be sunk into a divergent branch)
-        const int off = __builtin_amdgcn_readfirstlane(F->off[S][j]), nu = __builtin_amdgcn_readfirstlane(F->nu[S][j]);
-        const int delta = __builtin_amdgcn_readfirstlane(F->delta[S][j]), zoff = __builtin_amdgcn_readfirstlane(F->zoff);
-        const unsigned need = (unsigned)__builtin_amdgcn_readfirstlane((int)F->need[S][j]);
+        const unsigned need = R.need[S][j];
         const bool in = (flags & need) == need;
-        const double a0 = tab[off + xs];                          // a_k at x: part of DIAG (StateSpace.f90:207-212)
-        const double a1 = tab[in ? off + xs - nu : zoff];         // a_k at the source state x - nu_k, or 0
-        const double xv = xg[g + (in ? (int64_t)delta : 0)];
+        const double a0 = tab[R.off[S][j] + xs];                                      // a_k at x: part of DIAG (StateSpace.f90:207-212)
+        const double a1 = tab[in ? R.off[S][j] + xs - R.nu[S][j] : R.zoff];          // a_k at the source state x - nu_k, or 0
+        const double xv = xg[g + (in ? (int64_t)R.delta[S][j] : 0)];
         dsum += a0;
         acc += a1 * xv;
     }
 }
 
 template <int NS, int PER>
-__device__ __forceinline__ double row_box1(const BoxFast *__restrict__ F, const double *tab, int c0, int c1, int c2, int c3,
-                                           int c4, int c5, const double *__restrict__ xg, int64_t g)
+__device__ __forceinline__ double row_box1(const BoxRegs<NS, PER> &R, const double *tab, int c0, int c1, int c2, int c3, int c4,
+                                           int c5, const double *__restrict__ xg, int64_t g)
 {
-    unsigned flags = box_flag4(c0, F->dims[0]);
-    if (NS > 1) flags |= box_flag4(c1, F->dims[1]) << 4;
-    if (NS > 2) flags |= box_flag4(c2, F->dims[2]) << 8;
-    if (NS > 3) flags |= box_flag4(c3, F->dims[3]) << 12;
-    if (NS > 4) flags |= box_flag4(c4, F->dims[4]) << 16;
-    if (NS > 5) flags |= box_flag4(c5, F->dims[5]) << 20;
+    unsigned flags = box_flag4(c0, R.dims[0]);
+    if (NS > 1) flags |= box_flag4(c1, R.dims[NS > 1 ? 1 : 0]) << 4;
+    if (NS > 2) flags |= box_flag4(c2, R.dims[NS > 2 ? 2 : 0]) << 8;
+    if (NS > 3) flags |= box_flag4(c3, R.dims[NS > 3 ? 3 : 0]) << 12;
+    if (NS > 4) flags |= box_flag4(c4, R.dims[NS > 4 ? 4 : 0]) << 16;
+    if (NS > 5) flags |= box_flag4(c5, R.dims[NS > 5 ? 5 : 0]) << 20;
     const double xd = xg[g];
     double dsum = 0.0, acc = 0.0;
-    box_species<0, PER>(F, tab, c0, flags, xg, g, dsum, acc);
-    if (NS > 1) box_species<1, PER>(F, tab, c1, flags, xg, g, dsum, acc);
-    if (NS > 2) box_species<2, PER>(F, tab, c2, flags, xg, g, dsum, acc);
-    if (NS > 3) box_species<3, PER>(F, tab, c3, flags, xg, g, dsum, acc);
-    if (NS > 4) box_species<4, PER>(F, tab, c4, flags, xg, g, dsum, acc);
-    if (NS > 5) box_species<5, PER>(F, tab, c5, flags, xg, g, dsum, acc);
+    box_species<0, NS, PER>(R, tab, c0, flags, xg, g, dsum, acc);
+    if (NS > 1) box_species<(NS > 1 ? 1 : 0), NS, PER>(R, tab, c1, flags, xg, g, dsum, acc);
+    if (NS > 2) box_species<(NS > 2 ? 2 : 0), NS, PER>(R, tab, c2, flags, xg, g, dsum, acc);
+    if (NS > 3) box_species<(NS > 3 ? 3 : 0), NS, PER>(R, tab, c3, flags, xg, g, dsum, acc);
+    if (NS > 4) box_species<(NS > 4 ? 4 : 0), NS, PER>(R, tab, c4, flags, xg, g, dsum, acc);
+    if (NS > 5) box_species<(NS > 5 ? 5 : 0), NS, PER>(R, tab, c5, flags, xg, g, dsum, acc);
     return acc - dsum * xd;
 }
 
 template <int NS, int PER>
-__device__ __forceinline__ d2 rows_box1(const BoxFast *__restrict__ F, const double *tab, const double *__restrict__ xg,
+__device__ __forceinline__ d2 rows_box1(const BoxRegs<NS, PER> &R, const double *tab, const double *__restrict__ xg,
                                         int64_t row0, int64_t nloc, int64_t c, int lane)
 {
     d2 sum = {0.0, 0.0};
@@ -410,8 +437,8 @@ __device__ __forceinline__ d2 rows_box1(const BoxFast *__restrict__ F, const dou
     uint32_t q = (uint32_t)g;
 #define KFSP_BOX_DEC(S, VAR)                                             \
     if (NS > S + 1) {                                                    \
-        const int d = F->dims[S];                                        \
-        uint32_t t = (uint32_t)((double)q * F->inv_dim[S]);              \
+        const int d = R.dims[NS > S ? S : 0];                            \
+        uint32_t t = (uint32_t)((double)q * R.inv_dim[NS > S ? S : 0]);  \
         int r = (int)(q - t * (uint32_t)d);                              \
         const int lo = r < 0, hi = r >= d;                               \
         t = t - lo + hi;                                                 \
@@ -428,14 +455,14 @@ __device__ __forceinline__ d2 rows_box1(const BoxFast *__restrict__ F, const dou
     KFSP_BOX_DEC(4, c4)
     KFSP_BOX_DEC(5, c5)
 #undef KFSP_BOX_DEC
-    sum.x = row_box1<NS, PER>(F, tab, c0, c1, c2, c3, c4, c5, xg, g);
+    sum.x = row_box1<NS, PER>(R, tab, c0, c1, c2, c3, c4, c5, xg, g);
     if (r0 + 1 < nloc) {
         // next row: +1 with carry (the last species never wraps: g + 1 < n)
         int carry = 1;
 #define KFSP_BOX_INC(S, VAR)                                             \
     if (NS > S) {                                                        \
         const int v = VAR + carry;                                       \
-        const int wrap = (NS > S + 1) && v >= F->dims[S];                \
+        const int wrap = (NS > S + 1) && v >= R.dims[NS > S ? S : 0];    \
         VAR = wrap ? 0 : v;                                              \
         carry = wrap;                                                    \
     }
@@ -446,7 +473,7 @@ __device__ __forceinline__ d2 rows_box1(const BoxFast *__restrict__ F, const dou
         KFSP_BOX_INC(4, c4)
         KFSP_BOX_INC(5, c5)
 #undef KFSP_BOX_INC
-        sum.y = row_box1<NS, PER>(F, tab, c0, c1, c2, c3, c4, c5, xg, g + 1);
+        sum.y = row_box1<NS, PER>(R, tab, c0, c1, c2, c3, c4, c5, xg, g + 1);
     }
     return sum;
 }
@@ -466,10 +493,12 @@ __global__ __launch_bounds__(kBlock) void k_spmv(SpmvArgs a)
         if (*a.brk_flag) return;
     }
     const double *tab = nullptr;
+    BoxRegs<(NS ? NS : 1), (NE ? NE : 1)> boxr;
     if (BOX) {
         for (int i = threadIdx.x; i < a.B.ntab; i += kBlock) box_lds[i] = a.box_tab[i];
         __syncthreads();
         tab = box_lds;
+        if (FMT == 4) box_load(a.box_fast, boxr);
     }
 
     // SELL: one 64-row chunk per wavefront trip; DIA: one 128-row group
@@ -489,7 +518,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv(SpmvArgs a)
     unsigned gm = 0xFFFFFFFFu;                              // group mask of the trip about to be computed
     if (FMT == 2 && c < cend) gm = __builtin_amdgcn_readfirstlane(a.D.gmask[ct]);
     if (c < cend) {
-        if (FMT == 4) sum = rows_box1<(NS ? NS : 1), (NE ? NE : 1)>(a.box_fast, tab, a.xg, a.row0, a.A.nrows, ct, lane);
+        if (FMT == 4) sum = rows_box1<(NS ? NS : 1), (NE ? NE : 1)>(boxr, tab, a.xg, a.row0, a.A.nrows, ct, lane);
         else if (BOX) sum = rows_box<0, 0>(a.B, tab, a.xg, a.row0, a.A.nrows, ct, lane);
         else if (DIA) sum = rows_dia<NT, FMT == 2>(a.D, a.xg, a.row0, ct, lane, gm);
         else sum.x = row_sell<NT>(a.A, a.xg, a.row0, ct, lane);
@@ -548,7 +577,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv(SpmvArgs a)
         c = cn;
         ct = ctn;
         if (c < cend) {
-            if (FMT == 4) sum = rows_box1<(NS ? NS : 1), (NE ? NE : 1)>(a.box_fast, tab, a.xg, a.row0, a.A.nrows, ct, lane);
+            if (FMT == 4) sum = rows_box1<(NS ? NS : 1), (NE ? NE : 1)>(boxr, tab, a.xg, a.row0, a.A.nrows, ct, lane);
         else if (BOX) sum = rows_box<0, 0>(a.B, tab, a.xg, a.row0, a.A.nrows, ct, lane);
             else if (DIA) sum = rows_dia<NT, FMT == 2>(a.D, a.xg, a.row0, ct, lane, gm);
             else sum.x = row_sell<NT>(a.A, a.xg, a.row0, ct, lane);
