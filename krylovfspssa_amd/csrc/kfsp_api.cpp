@@ -236,7 +236,14 @@ int run_product(kfsp_ctx *ctx, int mode, SpmvArgs a, const double *src, bool src
     const bool dia = ctx->use_dia && !force_sell;
     const bool nt = use_nt(ctx);
     const int64_t trips = dia ? (ctx->nchunks + 1) / 2 : ctx->nchunks;
-    const int64_t cap = ctx->opt_grid > 0 ? round_up(ctx->opt_grid, 8) : 1024;
+    int64_t cap = ctx->opt_grid > 0 ? round_up(ctx->opt_grid, 8) : 1024;
+    if (ctx->use_box && dia && ctx->opt_grid <= 0) {
+        // every workgroup of a matrix-free product copies the table image into its LDS first: no more
+        // workgroups than are resident at once (160 KB of LDS per CU), or the later ones pay that copy
+        // again for fewer rows each (toggle 1000 x 1000, 64 KB image: 8.3 us with 512, 12.1 us with 1024)
+        const int64_t per_cu = std::max<int64_t>(1, (int64_t)(160 * 1024) / (int64_t)(ctx->box_lds_bytes + 512));
+        cap = std::min<int64_t>(cap, 256 * per_cu);
+    }
     double *P1 = mode != 0 ? next_partial(ctx) : nullptr;
     double *P2 = mode == 3 ? next_partial(ctx) : nullptr;
     a.row0 = ctx->row0;
@@ -974,8 +981,8 @@ int kfsp_set_matrix_box(kfsp_ctx *ctx, int32_t ns, const int32_t *dims, int32_t 
                 ntab += dims[s];
             }
         }
-        if (ntab + dims[0] > 6000) return fail(ctx, -8, "factor tables exceed the 48 KB they may take in LDS");
-        B.ntab = (int32_t)ntab;
+        const int head = kfsp::kBoxImageHead;              // image = [0.0, 0.0][factor tables][fast form's species tables]
+        if (head + ntab > 6000) return fail(ctx, -8, "factor tables exceed the 48 KB they may take in LDS");
         for (int p = 0; p < nr; ++p) {
             const int k = order[(size_t)p].k;
             B.delta[p] = (int32_t)order[(size_t)p].delta;
@@ -984,7 +991,7 @@ int kfsp_set_matrix_box(kfsp_ctx *ctx, int32_t ns, const int32_t *dims, int32_t 
                 const int s = dep_species[(size_t)k * kfsp::kBoxMaxDep + i];
                 B.dep_s[p][i] = (int8_t)s;
                 B.dep_nu[p][i] = (int8_t)stoich[(size_t)k * ns + s];
-                B.dep_off[p][i] = toff[(size_t)k * kfsp::kBoxMaxDep + i];
+                B.dep_off[p][i] = head + toff[(size_t)k * kfsp::kBoxMaxDep + i];
             }
             int nm = 0;
             for (int s = 0; s < ns; ++s) {
@@ -1001,7 +1008,7 @@ int kfsp_set_matrix_box(kfsp_ctx *ctx, int32_t ns, const int32_t *dims, int32_t 
             B.dorder[k] = p;                               // original reaction k sits at sorted position p
         }
         // single-factor fast form: every propensity one factor, no species changes by more than 2, at
-        // most kBoxFastPer propensities per species
+        // most kBoxFastPer propensities per species, the entries of a row within 2^32 bytes of x
         kfsp::BoxFast F;
         std::memset(&F, 0, sizeof(F));
         bool fast = ns <= kfsp::kBoxFastS;
@@ -1011,57 +1018,75 @@ int kfsp_set_matrix_box(kfsp_ctx *ctx, int32_t ns, const int32_t *dims, int32_t 
             for (int s = 0; s < ns; ++s) fast = fast && std::abs(stoich[(size_t)k * ns + s]) <= 2;
             if (fast) fast = ++per_species[dep_species[(size_t)k * kfsp::kBoxMaxDep]] <= kfsp::kBoxFastPer;
         }
+        const int64_t back = std::max<int64_t>(0, -order.front().delta), fwd = std::max<int64_t>(0, order.back().delta);
+        if (back + fwd + 130 >= (1LL << 28)) fast = false;
+        int per = 2, ns_inst = kfsp::kBoxFastS;
+        int64_t df_at[kfsp::kBoxFastS] = {0};
+        int64_t nimage = head + ntab;
         if (fast) {
-            int per = 2;
             for (int s = 0; s < ns; ++s) per = std::max(per, per_species[s]);
             if (per > 2) per = kfsp::kBoxFastPer;
             // instantiations (launch_spmv): 2, 3 or 6 species with 2 slots each, else 6 species with 4 slots
-            const int ns_inst = (per == 2 && ns <= 2) ? 2 : (per == 2 && ns == 3) ? 3 : kfsp::kBoxFastS;
+            ns_inst = (per == 2 && ns <= 2) ? 2 : (per == 2 && ns == 3) ? 3 : kfsp::kBoxFastS;
+            nimage += nimage & 1;
+            for (int s = 0; s < ns_inst; ++s) {
+                df_at[s] = nimage;
+                nimage += 2 * (s < ns ? dims[s] : 1);
+            }
+            if (nimage > 8180) {                                  // 64 KB of LDS less the kernel's own few words
+                fast = false;
+                nimage = head + ntab;
+            }
+        }
+        std::vector<double> image((size_t)nimage + (sizeof(kfsp::BoxFast) + 7) / 8, 0.0);
+        std::memcpy(image.data() + head, tables, (size_t)ntab * sizeof(double));
+        if (fast) {
             F.ns = ns_inst;
             F.per = per;
+            F.bias8 = (int32_t)(8 * back);
             for (int s = 0; s < kfsp::kBoxFastS; ++s) {
                 F.dims[s] = s < ns ? dims[s] : 1;                 // missing species: one population count, 0
                 F.inv_dim[s] = 1.0 / (double)F.dims[s];
-                for (int j = 0; j < kfsp::kBoxFastPer; ++j) F.need[s][j] = 0x80000000u;   // padding: never inside the box
+                F.df8[s] = (int32_t)(8 * df_at[s]);
             }
+            struct DF { double dsum; uint32_t valid, pad; };
+            static_assert(sizeof(DF) == 16, "layout of the kernel's BoxDF");
             int fill[kfsp::kBoxFastS] = {0};
+            int entry_k[kfsp::kBoxFastS * kfsp::kBoxFastPer];
+            for (int e = 0; e < ns_inst * per; ++e) entry_k[e] = -1;
             for (int p = 0; p < nr; ++p) {                        // ascending column offset within a species
                 const int k = order[(size_t)p].k;
                 const int s = dep_species[(size_t)k * kfsp::kBoxMaxDep];
                 const int j = fill[s]++;
-                F.off[s][j] = toff[(size_t)k * kfsp::kBoxMaxDep];
-                F.nu[s][j] = stoich[(size_t)k * ns + s];
-                F.delta[s][j] = (int32_t)order[(size_t)p].delta;
-                uint32_t need = 0;
-                for (int t = 0; t < ns; ++t) {
-                    const int v = stoich[(size_t)k * ns + t];     // source coordinate = x_t - v
-                    if (v == 1) need |= 1u << (4 * t);
-                    if (v == 2) need |= 2u << (4 * t);
-                    if (v == -1) need |= 4u << (4 * t);
-                    if (v == -2) need |= 8u << (4 * t);
+                F.koff8[s][j] = 8 * (head + toff[(size_t)k * kfsp::kBoxMaxDep] - stoich[(size_t)k * ns + s]);
+                F.delta8[s][j] = (int32_t)(8 * order[(size_t)p].delta);
+                entry_k[s * per + j] = k;
+            }
+            for (int s = 0; s < ns_inst; ++s) {
+                const int d = s < ns ? dims[s] : 1;
+                DF *df = reinterpret_cast<DF *>(image.data() + df_at[s]);
+                for (int i = 0; i < d; ++i) {
+                    double sum = 0.0;
+                    uint32_t valid = 0;
+                    for (int e = 0; e < ns_inst * per; ++e) {
+                        const int k = entry_k[e];
+                        if (k < 0) continue;                      // unused slot: never valid
+                        const int v = s < ns ? stoich[(size_t)k * ns + s] : 0;   // source coordinate = i - v
+                        if (i - v >= 0 && i - v < d) valid |= 1u << e;
+                        if (e / per == s) sum += tables[(size_t)toff[(size_t)k * kfsp::kBoxMaxDep] + i];
+                    }
+                    df[i] = DF{sum, valid, 0u};
                 }
-                F.need[s][j] = need;
             }
             B.pad = ns_inst * 16 + per;
         }
-        // dims[0] zeros behind the tables: the factor of the padded entries
-        const int64_t ntab_real = ntab;
-        ntab += dims[0];
-        F.zoff = (int32_t)ntab_real;
-        if (fast)
-            for (int s = 0; s < kfsp::kBoxFastS; ++s)
-                for (int j = 0; j < kfsp::kBoxFastPer; ++j)
-                    if (F.need[s][j] == 0x80000000u) F.off[s][j] = (int32_t)ntab_real;
-        B.ntab = (int32_t)ntab;
-        const size_t fwords = (sizeof(kfsp::BoxFast) + 7) / 8;
-        std::vector<double> image((size_t)ntab + fwords, 0.0);
-        std::memcpy(image.data(), tables, (size_t)ntab_real * sizeof(double));
-        std::memcpy(image.data() + ntab, &F, sizeof(F));
+        B.ntab = (int32_t)nimage;
+        std::memcpy(image.data() + nimage, &F, sizeof(F));
         HIP_TRY(ctx->d_box.reserve(image.size() + 8, false));
         HIP_TRY(hipMemcpy(ctx->d_box.p, image.data(), image.size() * sizeof(double), hipMemcpyHostToDevice));
         ctx->box = B;
         ctx->box_fast = fast;
-        ctx->box_lds_bytes = (size_t)ntab * sizeof(double);
+        ctx->box_lds_bytes = (size_t)nimage * sizeof(double);
         // the same bookkeeping as a banded generator with one diagonal per reaction
         ctx->nchunks = (ctx->nloc + kChunk - 1) / kChunk;
         ctx->slots = 0;

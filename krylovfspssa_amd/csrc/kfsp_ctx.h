@@ -21,6 +21,10 @@ constexpr int kNumStage = 8;     // rotating all-reduce staging scalars
 
 template <class T>
 struct DevBuf {
+    // kGuard elements in front of p and behind p + cap belong to the buffer and are zero: a kernel
+    // that loads two neighbouring elements at once may touch the element before the first or behind
+    // the last one it needs (the matrix-free product does) - readable, finite, never used.
+    static constexpr size_t kGuard = 256 / sizeof(T);
     T *p = nullptr;
     size_t cap = 0;
     hipError_t reserve(size_t n, bool zero)
@@ -30,11 +34,11 @@ struct DevBuf {
         // that hipFree/hipMalloc (both synchronise the device, and fresh memory
         // costs the first kernel that touches it) happen O(log n) times.
         if (cap > 0) n = std::max(n, cap + cap / 2);
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), n * sizeof(T));
+        release();
+        T *q = nullptr;
+        hipError_t e = alloc(n, &q);
         if (e != hipSuccess) return e;
+        p = q;
         cap = n;
         if (zero) e = hipMemset(p, 0, n * sizeof(T));
         return e;
@@ -46,20 +50,36 @@ struct DevBuf {
         if (keep == 0 || !p) return reserve(n, false);
         n = std::max(n, cap + cap / 2);
         T *q = nullptr;
-        hipError_t e = hipMalloc(reinterpret_cast<void **>(&q), n * sizeof(T));
+        hipError_t e = alloc(n, &q);
         if (e != hipSuccess) return e;
         e = hipMemcpyAsync(q, p, std::min(keep, cap) * sizeof(T), hipMemcpyDeviceToDevice, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
-        (void)hipFree(p);
+        (void)hipFree(p - kGuard);
         p = q;
         cap = n;
         return e;
     }
     void release()
     {
-        if (p) (void)hipFree(p);
+        if (p) (void)hipFree(p - kGuard);
         p = nullptr;
         cap = 0;
+    }
+
+private:
+    static hipError_t alloc(size_t n, T **out)
+    {
+        T *base = nullptr;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&base), (n + 2 * kGuard) * sizeof(T));
+        if (e != hipSuccess) return e;
+        e = hipMemset(base, 0, kGuard * sizeof(T));
+        if (e == hipSuccess) e = hipMemset(base + kGuard + n, 0, kGuard * sizeof(T));
+        if (e != hipSuccess) {
+            (void)hipFree(base);
+            return e;
+        }
+        *out = base + kGuard;
+        return hipSuccess;
     }
 };
 

@@ -76,21 +76,22 @@ struct BoxDev {
 
 // The same generator when every propensity has ONE factor and no reaction changes a species by
 // more than 2 (all benchmark boxes): the entries are grouped by the species their factor depends
-// on, kBoxPer... slots per species (padded with entries whose factor is 0), so that in the kernel
-// both the species and the slot of an entry are compile-time constants: straight-line code on
-// coordinate registers, all gathers of a row in flight together.  Whether the source state of an
-// entry lies inside the box is one AND against a per-row flag word (4 bits per species:
-// x >= 1, x >= 2, x <= d-2, x <= d-3).  Lives in device memory behind the tables; uniform, read
-// with scalar loads.
+// on, `per` slots per species (unused slots are never valid), so that in the kernel both the
+// species and the slot of an entry are compile-time constants: straight-line code on coordinate
+// registers, all gathers of a row in flight together.  The LDS image carries, behind the factor
+// tables, one table per species of {sum of the species' propensities at this count, valid bits}
+// (BoxDF in the kernel): bit e says that entry e's source coordinate of this species lies inside
+// the box; the AND over the species is the set of entries the row has.  Element 0 of the image is
+// 0.0 - what an invalid entry reads.  Lives in device memory behind the image; uniform.
 constexpr int kBoxFastS = 6, kBoxFastPer = 4;
+constexpr int kBoxImageHead = 2;              // doubles in front of the factor tables (the 0.0; keeps 16-byte alignment)
 struct BoxFast {
-    int32_t ns, per, zoff, pad1;              // species (padded with dimension 1), slots per species, offset of a 0.0
+    int32_t ns, per, bias8, pad1;             // species (padded with dimension 1), slots per species, see BoxRegs
     int32_t dims[kBoxFastS];
     double inv_dim[kBoxFastS];
-    int32_t off[kBoxFastS][kBoxFastPer];      // offset of the entry's factor table (zoff for padding)
-    int32_t nu[kBoxFastS][kBoxFastPer];       // stoichiometry of its own species (source coordinate = x - nu)
-    int32_t delta[kBoxFastS][kBoxFastPer];    // x index of the source state relative to the row
-    uint32_t need[kBoxFastS][kBoxFastPer];    // flag bits that must be set for the source to be inside the box
+    int32_t koff8[kBoxFastS][kBoxFastPer];    // 8 * (offset of the entry's factor table in the image - nu of its own species)
+    int32_t delta8[kBoxFastS][kBoxFastPer];   // 8 * (x index of the source state relative to the row)
+    int32_t df8[kBoxFastS];                   // byte offset of the species' {sum, valid} table in the image
 };
 
 // A scalar that is the sum of n doubles at p (block partials of the producing

@@ -347,19 +347,28 @@ __device__ __forceinline__ d2 rows_box(const BoxDev &B, const double *tab, const
 }
 
 // Single-factor fast path (BoxFast): NS species with PER entry slots each, both compile-time, so the
-// species and slot of every entry are constants: straight-line code, no coordinate array, no
-// branches (an entry outside the box reads the 0.0 behind the tables and x of the row itself), all
-// gathers of x and table look-ups of a row in flight together.  The descriptor is read ONCE per
-// wavefront into registers (BoxRegs; readfirstlane makes them scalar): left as loads from F inside the
-// row code they are re-issued for every row (the stores to y may alias F as far as the compiler knows)
-// - as per-lane vector loads -, and inside selects each becomes its own exec-masked block.
+// species and slot of every entry are constants: straight-line code, no branches, all gathers of x and
+// table look-ups of a row in flight together.  Per species ONE 16-byte LDS entry gives the sum of its
+// propensities at x_s (its share of DIAG, StateSpace.f90:207-212) and a word with one bit per entry:
+// "this coordinate lets the entry's source state x - nu lie inside the box"; the AND over the species
+// is the row's set of valid entries.  An invalid entry is not branched around: its mask (0 / -1)
+// redirects the look-up to the 0.0 at the head of the LDS image.
+// A lane owns rows 2l and 2l+1 of the wave's 128, and ONE 16-byte load per entry fetches the source
+// elements of both (x[g + delta], x[g + 1 + delta]): the kernel is bound by the number of vector-memory
+// instructions a CU can issue, not by bytes.  If only one of the two rows has the entry, the other slot
+// holds some other element of x, or the element just before / behind x (every device buffer carries
+// guard words, DevBuf): finite, and multiplied by the 0.0.  x is addressed as wave base (scalar) +
+// 32-bit lane offset (kfsp_set_matrix_box checks the reach).  The descriptor is read ONCE per wavefront
+// into scalar registers (BoxRegs): left as loads inside the row code they would be re-issued for every
+// row, as per-lane vector loads.
 template <int NS, int PER>
 struct BoxRegs {
-    int off[NS][PER], nu[NS][PER], delta[NS][PER];
-    unsigned need[NS][PER];
+    int koff8[NS][PER];    // byte offset in the LDS image of a_k(x_s - nu_k), less 8 x_s
+    int delta8[NS][PER];   // byte offset in x of the source state relative to the row
+    int df8[NS];           // byte offset of the species' {sum, valid bits} table
     int dims[NS];
     double inv_dim[NS];
-    int zoff;
+    int bias8;             // bytes the wave's x base lies below its first row (>= the largest backward reach)
 };
 
 template <int NS, int PER>
@@ -368,70 +377,86 @@ __device__ __forceinline__ void box_load(const BoxFast *__restrict__ F, BoxRegs<
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         R.dims[s] = __builtin_amdgcn_readfirstlane(F->dims[s]);
+        R.df8[s] = __builtin_amdgcn_readfirstlane(F->df8[s]);
         const double inv = F->inv_dim[s];
         R.inv_dim[s] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(inv)),
                                         __builtin_amdgcn_readfirstlane(__double2loint(inv)));
 #pragma unroll
         for (int j = 0; j < PER; ++j) {
-            R.off[s][j] = __builtin_amdgcn_readfirstlane(F->off[s][j]);
-            R.nu[s][j] = __builtin_amdgcn_readfirstlane(F->nu[s][j]);
-            R.delta[s][j] = __builtin_amdgcn_readfirstlane(F->delta[s][j]);
-            R.need[s][j] = (unsigned)__builtin_amdgcn_readfirstlane((int)F->need[s][j]);
+            R.koff8[s][j] = __builtin_amdgcn_readfirstlane(F->koff8[s][j]);
+            R.delta8[s][j] = __builtin_amdgcn_readfirstlane(F->delta8[s][j]);
         }
     }
-    R.zoff = __builtin_amdgcn_readfirstlane(F->zoff);
+    R.bias8 = __builtin_amdgcn_readfirstlane(F->bias8);
 }
 
-__device__ __forceinline__ unsigned box_flag4(int v, int d)
-{
-    return (unsigned)(v >= 1) | (unsigned)(v >= 2) << 1 | (unsigned)(v <= d - 2) << 2 | (unsigned)(v <= d - 3) << 3;
-}
+extern __shared__ double box_lds[];   // matrix-free kernels: the image of the factor tables (dynamic LDS)
+// byte pointers that keep their address space through integer arithmetic (LDS reads, scalar-base global loads)
+typedef const __attribute__((address_space(3))) char *lds_bytes_t;
+typedef const __attribute__((address_space(1))) char *global_bytes_t;
+typedef double __attribute__((ext_vector_type(2))) box_pair_t;
+// One population count of one species in the LDS image, 16 bytes: { double dsum - the sum of the
+// propensities that depend on this species; unsigned valid - bit e: entry e's source coordinate of this
+// species is inside the box; unsigned pad }.
 
 template <int S, int NS, int PER>
-__device__ __forceinline__ void box_species(const BoxRegs<NS, PER> &R, const double *tab, int xs, unsigned flags,
-                                            const double *__restrict__ xg, int64_t g, double &dsum, double &acc)
+__device__ __forceinline__ void box_species(const BoxRegs<NS, PER> &R, int xa, int xb, unsigned va, unsigned vb,
+                                            global_bytes_t xw, unsigned voff, double &acca, double &accb)
 {
+    const unsigned lds0 = (unsigned)(size_t)(lds_bytes_t)box_lds;                  // LDS address of the image = of its 0.0
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
-        const unsigned need = R.need[S][j];
-        const bool in = (flags & need) == need;
-        const double a0 = tab[R.off[S][j] + xs];                                      // a_k at x: part of DIAG (StateSpace.f90:207-212)
-        const double a1 = tab[in ? R.off[S][j] + xs - R.nu[S][j] : R.zoff];          // a_k at the source state x - nu_k, or 0
-        const double xv = xg[g + (in ? (int64_t)R.delta[S][j] : 0)];
-        dsum += a0;
-        acc += a1 * xv;
+        const int ma = __builtin_amdgcn_sbfe(va, S * PER + j, 1);                  // -1: source state of row A inside the box
+        const int mb = __builtin_amdgcn_sbfe(vb, S * PER + j, 1);
+        const unsigned ata = lds0 + (unsigned)(8 * xa + R.koff8[S][j]);           // a_k(x - nu_k) ...
+        const unsigned atb = lds0 + (unsigned)(8 * xb + R.koff8[S][j]);
+        const double a1a = *(const __attribute__((address_space(3))) double *)(size_t)((ma & ata) | (~ma & lds0));   // ... or 0
+        const double a1b = *(const __attribute__((address_space(3))) double *)(size_t)((mb & atb) | (~mb & lds0));
+        const unsigned vsrc = voff + (unsigned)R.delta8[S][j];                     // (the same in every trip of the lane)
+        const unsigned at = (unsigned)__builtin_amdgcn_bitop3_b32(ma | mb, (int)vsrc, (int)voff, 0xCA);   // either ? vsrc : voff
+        const box_pair_t xv = *(const __attribute__((address_space(1), aligned(8))) box_pair_t *)(xw + at);
+        acca += a1a * xv.x;
+        accb += a1b * xv.y;
     }
 }
 
 template <int NS, int PER>
-__device__ __forceinline__ double row_box1(const BoxRegs<NS, PER> &R, const double *tab, int c0, int c1, int c2, int c3, int c4,
-                                           int c5, const double *__restrict__ xg, int64_t g)
+__device__ __forceinline__ void box_df(const BoxRegs<NS, PER> &R, int c0, int c1, int c2, int c3, int c4, int c5,
+                                       double &dsum, unsigned &valid)
 {
-    unsigned flags = box_flag4(c0, R.dims[0]);
-    if (NS > 1) flags |= box_flag4(c1, R.dims[NS > 1 ? 1 : 0]) << 4;
-    if (NS > 2) flags |= box_flag4(c2, R.dims[NS > 2 ? 2 : 0]) << 8;
-    if (NS > 3) flags |= box_flag4(c3, R.dims[NS > 3 ? 3 : 0]) << 12;
-    if (NS > 4) flags |= box_flag4(c4, R.dims[NS > 4 ? 4 : 0]) << 16;
-    if (NS > 5) flags |= box_flag4(c5, R.dims[NS > 5 ? 5 : 0]) << 20;
-    const double xd = xg[g];
-    double dsum = 0.0, acc = 0.0;
-    box_species<0, NS, PER>(R, tab, c0, flags, xg, g, dsum, acc);
-    if (NS > 1) box_species<(NS > 1 ? 1 : 0), NS, PER>(R, tab, c1, flags, xg, g, dsum, acc);
-    if (NS > 2) box_species<(NS > 2 ? 2 : 0), NS, PER>(R, tab, c2, flags, xg, g, dsum, acc);
-    if (NS > 3) box_species<(NS > 3 ? 3 : 0), NS, PER>(R, tab, c3, flags, xg, g, dsum, acc);
-    if (NS > 4) box_species<(NS > 4 ? 4 : 0), NS, PER>(R, tab, c4, flags, xg, g, dsum, acc);
-    if (NS > 5) box_species<(NS > 5 ? 5 : 0), NS, PER>(R, tab, c5, flags, xg, g, dsum, acc);
-    return acc - dsum * xd;
+    const lds_bytes_t lds = (lds_bytes_t)box_lds;
+    {
+        const lds_bytes_t f = lds + R.df8[0] + 16 * c0;
+        dsum = *(const __attribute__((address_space(3))) double *)f;
+        valid = *(const __attribute__((address_space(3))) unsigned *)(f + 8);
+    }
+#define KFSP_BOX_DF(S, VAR)                                                                            \
+    if (NS > S) {                                                                                      \
+        const lds_bytes_t f = lds + R.df8[NS > S ? S : 0] + 16 * VAR;                                  \
+        dsum += *(const __attribute__((address_space(3))) double *)f;                                  \
+        valid &= *(const __attribute__((address_space(3))) unsigned *)(f + 8);                         \
+    }
+    KFSP_BOX_DF(1, c1)
+    KFSP_BOX_DF(2, c2)
+    KFSP_BOX_DF(3, c3)
+    KFSP_BOX_DF(4, c4)
+    KFSP_BOX_DF(5, c5)
+#undef KFSP_BOX_DF
 }
 
 template <int NS, int PER>
-__device__ __forceinline__ d2 rows_box1(const BoxRegs<NS, PER> &R, const double *tab, const double *__restrict__ xg,
+__device__ __forceinline__ d2 rows_box1(const BoxRegs<NS, PER> &R, const double *__restrict__ xg,
                                         int64_t row0, int64_t nloc, int64_t c, int lane)
 {
     d2 sum = {0.0, 0.0};
     const int64_t r0 = (c << 7) + 2 * lane;
     if (r0 >= nloc) return sum;
     const int64_t g = row0 + r0;
+    // x of this wave's 128 rows and everything an entry reaches from them: scalar base + unsigned lane offset
+    const uint64_t xb = reinterpret_cast<uint64_t>(xg + (row0 + (c << 7))) - (uint64_t)(int64_t)R.bias8;
+    const global_bytes_t xw = (global_bytes_t)((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)xb) |
+                                               (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(xb >> 32)) << 32);
+    const unsigned voff = (unsigned)(16 * lane + R.bias8);
     // coordinates of row g: successive division by the box dimensions (exact: g < 2^31, one correction step)
     int c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
     uint32_t q = (uint32_t)g;
@@ -455,10 +480,8 @@ __device__ __forceinline__ d2 rows_box1(const BoxRegs<NS, PER> &R, const double 
     KFSP_BOX_DEC(4, c4)
     KFSP_BOX_DEC(5, c5)
 #undef KFSP_BOX_DEC
-    sum.x = row_box1<NS, PER>(R, tab, c0, c1, c2, c3, c4, c5, xg, g);
-    if (r0 + 1 < nloc) {
-        // next row: +1 with carry (the last species never wraps: g + 1 < n)
-        int carry = 1;
+    // the next row: +1 with carry (the last species never wraps while g + 1 < n)
+    int b0 = c0, b1 = c1, b2 = c2, b3 = c3, b4 = c4, b5 = c5, carry = 1;
 #define KFSP_BOX_INC(S, VAR)                                             \
     if (NS > S) {                                                        \
         const int v = VAR + carry;                                       \
@@ -466,15 +489,30 @@ __device__ __forceinline__ d2 rows_box1(const BoxRegs<NS, PER> &R, const double 
         VAR = wrap ? 0 : v;                                              \
         carry = wrap;                                                    \
     }
-        KFSP_BOX_INC(0, c0)
-        KFSP_BOX_INC(1, c1)
-        KFSP_BOX_INC(2, c2)
-        KFSP_BOX_INC(3, c3)
-        KFSP_BOX_INC(4, c4)
-        KFSP_BOX_INC(5, c5)
+    KFSP_BOX_INC(0, b0)
+    KFSP_BOX_INC(1, b1)
+    KFSP_BOX_INC(2, b2)
+    KFSP_BOX_INC(3, b3)
+    KFSP_BOX_INC(4, b4)
+    KFSP_BOX_INC(5, b5)
 #undef KFSP_BOX_INC
-        sum.y = row_box1<NS, PER>(R, tab, c0, c1, c2, c3, c4, c5, xg, g + 1);
-    }
+    const bool two = r0 + 1 < nloc;
+    if (!two) b0 = b1 = b2 = b3 = b4 = b5 = 0;                 // (no such row: any coordinates inside the tables)
+    double dsa, dsb;
+    unsigned va, vb;
+    box_df<NS, PER>(R, c0, c1, c2, c3, c4, c5, dsa, va);
+    box_df<NS, PER>(R, b0, b1, b2, b3, b4, b5, dsb, vb);
+    if (!two) vb = 0u;
+    const box_pair_t xd = *(const __attribute__((address_space(1), aligned(8))) box_pair_t *)(xw + voff);
+    double acca = 0.0, accb = 0.0;
+    box_species<0, NS, PER>(R, c0, b0, va, vb, xw, voff, acca, accb);
+    if (NS > 1) box_species<(NS > 1 ? 1 : 0), NS, PER>(R, c1, b1, va, vb, xw, voff, acca, accb);
+    if (NS > 2) box_species<(NS > 2 ? 2 : 0), NS, PER>(R, c2, b2, va, vb, xw, voff, acca, accb);
+    if (NS > 3) box_species<(NS > 3 ? 3 : 0), NS, PER>(R, c3, b3, va, vb, xw, voff, acca, accb);
+    if (NS > 4) box_species<(NS > 4 ? 4 : 0), NS, PER>(R, c4, b4, va, vb, xw, voff, acca, accb);
+    if (NS > 5) box_species<(NS > 5 ? 5 : 0), NS, PER>(R, c5, b5, va, vb, xw, voff, acca, accb);
+    sum.x = acca - dsa * xd.x;
+    sum.y = two ? accb - dsb * xd.y : 0.0;
     return sum;
 }
 
@@ -486,7 +524,6 @@ __global__ __launch_bounds__(kBlock) void k_spmv(SpmvArgs a)
     constexpr bool DIA = FMT != 0;
     constexpr bool BOX = FMT == 3 || FMT == 4;
     __shared__ double red[12];
-    extern __shared__ double box_lds[];                   // FMT 3: the factor tables
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (MODE != 0) {
@@ -518,7 +555,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv(SpmvArgs a)
     unsigned gm = 0xFFFFFFFFu;                              // group mask of the trip about to be computed
     if (FMT == 2 && c < cend) gm = __builtin_amdgcn_readfirstlane(a.D.gmask[ct]);
     if (c < cend) {
-        if (FMT == 4) sum = rows_box1<(NS ? NS : 1), (NE ? NE : 1)>(boxr, tab, a.xg, a.row0, a.A.nrows, ct, lane);
+        if (FMT == 4) sum = rows_box1<(NS ? NS : 1), (NE ? NE : 1)>(boxr, a.xg, a.row0, a.A.nrows, ct, lane);
         else if (BOX) sum = rows_box<0, 0>(a.B, tab, a.xg, a.row0, a.A.nrows, ct, lane);
         else if (DIA) sum = rows_dia<NT, FMT == 2>(a.D, a.xg, a.row0, ct, lane, gm);
         else sum.x = row_sell<NT>(a.A, a.xg, a.row0, ct, lane);
@@ -577,8 +614,8 @@ __global__ __launch_bounds__(kBlock) void k_spmv(SpmvArgs a)
         c = cn;
         ct = ctn;
         if (c < cend) {
-            if (FMT == 4) sum = rows_box1<(NS ? NS : 1), (NE ? NE : 1)>(boxr, tab, a.xg, a.row0, a.A.nrows, ct, lane);
-        else if (BOX) sum = rows_box<0, 0>(a.B, tab, a.xg, a.row0, a.A.nrows, ct, lane);
+            if (FMT == 4) sum = rows_box1<(NS ? NS : 1), (NE ? NE : 1)>(boxr, a.xg, a.row0, a.A.nrows, ct, lane);
+            else if (BOX) sum = rows_box<0, 0>(a.B, tab, a.xg, a.row0, a.A.nrows, ct, lane);
             else if (DIA) sum = rows_dia<NT, FMT == 2>(a.D, a.xg, a.row0, ct, lane, gm);
             else sum.x = row_sell<NT>(a.A, a.xg, a.row0, ct, lane);
         }
