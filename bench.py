@@ -341,7 +341,7 @@ def main():
             "real_GBps": round(mf_bytes / (mf_ms * 1e-3) / 1e9, 2),
             "speedup_vs_stored": round(kern_ms / mf_ms, 3),
             "self_check": {"ok": bool(mf_err < 1e-12), "max_rel_err": mf_err},
-            "bound": "instruction issue (16 B/state of HBM traffic; the kernel is no longer bandwidth-bound)",
+            "bound": "memory latency / vector-memory issue (16 B/state of HBM traffic, about half of the HBM rate sustained; DESIGN 4.1b)",
         }
 
     # ---------------------------------------------------------------- expv

@@ -12,7 +12,7 @@ boxes = [("c3x", synth.repressilator(216)), ("c3", synth.repressilator(171)), ("
          ("c5s", synth.birth_death((22, 22, 22, 22, 22, 3)))]
 for name, mdl in boxes:
     row = []
-    for grid in (512, 768, 1024, 1280, 1536, 1792, 2048):
+    for grid in (256, 512, 768, 1024, 1536, 2048):
         with KfspContext(0) as c:
             c.set_option("grid_blocks", grid)
             c.set_matrix_box(mdl)
