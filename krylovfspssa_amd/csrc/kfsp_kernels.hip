@@ -174,6 +174,18 @@ __device__ __forceinline__ d2 ld_stream2(const double *p)
 // worth ~9 % of HBM rate over 8 B per lane (profiles/r01_stream_widths.log).
 // x is read as two 8-B loads (shifted by delta, so not 16-B aligned in
 // general; it is served from L2 anyway).
+// x[p], x[p + 1] as ONE 16-byte load (8-byte aligned): a CU issues vector-memory instructions at a fixed rate
+// whatever their width, so two 8-byte gathers cost twice one 16-byte gather.  p is clamped to [-1, n - 1]: the
+// element before x and the one behind it are the guard words / column padding every device buffer carries
+// (DevBuf, vcol): finite, and only ever multiplied by a stored 0.
+typedef double __attribute__((ext_vector_type(2))) xpair_t;
+typedef xpair_t __attribute__((aligned(8))) xpair_u;
+__device__ __forceinline__ xpair_t ld_xpair(const double *__restrict__ xg, int64_t p, int64_t last)
+{
+    p = p < -1 ? -1 : (p > last ? last : p);
+    return *reinterpret_cast<const xpair_u *>(xg + p);
+}
+
 template <bool NT, bool MASKED>
 __device__ __forceinline__ d2 rows_dia(const DiaDev &D, const double *__restrict__ xg, int64_t row0,
                                        int64_t c, int lane, unsigned m)
@@ -186,35 +198,29 @@ __device__ __forceinline__ d2 rows_dia(const DiaDev &D, const double *__restrict
     // m: which diagonals have entries in this group (same for the whole wavefront; the
     // caller fetched it one trip ahead, so no load sits in front of the address arithmetic)
     const d2 dg = ld_stream2<NT>(D.diag + r);
+    const xpair_t xd = ld_xpair(xg, g, last);
     d2 sum;
-    sum.x = -dg.x * xg[g < last ? g : last];
-    sum.y = -dg.y * xg[g + 1 < last ? g + 1 : last];
+    sum.x = -dg.x * xd.x;
+    sum.y = -dg.y * xd.y;
     int d = 0;
     for (; d + 2 <= D.nd; d += 2) {
         const bool on0 = !MASKED || ((m >> d) & 1u), on1 = !MASKED || ((m >> (d + 1)) & 1u);
         // an empty segment costs no HBM traffic: zeros from a cached line, x from the row itself
         const d2 v0 = ld_stream2<NT>(on0 ? vp + (int64_t)(d + 0) * D.ld : zp);
         const d2 v1 = ld_stream2<NT>(on1 ? vp + (int64_t)(d + 1) * D.ld : zp);
-        int64_t i0 = g + (on0 ? D.delta[d + 0] : 0), i1 = g + (on1 ? D.delta[d + 1] : 0);
-        int64_t j0 = i0 + 1, j1 = i1 + 1;
-        i0 = i0 < 0 ? 0 : (i0 > last ? last : i0);
-        j0 = j0 < 0 ? 0 : (j0 > last ? last : j0);
-        i1 = i1 < 0 ? 0 : (i1 > last ? last : i1);
-        j1 = j1 < 0 ? 0 : (j1 > last ? last : j1);
-        sum.x += v0.x * xg[i0];
-        sum.y += v0.y * xg[j0];
-        sum.x += v1.x * xg[i1];
-        sum.y += v1.y * xg[j1];
+        const xpair_t x0 = ld_xpair(xg, g + (on0 ? D.delta[d + 0] : 0), last);
+        const xpair_t x1 = ld_xpair(xg, g + (on1 ? D.delta[d + 1] : 0), last);
+        sum.x += v0.x * x0.x;
+        sum.y += v0.y * x0.y;
+        sum.x += v1.x * x1.x;
+        sum.y += v1.y * x1.y;
     }
     for (; d < D.nd; ++d) {
         const bool on0 = !MASKED || ((m >> d) & 1u);
         const d2 v0 = ld_stream2<NT>(on0 ? vp + (int64_t)d * D.ld : zp);
-        int64_t i0 = g + (on0 ? D.delta[d] : 0);
-        int64_t j0 = i0 + 1;
-        i0 = i0 < 0 ? 0 : (i0 > last ? last : i0);
-        j0 = j0 < 0 ? 0 : (j0 > last ? last : j0);
-        sum.x += v0.x * xg[i0];
-        sum.y += v0.y * xg[j0];
+        const xpair_t x0 = ld_xpair(xg, g + (on0 ? D.delta[d] : 0), last);
+        sum.x += v0.x * x0.x;
+        sum.y += v0.y * x0.y;
     }
     return sum;
 }
