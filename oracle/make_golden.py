@@ -180,7 +180,9 @@ def make_api(tmp):
 
 
 # (fixture, ref_cases workload, number of leading steps whose solution vector is kept)
-LOCKSTEP_CASES = [("toggle_input", "toggle_input", 72), ("toggle_example", "toggle_example", 72)]
+# (fixture name = a SOLVE_CASES entry, ref_cases workload, number of leading steps whose solution vector is kept)
+LOCKSTEP_CASES = [("toggle_input", "toggle_input", 72), ("toggle_example", "toggle_example", 72),
+                  ("repressilator_input_T1", "repressilator_input", 40), ("goutsias_input_T40", "goutsias_input", 60)]
 
 
 def run_trace(case, trace, out, T=None):
@@ -190,15 +192,17 @@ def run_trace(case, trace, out, T=None):
                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, check=True, text=True).stdout
 
 
-def make_lockstep(tmp):
+def make_lockstep(tmp, only=()):
     """G7: the reference's own decisions, state lists and solution vectors step by step
     (oracle/ref_trace_main.f90 + the BLAS observers of oracle/ref_trace.c), for the lock-step
     tests.  The observed run must be bit-identical to the plain one (solve_<name>.npz)."""
     from oracle import lockstep as L
     for name, case, keep in LOCKSTEP_CASES:
+        if only and name not in only:
+            continue
         _, T, fsptol, krytol = SOLVE_CASES[name]
         trace, out = os.path.join(tmp, f"{name}.trace"), os.path.join(tmp, f"{name}.tr.bin")
-        text = run_trace(case, trace, out)
+        text = run_trace(case, trace, out, T)
         plain = np.load(os.path.join(GOLDEN, f"solve_{name}.npz"))
         dout = read_fsp(out)
         assert np.array_equal(dout["state"], plain["state"]) and np.array_equal(dout["vector"], plain["vector"]), \
@@ -329,7 +333,7 @@ def main():
             make_goutsias_T300()
         return
     if sys.argv[1:2] == ["lockstep"]:
-        make_lockstep(tempfile.mkdtemp(prefix="kfsp_golden_"))
+        make_lockstep(tempfile.mkdtemp(prefix="kfsp_golden_"), set(sys.argv[2:]))
         return
     if not os.path.exists(os.path.join(REF_DIR, "ref_dump")):
         sys.exit("oracle/_ref/ref_dump missing: run `make -C oracle` where /root/reference exists")

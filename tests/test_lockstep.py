@@ -39,7 +39,7 @@ def _err_loc(E, m, beta, avnorm):
 # ------------------------------------------------------------------ CPU: why trajectories fork
 
 def test_script_fixtures_are_well_formed():
-    for name in ("toggle_input", "toggle_example"):
+    for name in ("toggle_input", "toggle_example", "repressilator_input_T1", "goutsias_input_T40"):
         g = np.load(os.path.join(GOLDEN, f"lockstep_{name}.npz"))
         s = g["script"]
         assert s.shape[1] == 4 and s[0, 0] == L.BEGIN and s[-1, 0] == L.END
@@ -127,11 +127,11 @@ def replay():
     return REPLAY
 
 
-def _run_replay(replay, tmp_path, name, case, safe):
+def _run_replay(replay, tmp_path, name, case, safe, horizon=None):
     g = np.load(os.path.join(GOLDEN, f"lockstep_{name}.npz"))
     script, steps, out = str(tmp_path / "script.bin"), str(tmp_path / "steps.bin"), str(tmp_path / "out.bin")
     L.write_script(script, g["script"])
-    r = subprocess.run([replay, case, script, steps, out, "-"] + (["safe"] if safe else []), cwd=MODELS,
+    r = subprocess.run([replay, case, script, steps, out, repr(horizon) if horizon else "-"] + (["safe"] if safe else []), cwd=MODELS,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:]
     ev = [e for e in L.read_trace(steps) if e["tag"] in "BF"]
@@ -188,6 +188,36 @@ def test_lock_step_with_the_reference(replay, tmp_path, name, case):
     assert int(tight.sum()) >= 20
     assert l1[tight].max() < 1e-10
     assert np.all(l1 <= 1e-10 + 2.0 * DELTA * krytol * t_at)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,case", [("repressilator_input_T1", "repressilator_input"), ("goutsias_input_T40", "goutsias_input")])
+def test_lock_step_on_three_and_six_species(replay, tmp_path, name, case):
+    """The same on the 3-species repressilator (T = 1: ten steps, FSP 91 -> 27 816 -> 21 559 states)
+    and the 6-species Goutsias model (T = 40: twenty steps, twelve expansions, seven compacting
+    drops, FSP -> 12 214 states): after EVERY step of the whole run the state list is the
+    reference's bit for bit - each list is the product of an SSA expansion on the shared random
+    stream, a one-step sweep and a drop decided on our vector - and the solution agrees to the
+    solver's tolerance."""
+    g, ours, rc, forks, next_ = _run_replay(replay, tmp_path, name, case, safe=True, horizon=float(g_T(name)))
+    krytol = float(g["krytol"])
+    hard = [f for f in forks if f["kind"] in ("UNSAFE_ACCEPT", "BREAKDOWN", "FSP_SIZE", "FSP_TEST")]
+    first_hard = min([f["step"] for f in hard], default=10 ** 9)
+    bad, l1 = _compare(g, ours, upto=first_hard)
+    t_at = g["t_at"][:len(l1)]
+    print(f"{name}: rc={rc} forks={len(forks)} basis extensions={next_} first hard fork at step {first_hard}; "
+          f"compared {len(l1)} of {len(g['n_after'])} steps, state lists equal={bad is None}; max l1 {l1.max():.3e}")
+    assert bad is None, f"state list differs at step {bad}"
+    assert len(l1) == len(g["n_after"])                  # the whole run
+    assert np.all(l1 <= 1e-10 + 2.0 * DELTA * krytol * t_at)
+    from oracle.make_golden import read_fsp
+    final = read_fsp(str(tmp_path / "out.bin"))
+    assert np.array_equal(final["state"], g["final_state"])
+    assert np.abs(final["vector"] - g["final_vector"]).sum() <= 1e-10 + 2.0 * DELTA * krytol * float(g["T"])
+
+
+def g_T(name):
+    return np.load(os.path.join(GOLDEN, f"lockstep_{name}.npz"))["T"]
 
 
 @pytest.mark.gpu
