@@ -461,7 +461,7 @@ void sell_layout(const std::vector<int32_t> &cnt, int64_t nloc, int64_t row0, Ho
         for (int64_t k = 0; k < w; ++k)
             for (int l = 0; l < kChunk; ++l) {
                 const int64_t r = std::min<int64_t>(c * kChunk + l, nloc > 0 ? nloc - 1 : 0);
-                S.col[(size_t)(o + k * kChunk + l)] = (int32_t)(row0 + r);
+                S.col[(size_t)kfsp::sell_pos(o, (int)w, (int)k, l)] = (int32_t)(row0 + r);
             }
     }
     S.diag.assign((size_t)S.nchunks * kChunk, 0.0);
@@ -503,8 +503,9 @@ int maybe_upload_dia(kfsp_ctx *ctx, const HostSell &S, const std::vector<int32_t
     int64_t nnz_off = 0;
     for (int64_t r = 0; r < nloc; ++r) {
         const int64_t c = r / kChunk, l = r % kChunk, o = S.off[(size_t)c];
+        const int w = (int)((S.off[(size_t)c + 1] - o) / kChunk);
         for (int k = 0; k < cnt[(size_t)r]; ++k) {
-            const int64_t dl = (int64_t)S.col[(size_t)(o + (int64_t)k * kChunk + l)] - (row0 + r);
+            const int64_t dl = (int64_t)S.col[(size_t)kfsp::sell_pos(o, w, k, (int)l)] - (row0 + r);
             int d = 0;
             while (d < nd && delta[d] != dl) ++d;
             if (d == nd) {
@@ -522,8 +523,9 @@ int maybe_upload_dia(kfsp_ctx *ctx, const HostSell &S, const std::vector<int32_t
     std::vector<double> val((size_t)nd * (size_t)ld, 0.0);
     for (int64_t r = 0; r < nloc; ++r) {
         const int64_t c = r / kChunk, l = r % kChunk, o = S.off[(size_t)c];
+        const int w = (int)((S.off[(size_t)c + 1] - o) / kChunk);
         for (int k = 0; k < cnt[(size_t)r]; ++k) {
-            const size_t pos = (size_t)(o + (int64_t)k * kChunk + l);
+            const size_t pos = (size_t)kfsp::sell_pos(o, w, k, (int)l);
             const int64_t dl = (int64_t)S.col[pos] - (row0 + r);
             const int d = (int)(std::lower_bound(delta, delta + nd, dl) - delta);
             val[(size_t)d * (size_t)ld + (size_t)r] += S.val[pos];
@@ -838,7 +840,7 @@ static int set_matrix_ell_impl(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld,
                 const int64_t r = k - 1 - row0;
                 if (r < 0 || r >= nloc) continue;
                 const int64_t c = r / kChunk, l = r % kChunk;
-                const int64_t pos = S.off[(size_t)c] + (int64_t)fill[(size_t)r]++ * kChunk + l;
+                const int64_t pos = kfsp::sell_pos(S.off[(size_t)c], (int)((S.off[(size_t)c + 1] - S.off[(size_t)c]) / kChunk), fill[(size_t)r]++, (int)l);
                 S.col[(size_t)pos] = (int32_t)i;
                 S.val[(size_t)pos] = o[j];
                 ++nnz;
@@ -910,7 +912,7 @@ int kfsp_set_matrix_csr(kfsp_ctx *ctx, int64_t n, int64_t row0, int64_t nrows, c
                 if (col[p] == row0 + r) {
                     d += val[p];
                 } else {
-                    const int64_t pos = S.off[(size_t)c] + (int64_t)k++ * kChunk + l;
+                    const int64_t pos = kfsp::sell_pos(S.off[(size_t)c], (int)((S.off[(size_t)c + 1] - S.off[(size_t)c]) / kChunk), k++, (int)l);
                     S.col[(size_t)pos] = col[p];
                     S.val[(size_t)pos] = val[p];
                 }

@@ -289,8 +289,8 @@ __global__ __launch_bounds__(kBlock) void k_sell_init(int64_t nchunks, int64_t n
     const int64_t r = c * kChunk + lane;
     const int64_t rr = r < nloc ? r : (nloc > 0 ? nloc - 1 : 0);
     for (int k = 0; k < w; ++k) {
-        col[o + (int64_t)k * kChunk + lane] = (int32_t)(row0 + rr);
-        val[o + (int64_t)k * kChunk + lane] = 0.0;
+        col[sell_pos(o, w, k, lane)] = (int32_t)(row0 + rr);
+        val[sell_pos(o, w, k, lane)] = 0.0;
     }
     diag_out[r] = r < nloc ? diag_in[row0 + r] : 0.0;
 }
@@ -308,7 +308,8 @@ __global__ __launch_bounds__(kBlock) void k_sell_fill(int64_t n, int bw, int ld,
         const int64_t r = (int64_t)k - 1 - row0;
         if (r < 0 || r >= nloc) continue;
         const int p = atomicAdd(&ticket[r], 1);
-        const int64_t pos = off[r >> 6] + (int64_t)p * kChunk + (r & 63);
+        const int64_t o = off[r >> 6];
+        const int64_t pos = sell_pos(o, (int)((off[(r >> 6) + 1] - o) >> 6), p, (int)(r & 63));
         col[pos] = (int32_t)i;
         val[pos] = offd[i * ld + j];
     }
@@ -326,23 +327,25 @@ __global__ __launch_bounds__(kBlock) void k_sell_sort_rows(int64_t nloc, const i
     if (r >= nloc) return;
     const int m = cnt[r];
     if (m < 2) return;
-    const int64_t base = off[r >> 6] + (r & 63);
+    const int64_t o = off[r >> 6];
+    const int w = (int)((off[(r >> 6) + 1] - o) >> 6);
+    const int l = (int)(r & 63);
     for (int a = 1; a < m; ++a) {                          // insertion sort, m <= #reactions
-        const int32_t ca = col[base + (int64_t)a * kChunk];
-        const double va = val[base + (int64_t)a * kChunk];
+        const int32_t ca = col[sell_pos(o, w, a, l)];
+        const double va = val[sell_pos(o, w, a, l)];
         const int32_t ka = perm ? perm[ca] : ca;
         int b = a - 1;
         while (b >= 0) {
-            const int32_t cb = col[base + (int64_t)b * kChunk];
-            const double vb = val[base + (int64_t)b * kChunk];
+            const int32_t cb = col[sell_pos(o, w, b, l)];
+            const double vb = val[sell_pos(o, w, b, l)];
             const int32_t kb = perm ? perm[cb] : cb;
             if (kb < ka || (kb == ka && vb <= va)) break;
-            col[base + (int64_t)(b + 1) * kChunk] = cb;
-            val[base + (int64_t)(b + 1) * kChunk] = vb;
+            col[sell_pos(o, w, b + 1, l)] = cb;
+            val[sell_pos(o, w, b + 1, l)] = vb;
             --b;
         }
-        col[base + (int64_t)(b + 1) * kChunk] = ca;
-        val[base + (int64_t)(b + 1) * kChunk] = va;
+        col[sell_pos(o, w, b + 1, l)] = ca;
+        val[sell_pos(o, w, b + 1, l)] = va;
     }
 }
 

@@ -22,6 +22,20 @@ constexpr int kMH = kMMax + 2;     // leading dimension of the device H image
 // wavefront reads 64 consecutive int32 / f64 per slot.  The diagonal is kept
 // apart (positive, as DIAG in StateSpace.f90:16) and padded slots carry
 // val = 0 with a valid column.
+// SELL-64 slot layout: the slots of a chunk (width w) go in PAIRS, the two slots of a pair adjacent per
+// lane - slot k of lane l sits at off[c] + (k / 2) * 128 + 2 l + (k & 1) - so that a lane reads the columns
+// of two slots as one 8-byte and their values as one 16-byte load (a CU issues vector-memory instructions
+// at a fixed rate whatever their width); the last slot of an odd width stands alone, 64 entries.  A row's
+// slots stay in FMATVEC's order.
+#if defined(__HIPCC__) || defined(__CUDACC__)
+__host__ __device__
+#endif
+inline int64_t sell_pos(int64_t chunk_off, int w, int k, int lane)
+{
+    if ((w & 1) && k == w - 1) return chunk_off + (int64_t)(w >> 1) * 128 + lane;
+    return chunk_off + (int64_t)(k >> 1) * 128 + 2 * lane + (k & 1);
+}
+
 struct SellDev {
     int64_t nrows;       // local rows
     int64_t nchunks;     // ceil(nrows / 64)

@@ -135,32 +135,8 @@ __device__ __forceinline__ int32_t ld_stream(const int32_t *p)
 // MODE 1: y = s A u ; partial = udot.y      (Arnoldi column, s = 1/||u||)
 // MODE 2: y = s A u ; partial = y.y         (the AVNORM product)
 // MODE 3: y = s A u ; partial = udot.y, partial2 = udot2.y   (IOP(2) column)
-template <bool NT>
-__device__ __forceinline__ double row_sell(const SellDev &A, const double *__restrict__ xg, int64_t row0,
-                                           int64_t c, int lane)
-{
-    const int64_t off = A.off[c];
-    const int w = (int)((A.off[c + 1] - off) >> 6);
-    const int64_t r = (c << 6) + lane;
-    const int32_t *cp = A.col + off + lane;
-    const double *vp = A.val + off + lane;
-    double sum = -ld_stream<NT>(A.diag + r) * xg[row0 + r];
-    int k = 0;
-    for (; k + 4 <= w; k += 4) {
-        const int32_t c0 = ld_stream<NT>(cp + (k + 0) * 64), c1 = ld_stream<NT>(cp + (k + 1) * 64);
-        const int32_t c2 = ld_stream<NT>(cp + (k + 2) * 64), c3 = ld_stream<NT>(cp + (k + 3) * 64);
-        const double v0 = ld_stream<NT>(vp + (k + 0) * 64), v1 = ld_stream<NT>(vp + (k + 1) * 64);
-        const double v2 = ld_stream<NT>(vp + (k + 2) * 64), v3 = ld_stream<NT>(vp + (k + 3) * 64);
-        sum += v0 * xg[c0];
-        sum += v1 * xg[c1];
-        sum += v2 * xg[c2];
-        sum += v3 * xg[c3];
-    }
-    for (; k < w; ++k) sum += ld_stream<NT>(vp + k * 64) * xg[ld_stream<NT>(cp + k * 64)];
-    return sum;
-}
-
 typedef double d2 __attribute__((ext_vector_type(2)));
+typedef int i2 __attribute__((ext_vector_type(2)));
 
 template <bool NT>
 __device__ __forceinline__ d2 ld_stream2(const double *p)
@@ -168,12 +144,49 @@ __device__ __forceinline__ d2 ld_stream2(const double *p)
     if (NT) return __builtin_nontemporal_load(reinterpret_cast<const d2 *>(p));
     return *reinterpret_cast<const d2 *>(p);
 }
+template <bool NT>
+__device__ __forceinline__ i2 ld_stream2(const int32_t *p)
+{
+    if (NT) return __builtin_nontemporal_load(reinterpret_cast<const i2 *>(p));
+    return *reinterpret_cast<const i2 *>(p);
+}
+
+// One SELL row: the slots come in pairs (sell_pos), columns as one 8-byte and values as one 16-byte load
+// per pair, summed slot by slot in FMATVEC's order.
+template <bool NT>
+__device__ __forceinline__ double row_sell(const SellDev &A, const double *__restrict__ xg, int64_t row0,
+                                           int64_t c, int lane)
+{
+    const int64_t off = A.off[c];
+    const int w = (int)((A.off[c + 1] - off) >> 6);
+    const int w2 = w >> 1;                                   // slot pairs; an odd width ends in a single slot
+    const int64_t r = (c << 6) + lane;
+    const int32_t *cp = A.col + off + 2 * lane;
+    const double *vp = A.val + off + 2 * lane;
+    double sum = -ld_stream<NT>(A.diag + r) * xg[row0 + r];
+    int k = 0;
+    for (; k + 2 <= w2; k += 2) {
+        const i2 c0 = ld_stream2<NT>(cp + (k + 0) * 128), c1 = ld_stream2<NT>(cp + (k + 1) * 128);
+        const d2 v0 = ld_stream2<NT>(vp + (k + 0) * 128), v1 = ld_stream2<NT>(vp + (k + 1) * 128);
+        sum += v0.x * xg[c0.x];
+        sum += v0.y * xg[c0.y];
+        sum += v1.x * xg[c1.x];
+        sum += v1.y * xg[c1.y];
+    }
+    if (k < w2) {
+        const i2 c0 = ld_stream2<NT>(cp + k * 128);
+        const d2 v0 = ld_stream2<NT>(vp + k * 128);
+        sum += v0.x * xg[c0.x];
+        sum += v0.y * xg[c0.y];
+    }
+    if (w & 1) sum += ld_stream<NT>(A.val + off + w2 * 128 + lane) * xg[ld_stream<NT>(A.col + off + w2 * 128 + lane)];
+    return sum;
+}
 
 // Banded form, TWO consecutive rows per lane (a wavefront covers 128 rows): the
 // value streams - the bulk of the traffic - are read 16 B per lane, which is
 // worth ~9 % of HBM rate over 8 B per lane (profiles/r01_stream_widths.log).
-// x is read as two 8-B loads (shifted by delta, so not 16-B aligned in
-// general; it is served from L2 anyway).
+// x too is read 16 B per lane and diagonal (ld_xpair: shifted by delta, so 8-B aligned in general).
 // x[p], x[p + 1] as ONE 16-byte load (8-byte aligned): a CU issues vector-memory instructions at a fixed rate
 // whatever their width, so two 8-byte gathers cost twice one 16-byte gather.  p is clamped to [-1, n - 1]: the
 // element before x and the one behind it are the guard words / column padding every device buffer carries
@@ -861,19 +874,16 @@ __device__ __forceinline__ double row_sell_pre(const SellDev &A, const double *x
                                                double dg)
 {
     const int lane = (int)(r & 63);
-    const int32_t *cp = A.col + off + lane;
-    const double *vp = A.val + off + lane;
+    const int32_t *cp = A.col + off + 2 * lane;
+    const double *vp = A.val + off + 2 * lane;
     double sum = -dg * xs[r];
-    int k = 0;
-    for (; k + 4 <= w; k += 4) {
-        const int32_t c0 = cp[(k + 0) * 64], c1 = cp[(k + 1) * 64], c2 = cp[(k + 2) * 64], c3 = cp[(k + 3) * 64];
-        const double v0 = vp[(k + 0) * 64], v1 = vp[(k + 1) * 64], v2 = vp[(k + 2) * 64], v3 = vp[(k + 3) * 64];
-        sum += v0 * xs[c0];
-        sum += v1 * xs[c1];
-        sum += v2 * xs[c2];
-        sum += v3 * xs[c3];
+    for (int k = 0; k < (w >> 1); ++k) {                  // slot pairs (sell_pos)
+        const i2 c0 = *reinterpret_cast<const i2 *>(cp + k * 128);
+        const d2 v0 = *reinterpret_cast<const d2 *>(vp + k * 128);
+        sum += v0.x * xs[c0.x];
+        sum += v0.y * xs[c0.y];
     }
-    for (; k < w; ++k) sum += vp[k * 64] * xs[cp[k * 64]];
+    if (w & 1) sum += A.val[off + (w >> 1) * 128 + lane] * xs[A.col[off + (w >> 1) * 128 + lane]];
     return sum;
 }
 
@@ -882,20 +892,18 @@ __device__ __forceinline__ double row_sell_pre(const SellDev &A, const double *x
 __device__ __forceinline__ double row_sell_lds(const double *vs, const unsigned short *cs, double dg,
                                                const double *xs, int64_t r, int64_t off, int w)
 {
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
     const int lane = (int)(r & 63);
-    const unsigned short *cp = cs + off + lane;
-    const double *vp = vs + off + lane;
+    const unsigned short *cp = cs + off + 2 * lane;
+    const double *vp = vs + off + 2 * lane;
     double sum = -dg * xs[r];
-    int k = 0;
-    for (; k + 4 <= w; k += 4) {
-        const int c0 = cp[(k + 0) * 64], c1 = cp[(k + 1) * 64], c2 = cp[(k + 2) * 64], c3 = cp[(k + 3) * 64];
-        const double v0 = vp[(k + 0) * 64], v1 = vp[(k + 1) * 64], v2 = vp[(k + 2) * 64], v3 = vp[(k + 3) * 64];
-        sum += v0 * xs[c0];
-        sum += v1 * xs[c1];
-        sum += v2 * xs[c2];
-        sum += v3 * xs[c3];
+    for (int k = 0; k < (w >> 1); ++k) {
+        const us2 c0 = *reinterpret_cast<const us2 *>(cp + k * 128);
+        const d2 v0 = *reinterpret_cast<const d2 *>(vp + k * 128);
+        sum += v0.x * xs[c0.x];
+        sum += v0.y * xs[c0.y];
     }
-    for (; k < w; ++k) sum += vp[k * 64] * xs[cp[k * 64]];
+    if (w & 1) sum += vs[off + (w >> 1) * 128 + lane] * xs[cs[off + (w >> 1) * 128 + lane]];
     return sum;
 }
 
