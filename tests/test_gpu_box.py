@@ -107,3 +107,70 @@ def test_bad_boxes_are_rejected():
         big = synth.toggle(4000, 3000)                           # 7000 table entries
         with pytest.raises(KfspError):
             c.set_matrix_box(big)
+
+
+def _random_box(rng, k):
+    """a random reaction network on a random box: 1-6 species, dimensions 1..12 (odd and even, a few
+    ones), 1-4 reactions per factor species, stoichiometry in {-2..2} on up to three species, one
+    propensity factor each (-> the fast path) or, every third model, two factors (-> interpreted)"""
+    from krylovfspssa_amd import synth
+    d = int(rng.integers(1, 7))
+    dims = [int(rng.integers(1, 13)) for _ in range(d)]
+    if np.prod(dims) < 2:
+        dims[0] = 5
+    two = k % 3 == 2 and d >= 2
+    R, stoich, deps, coef = 0, [], [], []
+    for s in range(d):
+        for _ in range(int(rng.integers(0 if d > 1 else 1, 5 if not two else 3))):
+            col = np.zeros(d, dtype=np.int64)
+            for t in rng.choice(d, size=min(d, int(rng.integers(1, 4))), replace=False):
+                col[t] = int(rng.integers(-2, 3))
+            if not col.any():
+                col[s] = 1
+            stoich.append(col)
+            dep = (s, int((s + 1) % d)) if two else (s,)
+            deps.append(dep)
+            coef.append((float(rng.uniform(0.1, 3.0)), int(rng.integers(0, 3))))
+            R += 1
+    if R == 0:
+        stoich, deps, coef, R = [np.eye(d, dtype=np.int64)[0]], [(0,)], [(1.0, 1)], 1
+    if R > 16:
+        stoich, deps, coef, R = stoich[:16], deps[:16], coef[:16], 16
+
+    def prop(r, X):
+        c, kind = coef[r]
+        a = c * np.ones_like(X[deps[r][0]])
+        for s in deps[r]:
+            x = X[s]
+            a = a * (x if kind == 0 else (1.0 + x * x if kind == 1 else 1.0 / (1.0 + 0.1 * x)))
+        return a
+
+    return synth.BoxModel(f"random{k}", dims, np.array(stoich).T, prop, deps=deps)
+
+
+def test_matrix_free_on_random_boxes(oracle):
+    """60 random networks on random boxes (see _random_box): the matrix-free product - fast path
+    where the model allows it, and the interpreted kernel on the same model - against the stored
+    generator and the oracle; one context throughout, so every model also runs on whatever the
+    previous one left in device memory."""
+    from krylovfspssa_amd import KfspContext
+    rng = np.random.default_rng(2024)
+    fast_seen = 0
+    with KfspContext(0) as c, KfspContext(0) as g, KfspContext(0) as b:
+        g.set_option("box_generic", 1)
+        for k in range(60):
+            mdl = _random_box(rng, k)
+            adj, off, diag = mdl.ell()
+            A = oracle.EllMatrix(adj, off, diag)
+            x = rng.standard_normal(mdl.n)
+            yref = oracle.spmv_ell(A, x)
+            scale = oracle.spmv_ell(oracle.EllMatrix(adj, np.abs(off), -np.abs(diag)), np.abs(x))
+            c.set_matrix_box(mdl)
+            g.set_matrix_box(mdl)
+            b.set_matrix_csr(mdl.n, *mdl.csr_rows())
+            ys = [ctx.spmv(x) for ctx in (c, g, b)]
+            for y in ys:
+                assert np.all(np.abs(y - yref) <= 2e-13 * np.abs(scale) + 1e-300), (k, mdl.dims, mdl.stoich.tolist())
+            assert np.array_equal(ys[0], c.spmv(x))                   # deterministic
+            fast_seen += max(len(dp) for dp in mdl.deps) == 1 and int(np.abs(mdl.stoich).max()) <= 2
+    assert fast_seen >= 30
