@@ -174,3 +174,31 @@ def test_matrix_free_on_random_boxes(oracle):
             assert np.array_equal(ys[0], c.spmv(x))                   # deterministic
             fast_seen += max(len(dp) for dp in mdl.deps) == 1 and int(np.abs(mdl.stoich).max()) <= 2
     assert fast_seen >= 30
+
+
+@pytest.mark.parametrize("P", [2, 3])
+def test_matrix_free_random_boxes_with_a_row_partition(oracle, P):
+    """the same random networks cut into P row blocks (loop-back ranks): blocks shorter than the
+    generator's reach (all-gather instead of halo strips), ragged last blocks, empty ranks"""
+    from krylovfspssa_amd import host
+    rng = np.random.default_rng(77 + P)
+    done = 0
+    for k in range(40):
+        mdl = _random_box(rng, k)
+        if mdl.n < 200 or done == 10:
+            continue
+        done += 1
+        adj, off, diag = mdl.ell()
+        A = oracle.EllMatrix(adj, off, diag)
+        x = rng.standard_normal(mdl.n)
+
+        def body(ctx, rank):
+            ctx.set_matrix_box(mdl)
+            r0, nr = ctx.row_block(mdl.n)
+            ctx.set_vector(x[r0:r0 + nr])
+            return ctx.spmv_w()
+
+        y = np.concatenate(host.run_loopback_ranks(P, body))
+        scale = oracle.spmv_ell(oracle.EllMatrix(adj, np.abs(off), -np.abs(diag)), np.abs(x))
+        assert np.all(np.abs(y - oracle.spmv_ell(A, x)) <= 2e-13 * np.abs(scale) + 1e-300), (k, mdl.dims, mdl.stoich.tolist())
+    assert done == 10

@@ -211,3 +211,39 @@ def test_growing_fsp_uploads_only_the_new_propensity_columns(oracle, golden_dir)
         assert not np.all(np.abs(c.spmv(x) - yref) <= 1e-13 * scale)
         c.update_matrix_ell(b["adj"], b["offdiag"], b["diag"], 0)        # everything travels again
         assert np.all(np.abs(c.spmv(x) - yref) <= 1e-13 * scale)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_banded_generators(ctx, seed):
+    """Banded rows with random offsets (odd and even, +-1, some longer than the matrix) and ragged
+    sizes: the banded kernel's paired x gathers at both ends of x (first and last rows, offsets that
+    leave the vector), against numpy; the same rows forced through SELL-64 give the same bits."""
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(130, 5000))
+    nd = int(rng.integers(1, 13))
+    deltas = np.unique(np.concatenate([rng.integers(-n - 5, n + 6, nd), [(-1) ** seed]]))
+    deltas = deltas[deltas != 0]
+    rows = np.arange(n)
+    cols_l, vals_l = [rows], [-(rng.random(n) + 0.5)]
+    for d in deltas:
+        c = rows + d
+        ok = (c >= 0) & (c < n) & (rng.random(n) < 0.9)
+        cols_l.append(np.where(ok, c, -1))
+        vals_l.append(np.where(ok, rng.random(n), 0.0))
+    C, V = np.stack(cols_l, 1), np.stack(vals_l, 1)
+    order = np.argsort(np.where(C < 0, 1 << 40, C), axis=1, kind="stable")
+    C, V = np.take_along_axis(C, order, 1), np.take_along_axis(V, order, 1)
+    valid = C >= 0
+    rowptr = np.concatenate(([0], np.cumsum(valid.sum(1)))).astype(np.int64)
+    col, val = C[valid].astype(np.int32), V[valid]
+    x = rng.standard_normal(n)
+    ref = np.array([val[rowptr[r]:rowptr[r + 1]] @ x[col[rowptr[r]:rowptr[r + 1]]] for r in range(n)])
+    mag = np.array([np.abs(val[rowptr[r]:rowptr[r + 1]]) @ np.abs(x[col[rowptr[r]:rowptr[r + 1]]]) for r in range(n)])
+    out = {}
+    for fmt in (0, 1):
+        ctx.set_option("format", fmt)
+        ctx.set_matrix_csr(n, rowptr, col, val)
+        out[fmt] = ctx.spmv(x)
+        assert np.all(np.abs(out[fmt] - ref) <= 1e-13 * mag + 1e-300)
+    ctx.set_option("format", 0)
+    assert np.array_equal(out[0], out[1])
