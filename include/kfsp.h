@@ -369,7 +369,8 @@ int kfsp_add_timer(kfsp_ctx *ctx, int phase, double ms);
 
 /* tuning knobs (name/value); unknown name -> -2: "grid_blocks",
  * "vec_grid_blocks", "nt_loads", "format", "fused_ortho",
- * "host_build", "halo", "overlap", "small_kernel", "small_lds", "dia_mask", "box_generic" (1: matrix-free boxes take
+ * "host_build", "halo", "halo_p2p" (1: halo strips travel between neighbouring ranks only, ncclSend/ncclRecv straight into the
+ * column margins; 0, default: one all-gather of every rank's strips), "overlap", "small_kernel", "small_lds", "dia_mask", "box_generic" (1: matrix-free boxes take
  * the run-time interpreted kernel even when the single-factor fast path applies), "state_order" (1: use
  * kfsp_set_state_coords, the default; 0: never), "state_order_min" (smallest generator that is
  * reordered, default 32768), "state_order_products" (products the previous

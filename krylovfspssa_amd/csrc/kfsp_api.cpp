@@ -331,11 +331,44 @@ int resize(kfsp_ctx *ctx, int64_t n);
 int exchange_strips(kfsp_ctx *ctx, const double *src_local, hipStream_t st)
 {
     const int64_t H = ctx->halo, L = ctx->L;
+    double *col = const_cast<double *>(src_local);
+    if (ctx->opt_halo_p2p != 0) {
+        // Neighbours only, and straight between the columns: a rank's first H rows go into the margin
+        // behind the previous rank's block, its last H rows into the margin in front of the next rank's.
+        // No staging copies, no strips of ranks that are not neighbours (an all-gather moves
+        // nranks * 2H doubles to every rank for the 2H it needs).
+        const bool up = ctx->rank > 0, down = ctx->rank + 1 < ctx->nranks;
+        if (!ctx->loop) {
+            NCCL_TRY(ncclGroupStart());
+            if (up) {
+                NCCL_TRY(ncclSend(src_local, (size_t)H, ncclDouble, ctx->rank - 1, ctx->comm, st));
+                NCCL_TRY(ncclRecv(col - H, (size_t)H, ncclDouble, ctx->rank - 1, ctx->comm, st));
+            }
+            if (down) {
+                NCCL_TRY(ncclSend(src_local + (L - H), (size_t)H, ncclDouble, ctx->rank + 1, ctx->comm, st));
+                NCCL_TRY(ncclRecv(col + L, (size_t)H, ncclDouble, ctx->rank + 1, ctx->comm, st));
+            }
+            NCCL_TRY(ncclGroupEnd());
+            return 0;
+        }
+        kfsp::LoopGroup *g = ctx->loop;
+        HIP_TRY(hipStreamSynchronize(st));
+        g->slot[(size_t)ctx->rank] = src_local;
+        if (!g->barrier()) return fail(ctx, 2999, "loop-back barrier timed out");
+        if (up)      // the previous rank's LAST rows sit just below row 0
+            HIP_TRY(hipMemcpyAsync(col - H, static_cast<const double *>(g->slot[(size_t)ctx->rank - 1]) + (L - H),
+                                   (size_t)H * sizeof(double), hipMemcpyDefault, st));
+        if (down)    // the next rank's FIRST rows follow row L-1
+            HIP_TRY(hipMemcpyAsync(col + L, static_cast<const double *>(g->slot[(size_t)ctx->rank + 1]),
+                                   (size_t)H * sizeof(double), hipMemcpyDefault, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (!g->barrier()) return fail(ctx, 2999, "loop-back barrier timed out");   // nobody moves on before all have copied
+        return 0;
+    }
     double *send = ctx->d_strip.p, *recv = ctx->d_strip.p + 2 * H;
     HIP_TRY(hipMemcpyAsync(send, src_local, (size_t)H * sizeof(double), hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemcpyAsync(send + H, src_local + (L - H), (size_t)H * sizeof(double), hipMemcpyDeviceToDevice, st));
     if (int rc = comm_allgather(ctx, send, recv, (size_t)(2 * H), st)) return rc;
-    double *col = const_cast<double *>(src_local);
     if (ctx->rank > 0)                 // the previous rank's LAST rows sit just below row 0
         HIP_TRY(hipMemcpyAsync(col - H, recv + (size_t)(ctx->rank - 1) * 2 * H + H, (size_t)H * sizeof(double),
                                hipMemcpyDeviceToDevice, st));
@@ -1768,6 +1801,7 @@ int kfsp_set_option(kfsp_ctx *ctx, const char *name, int64_t value)
     else if (k == "state_order_min") ctx->opt_state_order_min = value;
     else if (k == "state_order_products") ctx->opt_state_order_products = value;
     else if (k == "halo") ctx->opt_halo = value;
+    else if (k == "halo_p2p") ctx->opt_halo_p2p = value;
     else if (k == "overlap") ctx->opt_overlap = value;
     else if (k == "small_kernel") ctx->opt_small = value;
     else return fail(ctx, -2, "unknown option");

@@ -28,7 +28,8 @@ def _models():
     }
 
 
-MODES = {"halo": {}, "halo+split": {"overlap": 2}, "allgather": {"halo": 0}, "sell": {"format": 1}}
+MODES = {"halo": {}, "halo+split": {"overlap": 2}, "strips between neighbours": {"halo_p2p": 1},
+         "strips between neighbours+split": {"halo_p2p": 1, "overlap": 2}, "allgather": {"halo": 0}, "sell": {"format": 1}}
 
 
 @pytest.mark.parametrize("P", [2, 3, 4])
