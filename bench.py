@@ -161,14 +161,18 @@ def main():
     for kv in args.opt:
         k, v = kv.split("=")
         ctx.set_option(k, int(v))
-    if world == 1 and args.force_comm:
-        ctx.comm_init(1, 0, KfspContext.unique_id())
-    if world > 1:
-        idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
-        if rank == 0:
-            idt.copy_(torch.from_numpy(KfspContext.unique_id()))
-        dist.broadcast(idt, 0)
-        ctx.comm_init(world, rank, idt.cpu().numpy())
+    def comm_setup():
+        """(re)create the library's communicator: a fresh unique id from rank 0, broadcast by the launcher"""
+        if world == 1 and args.force_comm:
+            ctx.comm_init(1, 0, KfspContext.unique_id())
+        if world > 1:
+            idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                idt.copy_(torch.from_numpy(KfspContext.unique_id()))
+            dist.broadcast(idt, 0)
+            ctx.comm_init(world, rank, idt.cpu().numpy())
+
+    comm_setup()
 
     # ---------------------------------------------------------------- SpMV
     mdl, desc = spmv_model(args.workload, world)
@@ -179,42 +183,51 @@ def main():
     rowptr, col, val = mdl.csr_rows(row0, nrows)
     t_gen = time.time() - t0
     nnz_global = mdl.nnz()
-    if args.matrix_free:
-        ctx.set_matrix_box(mdl)
-    else:
-        ctx.set_matrix_csr(mdl.n, rowptr, col, val)
     nnz_local = int(rowptr[-1])
     x = np.random.default_rng(12345 + rank).random(nrows)
-    ctx.set_vector(x)
-    ctx.begin_step()                      # source column of the SpMV = x
+
+    def load_generator():
+        if args.matrix_free:
+            ctx.set_matrix_box(mdl)
+        else:
+            ctx.set_matrix_csr(mdl.n, rowptr, col, val)
+        ctx.set_vector(x)
+        ctx.begin_step()                  # source column of the SpMV = x
+
+    load_generator()
     info = ctx.matrix_info()
     b_alg_global = synth.spmv_alg_bytes(nnz_global, mdl.n)
     b_alg_local = synth.spmv_alg_bytes(nnz_local, nrows)
 
+    inject = [int(v) for v in os.environ.get("KFSP_BENCH_INJECT_RAISE", "").split(",") if v]   # (tests: attempts that "raise")
+    attempts = [0]
+
     def product_check():
         """y = A x through the solver's own path (plain launch on one rank; halo strips or
         all-gather with more) against numpy on a sample of this rank's rows.
-        -> worst relative error over all ranks (inf: the product did not run on some rank)."""
+        -> (worst relative error over all ranks, some rank's product raised)"""
         failed = None
+        attempts[0] += 1
         try:
             y = ctx.spmv_w()
+            if attempts[0] in inject:
+                raise RuntimeError("injected failure (KFSP_BENCH_INJECT_RAISE)")
         except RuntimeError as e:
             failed = e
             y = None
-        if world > 1:
-            # a rank whose product raised has left the library's communicator out of step with
-            # the others: no fallback is possible on it - every rank learns of it and stops
+        if world > 1 or args.force_comm:
             if max_over_ranks(1.0 if failed is not None else 0.0) > 0.0:
-                print(f"[bench] rank {rank}: product failed ({failed}); aborting all ranks", file=sys.stderr)
-                sys.exit(3)
+                print(f"[bench] rank {rank}: product failed on some rank ({failed})", file=sys.stderr)
+                return float("inf"), True
+        elif failed is not None:
+            raise failed
+        if world > 1:
             xs = torch.zeros(L, dtype=torch.float64, device="cuda")
             xs[:nrows] = torch.from_numpy(x).cuda()
             xall = torch.zeros(world * L, dtype=torch.float64, device="cuda")
             dist.all_gather_into_tensor(xall, xs)
             xg = xall.cpu().numpy()
         else:
-            if failed is not None:
-                raise failed
             xg = x
         bad = 0.0
         if nrows > 0:
@@ -223,28 +236,31 @@ def main():
             ref = np.array([val[rowptr[r]:rowptr[r + 1]] @ xg[col[rowptr[r]:rowptr[r + 1]]] for r in rows])
             mag = np.array([np.abs(val[rowptr[r]:rowptr[r + 1]]) @ np.abs(xg[col[rowptr[r]:rowptr[r + 1]]]) for r in rows])
             bad = float(np.max(np.abs(y[rows] - ref) / (mag + 1e-300)))
-        return max_over_ranks(bad)
+        return max_over_ranks(bad), False
 
     from krylovfspssa_amd import host as _host
     L = _host.partition(mdl.n, world, rank)[2]
     exchange = "none (single rank)"
-    check_err = product_check()
+    check_err, raised = product_check()
     if world > 1 or args.force_comm:
         exchange = "halo strips (banded generator), overlapped with the interior rows when the block is large"
-        # never report a number from a wrong product: step down to the simpler exchanges
+        # never report a number from a wrong product: step down to the simpler exchanges.  A rank whose
+        # product RAISED has left the library's communicator out of step with the others: every rank
+        # learns of it (the launcher's own process group carries the verdict) and the communicator is
+        # thrown away and made anew before the next mode is tried.
         for opt, label in (("overlap", "halo strips, not overlapped (overlap self-check failed)"),
                            ("halo", "all-gather of the whole vector (halo self-check failed)")):
             if check_err < 1e-12:
                 break
             ctx.set_option(opt, 0)
-            if args.matrix_free:
-                ctx.set_matrix_box(mdl)
-            else:
-                ctx.set_matrix_csr(mdl.n, rowptr, col, val)
-            ctx.set_vector(x)
-            ctx.begin_step()
+            if raised:
+                comm_setup()
+            load_generator()
             exchange = label
-            check_err = product_check()
+            check_err, raised = product_check()
+        if raised:
+            print(f"[bench] rank {rank}: the product raised in every exchange mode; aborting all ranks", file=sys.stderr)
+            sys.exit(3)
     check_ok = check_err < 1e-12
     ctx.set_vector(x)
     ctx.begin_step()
@@ -324,25 +340,30 @@ def main():
         ctx.set_matrix_box(mdl)
         ctx.set_vector(x)
         ctx.begin_step()
-        mf_err = product_check()
-        ctx.set_vector(x)
-        ctx.begin_step()
-        ctx.spmv_bench(max(args.warmup, 1), 0)
-        barrier()
-        mf_ms = max_over_ranks(ctx.spmv_bench(args.steps, 0)) / args.steps
-        barrier()
-        mf_bytes = ctx.matrix_bytes()
-        out["matrix_free"] = {
-            "what": "y = A x of the same workload with NO stored generator: propensity factor tables in LDS, rows rebuilt "
-                    "from the row index (kfsp_set_matrix_box)",
-            "avg_launch_ms": round(mf_ms, 5),
-            "alg_GBps": round(b_alg_local / (mf_ms * 1e-3) / 1e9, 2),
-            "real_bytes_per_launch": mf_bytes,
-            "real_GBps": round(mf_bytes / (mf_ms * 1e-3) / 1e9, 2),
-            "speedup_vs_stored": round(kern_ms / mf_ms, 3),
-            "self_check": {"ok": bool(mf_err < 1e-12), "max_rel_err": mf_err},
-            "bound": "memory latency / vector-memory issue (16 B/state of HBM traffic, about half of the HBM rate sustained; DESIGN 4.1b)",
-        }
+        mf_err, mf_raised = product_check()
+        if mf_raised:
+            # (an extra, not the headline: note it, make the communicator anew, carry on)
+            out["matrix_free"] = {"failed": "the matrix-free product raised on some rank"}
+            comm_setup()
+        else:
+            ctx.set_vector(x)
+            ctx.begin_step()
+            ctx.spmv_bench(max(args.warmup, 1), 0)
+            barrier()
+            mf_ms = max_over_ranks(ctx.spmv_bench(args.steps, 0)) / args.steps
+            barrier()
+            mf_bytes = ctx.matrix_bytes()
+            out["matrix_free"] = {
+                "what": "y = A x of the same workload with NO stored generator: propensity factor tables in LDS, rows rebuilt "
+                        "from the row index (kfsp_set_matrix_box)",
+                "avg_launch_ms": round(mf_ms, 5),
+                "alg_GBps": round(b_alg_local / (mf_ms * 1e-3) / 1e9, 2),
+                "real_bytes_per_launch": mf_bytes,
+                "real_GBps": round(mf_bytes / (mf_ms * 1e-3) / 1e9, 2),
+                "speedup_vs_stored": round(kern_ms / mf_ms, 3),
+                "self_check": {"ok": bool(mf_err < 1e-12), "max_rel_err": mf_err},
+                "bound": "memory latency / vector-memory issue (16 B/state of HBM traffic, about half of the HBM rate sustained; DESIGN 4.1b)",
+            }
 
     # ---------------------------------------------------------------- expv
     if not args.no_expv:

@@ -720,7 +720,9 @@ int kfsp_comm_init(kfsp_ctx *ctx, int nranks, int rank, const void *id_bytes)
     if (nranks > 1 && !id_bytes) return fail(ctx, -4, "null unique id");
     HIP_TRY(hipSetDevice(ctx->device));
     if (ctx->comm) {
-        (void)ncclCommDestroy(ctx->comm);
+        // (abort, not destroy: the usual reason to come here twice is a communicator that returned an
+        // error on some rank, and destroying one of those can wait for ever)
+        (void)ncclCommAbort(ctx->comm);
         ctx->comm = nullptr;
     }
     ctx->loop = nullptr;
