@@ -127,8 +127,8 @@ def replay():
     return REPLAY
 
 
-def _run_replay(replay, tmp_path, name, case, safe, horizon=None):
-    g = np.load(os.path.join(GOLDEN, f"lockstep_{name}.npz"))
+def _run_replay(replay, tmp_path, name, case, safe, horizon=None, prefix="lockstep_"):
+    g = np.load(os.path.join(GOLDEN, f"{prefix}{name}.npz"))
     script, steps, out = str(tmp_path / "script.bin"), str(tmp_path / "steps.bin"), str(tmp_path / "out.bin")
     L.write_script(script, g["script"])
     r = subprocess.run([replay, case, script, steps, out, repr(horizon) if horizon else "-"] + (["safe"] if safe else []), cwd=MODELS,
@@ -214,6 +214,38 @@ def test_lock_step_on_three_and_six_species(replay, tmp_path, name, case):
     final = read_fsp(str(tmp_path / "out.bin"))
     assert np.array_equal(final["state"], g["final_state"])
     assert np.abs(final["vector"] - g["final_vector"]).sum() <= 1e-10 + 2.0 * DELTA * krytol * float(g["T"])
+
+
+@pytest.mark.gpu
+def test_lock_step_on_a_longer_goutsias_run_by_digests(replay, tmp_path):
+    """Goutsias `.input` model to T = 100: 37 steps, FSP -> 90 961 states - lists and vectors too big
+    to keep, so the fixture holds per step a SHA-256 of the reference's state list and eight weighted
+    sums of its solution vector (weights a function of the state's coordinates; the difference of a
+    sum is at most the l1 difference of the vectors).  Same protocol as above: recorded step sizes
+    and dimensions, our arithmetic and state-space code."""
+    from oracle.make_golden import read_fsp, state_sha, state_weights
+    name = "goutsias_input_T100"
+    g, ours, rc, forks, next_ = _run_replay(replay, tmp_path, name, "goutsias_input", safe=True, horizon=100.0,
+                                            prefix="lockstep_digest_")
+    krytol = float(g["krytol"])
+    hard = [f for f in forks if f["kind"] in ("UNSAFE_ACCEPT", "BREAKDOWN", "FSP_SIZE", "FSP_TEST")]
+    first_hard = min([f["step"] for f in hard], default=10 ** 9)
+    nstep = min(len(ours), len(g["n_after"]), first_hard)
+    worst = 0.0
+    for k in range(nstep):
+        b, f = ours[k]
+        assert f["n"] == int(g["n_after"][k]), f"FSP size differs at step {k}"
+        assert np.array_equal(state_sha(f["state"]), g["state_sha"][k]), f"state list differs at step {k}"
+        d = np.abs(b["w"] @ state_weights(f["state"]) - g["proj"][k]).max()
+        worst = max(worst, d)
+        assert d <= 1e-10 + 2.0 * DELTA * krytol * float(g["t_at"][k]), (k, d)
+    print(f"{name}: rc={rc} forks={len(forks)} basis extensions={next_} first hard fork at step {first_hard}; "
+          f"{nstep} of {len(g['n_after'])} steps compared, state lists equal, max projection difference {worst:.3e}")
+    assert nstep >= 30
+    if nstep == len(g["n_after"]) and not hard:
+        final = read_fsp(str(tmp_path / "out.bin"))
+        assert final["n"] == int(g["final_n"]) and np.array_equal(state_sha(final["state"]), g["final_sha"])
+        assert np.abs(final["vector"] @ state_weights(final["state"]) - g["final_proj"]).max() <= 1e-10 + 2.0 * DELTA * krytol * 100.0
 
 
 def g_T(name):
