@@ -85,6 +85,107 @@ def read_trace(path):
     return ev
 
 
+HASH_MULT = np.array([1000003, 998244353, 19260817, 1000000007, 74207281, 433494437, 2971215073, 32452843], dtype=np.int64)
+HASH_M = 2147483647
+
+
+def row_hash(state):
+    """one number < 2^31 per state, from its coordinates only"""
+    return (state.astype(np.int64) * HASH_MULT[:state.shape[1]]).sum(axis=1) % HASH_M
+
+
+def list_hash(state):
+    """order-sensitive checksum of a state list: two sums mod 2^31 - 1 (a Fortran observer can form
+    them too: oracle/replay_main.f90 OBSERVE, digest mode)"""
+    h = row_hash(state)
+    i = np.arange(1, len(h) + 1, dtype=np.int64)
+    a = ((i % 1000003 + 1) * h) % HASH_M
+    b = ((i % 999983 + 7) * ((h * 48271 + 11) % HASH_M)) % HASH_M
+    return np.array([int(a.sum() % HASH_M), int(b.sum() % HASH_M)], dtype=np.int64)
+
+
+def state_weights(state, nproj=8):
+    """nproj pseudo-random weights in [-1, 1] per state, a function of its coordinates only (two runs
+    that list the same states in the same order weigh them alike)"""
+    c = 0.0001 * np.arange(1, nproj + 1) + 1e-9 * np.arange(1, nproj + 1) ** 2
+    return np.cos(np.outer(row_hash(state).astype(np.float64), c))
+
+
+def read_trace_digest(path):
+    """read_trace for traces too big to hold (a run to 10^6 states writes ~50 GB): the file is
+    streamed; a 'B' record keeps, instead of the vector, its eight weighted sums (state_weights of
+    the list in force) and the list's checksum; 'F' keeps nothing but its size; 'S' keeps wsum."""
+    import os
+    ev = []
+    size = os.path.getsize(path)
+    cur, cur_w8, cur_hash = None, None, None
+    pending = None                       # the last 'B' record, its vector not yet digested
+
+    def settle():
+        nonlocal pending
+        if pending is not None:
+            w = pending.pop("w")
+            pending["proj"] = w @ cur_w8
+            pending["list_hash"] = cur_hash
+            pending = None
+
+    with open(path, "rb") as f:
+        def i32():
+            return struct.unpack("<i", f.read(4))[0]
+
+        def f64():
+            return struct.unpack("<d", f.read(8))[0]
+
+        while f.tell() < size:
+            tag = f.read(1).decode()
+            if tag != "F":
+                settle()
+            if tag == "B":
+                n = i32()
+                beta = f64()
+                pending = dict(tag="B", n=n, beta=beta, w=np.fromfile(f, dtype=np.float64, count=n))
+                ev.append(pending)
+            elif tag == "F":
+                ns, nr, n = i32(), i32(), i32()
+                cur = np.fromfile(f, dtype=np.int32, count=ns * n).reshape(n, ns)
+                f.seek(nr * n * 4 + nr * n * 8 + n * 8, 1)
+                cur_w8, cur_hash = state_weights(cur), list_hash(cur)
+                ev.append(dict(tag="F", ns=ns, nr=nr, n=n))
+                settle()
+            elif tag == "P":
+                m, lda = i32(), i32()
+                alpha = f64()
+                ev.append(dict(tag="P", m=m, lda=lda, alpha=alpha,
+                               H=np.fromfile(f, dtype=np.float64, count=m * m).reshape(m, m).T.copy()))
+            elif tag == "G":
+                m = i32()
+                alpha = f64()
+                ev.append(dict(tag="G", m=m, alpha=alpha, a_is_b=i32()))
+            elif tag == "V":
+                ev.append(dict(tag="V", n=i32()))
+            elif tag == "N":
+                n = i32()
+                ev.append(dict(tag="N", n=n, value=f64()))
+            elif tag == "C":
+                n, mx = i32(), i32()
+                beta = f64()
+                ev.append(dict(tag="C", n=n, mx=mx, beta=beta, y=np.fromfile(f, dtype=np.float64, count=mx)))
+            elif tag == "S":
+                n = i32()
+                wsum = f64()
+                f.seek(n * 8, 1)
+                ev.append(dict(tag="S", n=n, wsum=wsum))
+            elif tag == "D":
+                n = i32()
+                beta = f64()
+                h = np.fromfile(f, dtype=np.int64, count=2)
+                ev.append(dict(tag="B", n=n, beta=beta, list_hash=h, proj=np.fromfile(f, dtype=np.float64, count=8)))
+            else:
+                raise ValueError(f"bad tag {tag!r} at {f.tell() - 1}")
+        settle()
+    return ev
+
+
 def pade_calls(ev):
     """Fold the DGEMM/DGESV records of each DGPADM(norm) call (dgpadm.f:100-163: H*H, five Horner
     products, the odd part, DGESV, ns squarings) into one record with the step size recovered
@@ -140,7 +241,7 @@ def build_script(ev, log, t_out, fsptol):
     while i < len(ev):
         e = ev[i]
         assert e["tag"] == "B", e["tag"]
-        w_after.append(e["w"])
+        w_after.append(e["w"] if "w" in e else dict(proj=e["proj"], list_hash=e["list_hash"]))
         n_after.append(e["n"])
         if rows:
             # END of the previous step: size it left behind; T_NEW is filled in below

@@ -232,41 +232,30 @@ def make_lockstep(tmp, only=()):
             make_sensitivity_sample(r, os.path.join(GOLDEN, "lockstep_sample_toggle.npz"))
 
 
-def state_weights(state, nproj=8):
-    """nproj pseudo-random weights in [-1, 1] per state, a function of its coordinates only (so
-    that two runs that list the same states in the same order weigh them alike)"""
-    mult = np.array([1000003, 998244353, 19260817, 1000000007, 74207281, 433494437, 2971215073, 32452843], dtype=np.int64)
-    h = (state.astype(np.int64) * mult[:state.shape[1]]).sum(axis=1) % 2147483647
-    c = 0.0001 * np.arange(1, nproj + 1) + 1e-9 * np.arange(1, nproj + 1) ** 2
-    return np.cos(np.outer(h.astype(np.float64), c))
+from oracle.lockstep import list_hash, state_weights  # noqa: E402  (shared with the tests)
 
 
-def state_sha(state):
-    import hashlib
-    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(state, dtype=np.int32).tobytes()).digest(), dtype=np.uint8)
-
-
-# longer runs whose state lists and vectors are too big to keep: per step a SHA-256 of the state list
-# and eight weighted sums of the solution vector (|difference of a sum| <= l1 difference of the vectors)
-LOCKSTEP_DIGEST_CASES = [("goutsias_input_T100", "goutsias_input", 100.0, 1e-6, 1e-8)]
+# longer runs whose state lists and vectors are too big to keep: per step a checksum of the state list
+# (oracle.lockstep.list_hash) and eight weighted sums of the solution vector (|difference of a sum| <= l1
+# difference of the vectors)
+LOCKSTEP_DIGEST_CASES = [("goutsias_input_T100", "goutsias_input", 100.0, 1e-6, 1e-8),
+                         # the horizon of the reference's own example (N -> 1.03e6; the reference needs ~40 min and
+                         # writes a ~50 GB trace, which is streamed): KFSP_CASE_CAPACITY as for digest_goutsias_input_T300
+                         ("goutsias_input_T300", "goutsias_input", 300.0, 1e-6, 1e-8)]
 
 
 def make_lockstep_digest(tmp, only=()):
     from oracle import lockstep as L
     for name, case, T, fsptol, krytol in LOCKSTEP_DIGEST_CASES:
-        if only and name not in only:
+        if (only and name not in only) or (not only and T > 100.0):
             continue
         trace, out = os.path.join(tmp, f"{name}.trace"), os.path.join(tmp, f"{name}.tr.bin")
+        if T > 100.0:
+            os.environ["KFSP_CASE_CAPACITY"] = "2097169"
         text = run_trace(case, trace, out, T)
         dout = read_fsp(out)
-        r = L.build_script(L.read_trace(trace), parse_log(text), T, fsptol)
-        fsp_at = dict(r["fsps"])
-        cur, shas, projs = None, [], []
-        for k, w in enumerate(r["w_after"]):
-            if k in fsp_at:
-                cur = fsp_at[k]["state"]
-            shas.append(state_sha(cur))
-            projs.append(w @ state_weights(cur))
+        r = L.build_script(L.read_trace_digest(trace), parse_log(text), T, fsptol)
+        os.remove(trace)
         t_now, times = 0.0, [0.0]
         for row in r["script"]:
             if row[0] == L.FSP and row[1] == 0.0:
@@ -275,7 +264,8 @@ def make_lockstep_digest(tmp, only=()):
                 times.append(t_now)
         np.savez_compressed(os.path.join(GOLDEN, f"lockstep_digest_{name}.npz"), T=T, fsptol=fsptol, krytol=krytol,
                             script=r["script"], n_after=r["n_after"], t_at=np.array(times[:len(r["n_after"])]),
-                            state_sha=np.array(shas), proj=np.array(projs), final_sha=state_sha(dout["state"]),
+                            list_hash=np.array([w["list_hash"] for w in r["w_after"]]),
+                            proj=np.array([w["proj"] for w in r["w_after"]]), final_hash=list_hash(dout["state"]),
                             final_proj=dout["vector"] @ state_weights(dout["state"]), final_n=np.int64(dout["n"]))
         print(f"lockstep digest {name}: {len(r['script'])} script rows, {len(r['n_after'])} steps, N -> {dout['n']}")
 

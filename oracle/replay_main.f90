@@ -9,7 +9,7 @@
 ! step in the record layout of oracle/ref_trace.c ('B' / 'F'), so that the test
 ! reads both runs with one reader and compares them step by step.
 !
-! usage:  kfsp_replay <case> <script.bin> <steps.bin> <out.bin> [T] [safe]
+! usage:  kfsp_replay <case> <script.bin> <steps.bin> <out.bin> [T] [safe|-] [digest]
 !         kfsp_replay rkey <model> <out.txt>     COMPUTE_RKEY of our STATESPACE for one of the
 !                                                .input models: one line "sign key" per reaction
 !   script.bin: int64 rows; f64 script(4, rows)
@@ -19,6 +19,7 @@ MODULE REPLAY_OBSERVER
   USE STATESPACE
   IMPLICIT NONE
   INTEGER :: OUT_UNIT = -1, ONS = 0, ONR = 0
+  LOGICAL :: DIGEST = .FALSE.
   INTEGER, ALLOCATABLE :: LAST_STATE(:, :)
 CONTAINS
   SUBROUTINE OBSERVE(NSTEP, T_NOW, BETA, FSP)
@@ -28,6 +29,10 @@ CONTAINS
     INTEGER :: N
     LOGICAL :: SAME
     N = FSP%SIZE
+    IF (DIGEST) THEN
+       CALL WRITE_DIGEST(N, BETA, FSP)
+       RETURN
+    ENDIF
     WRITE(OUT_UNIT) 'B', INT(N, C_INT32_T), BETA, FSP%VECTOR(1:N)
     SAME = .FALSE.
     IF (ALLOCATED(LAST_STATE)) THEN
@@ -42,6 +47,42 @@ CONTAINS
        WRITE(OUT_UNIT) FSP%MATRIX%DIAG(1:N)
     ENDIF
   END SUBROUTINE OBSERVE
+
+  ! digest mode (argument 7 = 'digest'; runs whose lists are too big to write out): record 'D' = size,
+  ! beta, the checksum pair of the state list and eight weighted sums of the vector, formed exactly
+  ! as oracle/lockstep.py list_hash / state_weights form them for the reference's run
+  SUBROUTINE WRITE_DIGEST(N, BETA, FSP)
+    INTEGER, INTENT(IN) :: N
+    DOUBLE PRECISION, INTENT(IN) :: BETA
+    TYPE(FINITE_STATE_PROJECTION), INTENT(IN) :: FSP
+    INTEGER(8), PARAMETER :: MULT(8) = [1000003_8, 998244353_8, 19260817_8, 1000000007_8, 74207281_8, &
+         433494437_8, 2971215073_8, 32452843_8]
+    INTEGER(8), PARAMETER :: M = 2147483647_8
+    INTEGER(8) :: H, A, B, I8
+    DOUBLE PRECISION :: PROJ(8), C(8), X
+    INTEGER :: I, S, J
+    DO J = 1, 8
+       C(J) = 0.0001D0 * DBLE(J) + 1.0D-9 * DBLE(J)**2
+    ENDDO
+    A = 0_8
+    B = 0_8
+    PROJ = 0.0D0
+    DO I = 1, N
+       H = 0_8
+       DO S = 1, ONS
+          H = H + INT(FSP%STATE(S, I), 8) * MULT(S)
+       ENDDO
+       H = MOD(H, M)
+       I8 = INT(I, 8)
+       A = A + MOD((MOD(I8, 1000003_8) + 1_8) * H, M)
+       B = B + MOD((MOD(I8, 999983_8) + 7_8) * MOD(H * 48271_8 + 11_8, M), M)
+       X = DBLE(H)
+       DO J = 1, 8
+          PROJ(J) = PROJ(J) + FSP%VECTOR(I) * COS(X * C(J))
+       ENDDO
+    ENDDO
+    WRITE(OUT_UNIT) 'D', INT(N, C_INT32_T), BETA, MOD(A, M), MOD(B, M), PROJ
+  END SUBROUTINE WRITE_DIGEST
 END MODULE REPLAY_OBSERVER
 
 PROGRAM KFSP_REPLAY_MAIN
@@ -51,7 +92,7 @@ PROGRAM KFSP_REPLAY_MAIN
   USE STATESPACE
   USE KRYLOVSOLVER
   IMPLICIT NONE
-  CHARACTER(LEN=256) :: CASENAME, SCRIPTFILE, STEPFILE, OUTFILE, TARG, SARG
+  CHARACTER(LEN=256) :: CASENAME, SCRIPTFILE, STEPFILE, OUTFILE, TARG, SARG, DARG
   TYPE(CME_MODEL) :: MODEL
   TYPE(FINITE_STATE_PROJECTION) :: FSP_IN, FSP
   DOUBLE PRECISION :: T, FSPTOL, KRYTOL
@@ -65,6 +106,7 @@ PROGRAM KFSP_REPLAY_MAIN
   CALL GET_COMMAND_ARGUMENT(4, OUTFILE)
   CALL GET_COMMAND_ARGUMENT(5, TARG)
   CALL GET_COMMAND_ARGUMENT(6, SARG)
+  CALL GET_COMMAND_ARGUMENT(7, DARG)
   IF (TRIM(CASENAME) == 'rkey') THEN
      CALL DO_RKEY(TRIM(SCRIPTFILE), TRIM(STEPFILE))
      STOP
@@ -73,6 +115,7 @@ PROGRAM KFSP_REPLAY_MAIN
   CALL SETUP_SOLVE_CASE(TRIM(CASENAME), MODEL, FSP_IN, FSP, T, FSPTOL, KRYTOL)
   IF (LEN_TRIM(TARG) > 0 .AND. TRIM(TARG) /= '-') READ(TARG, *) T
   IF (TRIM(SARG) == 'safe') KFSP_REPLAY_SAFE = 1
+  DIGEST = TRIM(DARG) == 'digest'
 
   IF (TRIM(SCRIPTFILE) /= '-') THEN
      OPEN(NEWUNIT=U, FILE=TRIM(SCRIPTFILE), ACCESS='STREAM', FORM='UNFORMATTED', STATUS='OLD')

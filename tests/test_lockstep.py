@@ -216,36 +216,72 @@ def test_lock_step_on_three_and_six_species(replay, tmp_path, name, case):
     assert np.abs(final["vector"] - g["final_vector"]).sum() <= 1e-10 + 2.0 * DELTA * krytol * float(g["T"])
 
 
-@pytest.mark.gpu
-def test_lock_step_on_a_longer_goutsias_run_by_digests(replay, tmp_path):
-    """Goutsias `.input` model to T = 100: 37 steps, FSP -> 90 961 states - lists and vectors too big
-    to keep, so the fixture holds per step a SHA-256 of the reference's state list and eight weighted
-    sums of its solution vector (weights a function of the state's coordinates; the difference of a
-    sum is at most the l1 difference of the vectors).  Same protocol as above: recorded step sizes
-    and dimensions, our arithmetic and state-space code."""
-    from oracle.make_golden import read_fsp, state_sha, state_weights
-    name = "goutsias_input_T100"
-    g, ours, rc, forks, next_ = _run_replay(replay, tmp_path, name, "goutsias_input", safe=True, horizon=100.0,
-                                            prefix="lockstep_digest_")
+def _run_replay_digest(replay, tmp_path, name, case, horizon, env=None):
+    """kfsp_replay in digest mode (its observer writes checksums, not lists) -> fixture, per-step digests"""
+    g = np.load(os.path.join(GOLDEN, f"lockstep_digest_{name}.npz"))
+    script, steps, out = str(tmp_path / "script.bin"), str(tmp_path / "steps.bin"), str(tmp_path / "out.bin")
+    L.write_script(script, g["script"])
+    r = subprocess.run([replay, case, script, steps, out, repr(horizon), "safe", "digest"], cwd=MODELS,
+                       env=dict(os.environ, **(env or {})), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:]
+    ours = [e for e in L.read_trace_digest(steps) if e["tag"] == "B"]
+    rc, nforks, wdiff, next_, forks = L.read_forks(steps + ".forks")
+    return g, ours, rc, forks, next_
+
+
+def _compare_digests(name, g, ours, rc, forks, next_, min_steps):
     krytol = float(g["krytol"])
     hard = [f for f in forks if f["kind"] in ("UNSAFE_ACCEPT", "BREAKDOWN", "FSP_SIZE", "FSP_TEST")]
     first_hard = min([f["step"] for f in hard], default=10 ** 9)
     nstep = min(len(ours), len(g["n_after"]), first_hard)
     worst = 0.0
     for k in range(nstep):
-        b, f = ours[k]
-        assert f["n"] == int(g["n_after"][k]), f"FSP size differs at step {k}"
-        assert np.array_equal(state_sha(f["state"]), g["state_sha"][k]), f"state list differs at step {k}"
-        d = np.abs(b["w"] @ state_weights(f["state"]) - g["proj"][k]).max()
+        assert ours[k]["n"] == int(g["n_after"][k]), f"FSP size differs at step {k}"
+        assert np.array_equal(ours[k]["list_hash"], g["list_hash"][k]), f"state list differs at step {k}"
+        d = np.abs(ours[k]["proj"] - g["proj"][k]).max()
         worst = max(worst, d)
         assert d <= 1e-10 + 2.0 * DELTA * krytol * float(g["t_at"][k]), (k, d)
     print(f"{name}: rc={rc} forks={len(forks)} basis extensions={next_} first hard fork at step {first_hard}; "
-          f"{nstep} of {len(g['n_after'])} steps compared, state lists equal, max projection difference {worst:.3e}")
-    assert nstep >= 30
-    if nstep == len(g["n_after"]) and not hard:
+          f"{nstep} of {len(g['n_after'])} steps compared, state lists equal, max difference of a weighted sum {worst:.3e}")
+    assert nstep >= min_steps
+    return nstep == len(g["n_after"]) and not hard
+
+
+@pytest.mark.gpu
+def test_lock_step_on_a_longer_goutsias_run_by_digests(replay, tmp_path):
+    """Goutsias `.input` model to T = 100: 37 steps, FSP -> 90 961 states - lists and vectors too big
+    to keep, so the fixture holds per step a checksum of the reference's state list (two order-sensitive
+    sums mod 2^31 - 1, oracle.lockstep.list_hash) and eight weighted sums of its solution vector
+    (weights a function of the state's coordinates; the difference of a sum is at most the l1
+    difference of the vectors); our side's observer forms the same numbers.  Same protocol as above:
+    recorded step sizes and dimensions, our arithmetic and state-space code."""
+    from oracle.make_golden import read_fsp
+    name = "goutsias_input_T100"
+    g, ours, rc, forks, next_ = _run_replay_digest(replay, tmp_path, name, "goutsias_input", 100.0)
+    whole = _compare_digests(name, g, ours, rc, forks, next_, min_steps=30)
+    if whole:
         final = read_fsp(str(tmp_path / "out.bin"))
-        assert final["n"] == int(g["final_n"]) and np.array_equal(state_sha(final["state"]), g["final_sha"])
-        assert np.abs(final["vector"] @ state_weights(final["state"]) - g["final_proj"]).max() <= 1e-10 + 2.0 * DELTA * krytol * 100.0
+        assert final["n"] == int(g["final_n"]) and np.array_equal(L.list_hash(final["state"]), g["final_hash"])
+        assert np.abs(final["vector"] @ L.state_weights(final["state"]) - g["final_proj"]).max() <= 1e-10 + 2.0 * DELTA * float(g["krytol"]) * 100.0
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(os.path.join(GOLDEN, "lockstep_digest_goutsias_input_T300.npz")),
+                    reason="fixture not generated (python -m oracle.make_golden lockstep_digest goutsias_input_T300: ~1 h, 50 GB of scratch)")
+def test_lock_step_over_the_full_horizon_of_the_goutsias_example(replay, tmp_path):
+    """The horizon of the reference's own example (examples/transcr6d.f90: T = 300, FSPTOL 1e-6, KRYTOL
+    1e-8; FSP -> 1.03e6 states, ~240 expansions by SSA + one-step sweeps, ~220 drops) in lock step, by
+    digests: the state list after every step must carry the reference's checksum, the weighted sums
+    of the solution must agree to the solver's tolerance."""
+    name = "goutsias_input_T300"
+    g, ours, rc, forks, next_ = _run_replay_digest(replay, tmp_path, name, "goutsias_input", 300.0,
+                                                   env={"KFSP_CASE_CAPACITY": "2097169"})
+    whole = _compare_digests(name, g, ours, rc, forks, next_, min_steps=100)
+    if whole:
+        from oracle.make_golden import read_fsp
+        final = read_fsp(str(tmp_path / "out.bin"))
+        assert final["n"] == int(g["final_n"]) and np.array_equal(L.list_hash(final["state"]), g["final_hash"])
+        assert np.abs(final["vector"] @ L.state_weights(final["state"]) - g["final_proj"]).max() <= 1e-10 + 2.0 * DELTA * float(g["krytol"]) * 300.0
 
 
 def g_T(name):
