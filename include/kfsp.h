@@ -332,7 +332,9 @@ typedef struct {
                                Krylov step that fails THIS run's error test (OMEGA > DELTA), keep the
                                recorded step size but enlarge the basis by the run's own rule until the
                                test passes (m < M_MAX), so that no error the record does not have is
-                               injected and the two runs stay comparable step by step */
+                               injected and the two runs stay comparable step by step; 2 = the same, and
+                               return 21 at the first step that leaves a state list of another size than
+                               the record's (KFSP_FORK_FSP_SIZE): beyond it the record describes another problem */
     int32_t n_safe_extensions;   /* out: how often that happened */
 } kfsp_replay;
 int kfsp_dgexpv_replay(kfsp_ctx *ctx, double t, double fsptol, double krytol, int n_reactions,

@@ -520,8 +520,15 @@ int dgexpv_impl(kfsp_ctx *ctx, double t, double fsptol, double krytol, int n_rea
         // bookkeeping for the next step  :537-548
         if ((rc = kfsp_num_states(ctx, &S.n))) return rc;
         S.nnz = (int64_t)(n_reactions + 1) * S.n;
-        if (rp && n_expected >= 0 && n_expected != S.n)
+        if (rp && n_expected >= 0 && n_expected != S.n) {
             ls.fork(st.nstep, KFSP_FORK_FSP_SIZE, (double)S.n, 0.0, (double)n_expected, 0.0, 0.0, 0.0);
+            if (rp->safe == 2) {
+                // the state lists have parted: from here on the record describes another problem
+                st.t_now = S.sgn * t_now;
+                if (stats) *stats = st;
+                return 21;
+            }
+        }
         if ((rc = kfsp_begin_step(ctx, &beta))) return rc;     // BETA = ||w||  :540 (and v1 of the next step)
         first_begin_done = true;
         emit(KFSP_EV_READY, {(double)st.nstep, t_now, beta, (double)S.n});

@@ -9,7 +9,7 @@
 ! step in the record layout of oracle/ref_trace.c ('B' / 'F'), so that the test
 ! reads both runs with one reader and compares them step by step.
 !
-! usage:  kfsp_replay <case> <script.bin> <steps.bin> <out.bin> [T] [safe|-] [digest]
+! usage:  kfsp_replay <case> <script.bin> <steps.bin> <out.bin> [T] [safe|safestop|-] [digest]
 !         kfsp_replay rkey <model> <out.txt>     COMPUTE_RKEY of our STATESPACE for one of the
 !                                                .input models: one line "sign key" per reaction
 !   script.bin: int64 rows; f64 script(4, rows)
@@ -67,6 +67,7 @@ CONTAINS
     A = 0_8
     B = 0_8
     PROJ = 0.0D0
+    !$OMP PARALLEL DO SCHEDULE(STATIC) PRIVATE(H, S, I8, X, J) REDUCTION(+:A, B, PROJ) IF(N > 20000)
     DO I = 1, N
        H = 0_8
        DO S = 1, ONS
@@ -81,6 +82,7 @@ CONTAINS
           PROJ(J) = PROJ(J) + FSP%VECTOR(I) * COS(X * C(J))
        ENDDO
     ENDDO
+    !$OMP END PARALLEL DO
     WRITE(OUT_UNIT) 'D', INT(N, C_INT32_T), BETA, MOD(A, M), MOD(B, M), PROJ
   END SUBROUTINE WRITE_DIGEST
 END MODULE REPLAY_OBSERVER
@@ -115,6 +117,7 @@ PROGRAM KFSP_REPLAY_MAIN
   CALL SETUP_SOLVE_CASE(TRIM(CASENAME), MODEL, FSP_IN, FSP, T, FSPTOL, KRYTOL)
   IF (LEN_TRIM(TARG) > 0 .AND. TRIM(TARG) /= '-') READ(TARG, *) T
   IF (TRIM(SARG) == 'safe') KFSP_REPLAY_SAFE = 1
+  IF (TRIM(SARG) == 'safestop') KFSP_REPLAY_SAFE = 2     ! ... and stop where the state lists part
   DIGEST = TRIM(DARG) == 'digest'
 
   IF (TRIM(SCRIPTFILE) /= '-') THEN
