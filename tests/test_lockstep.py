@@ -254,6 +254,15 @@ def _compare_digests(name, g, ours, rc, forks, next_, min_steps):
 
 
 @pytest.mark.gpu
+def test_lock_step_on_a_longer_repressilator_run_by_digests(replay, tmp_path):
+    """repressilator `.input` model to T = 3 (18 steps, FSP -> 52 361 states), by digests as below"""
+    name = "repressilator_input_T3"
+    g, ours, rc, forks, next_ = _run_replay_digest(replay, tmp_path, name, "repressilator_input", 3.0,
+                                                   env={"KFSP_CASE_CAPACITY": "2097169"})
+    _compare_digests(name, g, ours, rc, forks, next_, min_steps=12)
+
+
+@pytest.mark.gpu
 def test_lock_step_on_a_longer_goutsias_run_by_digests(replay, tmp_path):
     """Goutsias `.input` model to T = 100: 37 steps, FSP -> 90 961 states - lists and vectors too big
     to keep, so the fixture holds per step a checksum of the reference's state list (two order-sensitive
