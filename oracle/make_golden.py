@@ -239,7 +239,7 @@ from oracle.lockstep import list_hash, state_weights  # noqa: E402  (shared with
 # (oracle.lockstep.list_hash) and eight weighted sums of the solution vector (|difference of a sum| <= l1
 # difference of the vectors)
 LOCKSTEP_DIGEST_CASES = [("goutsias_input_T100", "goutsias_input", 100.0, 1e-6, 1e-8),
-                         ("repressilator_input_T3", "repressilator_input", 3.0, 1e-4, 1e-10),
+                         ("repressilator_input_T10", "repressilator_input", 10.0, 1e-4, 1e-10),
                          # the horizon of the reference's own example (N -> 1.03e6; the reference needs ~40 min and
                          # writes a ~50 GB trace, which is streamed): KFSP_CASE_CAPACITY as for digest_goutsias_input_T300
                          ("goutsias_input_T300", "goutsias_input", 300.0, 1e-6, 1e-8)]
@@ -251,7 +251,7 @@ def make_lockstep_digest(tmp, only=()):
         if (only and name not in only) or (not only and T > 100.0):
             continue
         trace, out = os.path.join(tmp, f"{name}.trace"), os.path.join(tmp, f"{name}.tr.bin")
-        os.environ["KFSP_CASE_CAPACITY"] = "2097169"
+        os.environ["KFSP_CASE_CAPACITY"] = "4194319"
         text = run_trace(case, trace, out, T)
         dout = read_fsp(out)
         r = L.build_script(L.read_trace_digest(trace), parse_log(text), T, fsptol)

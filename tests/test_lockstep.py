@@ -255,11 +255,12 @@ def _compare_digests(name, g, ours, rc, forks, next_, min_steps):
 
 @pytest.mark.gpu
 def test_lock_step_on_a_longer_repressilator_run_by_digests(replay, tmp_path):
-    """repressilator `.input` model to T = 3 (18 steps, FSP -> 52 361 states), by digests as below"""
-    name = "repressilator_input_T3"
-    g, ours, rc, forks, next_ = _run_replay_digest(replay, tmp_path, name, "repressilator_input", 3.0,
-                                                   env={"KFSP_CASE_CAPACITY": "2097169"})
-    _compare_digests(name, g, ours, rc, forks, next_, min_steps=12)
+    """repressilator `.input` model to T = 10 (the horizon of the workload in oracle/ref_cases.f90: 41 steps,
+    FSP -> 105 229 states), by digests as below"""
+    name = "repressilator_input_T10"
+    g, ours, rc, forks, next_ = _run_replay_digest(replay, tmp_path, name, "repressilator_input", 10.0,
+                                                   env={"KFSP_CASE_CAPACITY": "4194319"})
+    _compare_digests(name, g, ours, rc, forks, next_, min_steps=19)
 
 
 @pytest.mark.gpu
@@ -294,7 +295,7 @@ def test_lock_step_over_the_full_horizon_of_the_goutsias_example(replay, tmp_pat
     carries the reference's checksum."""
     name = "goutsias_input_T300"
     g, ours, rc, forks, next_ = _run_replay_digest(replay, tmp_path, name, "goutsias_input", 300.0,
-                                                   env={"KFSP_CASE_CAPACITY": "2097169"})
+                                                   env={"KFSP_CASE_CAPACITY": "4194319"})
     whole = _compare_digests(name, g, ours, rc, forks, next_, min_steps=30)
     if whole:
         from oracle.make_golden import read_fsp
