@@ -376,7 +376,8 @@ int kfsp_add_timer(kfsp_ctx *ctx, int phase, double ms);
  * the run-time interpreted kernel even when the single-factor fast path applies), "state_order" (1: use
  * kfsp_set_state_coords, the default; 0: never), "state_order_min" (smallest generator that is
  * reordered, default 32768), "state_order_products" (products the previous
- * generator must have seen, default 48) ... see DESIGN.md */
+ * generator must have seen, default 48), "sell_sigma" (rows per window in which the internal order puts the longest
+ * rows first, >= 128; default 0: plain lexicographic order) ... see DESIGN.md */
 int kfsp_set_option(kfsp_ctx *ctx, const char *name, int64_t value);
 
 #ifdef __cplusplus

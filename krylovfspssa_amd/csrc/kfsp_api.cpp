@@ -1804,6 +1804,7 @@ int kfsp_set_option(kfsp_ctx *ctx, const char *name, int64_t value)
     else if (k == "state_order_products") ctx->opt_state_order_products = value;
     else if (k == "halo") ctx->opt_halo = value;
     else if (k == "halo_p2p") ctx->opt_halo_p2p = value;
+    else if (k == "sell_sigma") ctx->opt_sell_sigma = value;
     else if (k == "overlap") ctx->opt_overlap = value;
     else if (k == "small_kernel") ctx->opt_small = value;
     else return fail(ctx, -2, "unknown option");

@@ -239,6 +239,8 @@ struct kfsp_ctx {
     int64_t opt_format = 0; // 0 auto (DIA when banded), 1 always SELL
     int64_t opt_fused = 1;  // 1: one-pass IOP(2) orthogonalisation (k_ortho2)
     int64_t opt_halo = 1;         // 0: always all-gather the whole source vector
+    int64_t opt_sell_sigma = 0;           // rows per window of the SELL-sigma sort under the internal state order (0: off, the default:
+                                          // measured slower - what it saves in padding it loses in gather coalescing)
     int64_t opt_halo_p2p = 0;     // 1: a rank exchanges its strips with its two neighbours only (send/recv); 0: all-gather of all strips
     int64_t opt_small = 1;        // 1: one-launch Arnoldi pass for <= 16384 rows
     int64_t opt_overlap = 1;      // 0: exchange and product strictly one after the other

@@ -16,11 +16,12 @@ with open(sys.argv[1], "rb") as f:
     diag = np.fromfile(f, dtype=np.float64, count=n)
     state = np.fromfile(f, dtype=np.int32, count=ns * n).reshape(n, ns)
 x = np.random.default_rng(12345).random(n)
-for order in (1, 0):
+for order, sigma in ((1, 0), (1, 128), (1, 256), (1, 512), (1, 1024), (0, 0)):
     row = []
-    for grid in (512, 1024, 1536, 2048):
+    for grid in (1024,):
         with KfspContext(0) as c:
             c.set_option("grid_blocks", grid)
+            c.set_option("sell_sigma", sigma)
             c.set_option("state_order", order)
             c.set_option("state_order_products", 0)
             if order:
@@ -28,6 +29,7 @@ for order in (1, 0):
             c.set_matrix_ell(adj, off, diag)
             c.set_vector(x)
             c.begin_step()
+            slots = c.matrix_info()["slots"]
             c.spmv_bench(20)
             row.append((grid, round(1e3 * min(c.spmv_bench(200) for _ in range(3)) / 200, 2)))
-    print("internal order" if order else "discovery order", n, "us per launch:", row, flush=True)
+    print(("internal order, sigma %d" % sigma) if order else "discovery order", n, "us per launch:", row, "slots", slots, flush=True)

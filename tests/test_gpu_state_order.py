@@ -144,3 +144,31 @@ def test_shuffled_box(oracle):
         assert np.all(np.abs(c.spmv(x) - oracle.spmv_ell(A, x)) <= 1e-13 * scale)
     finally:
         c.close()
+
+
+def test_sell_sigma_windows_keep_the_product_bit_identical(golden_dir):
+    """option sell_sigma: inside windows of sigma rows of the internal order the longest rows first -
+    fewer padded slots, the same bits in every row of the product (rows are still summed in the
+    caller's column order) and through the vector transfers"""
+    import os
+    from krylovfspssa_amd import KfspContext
+    g = np.load(os.path.join(golden_dir, "assembly_goutsias_k16.npz"))
+    n = int(g["n"])
+    x = np.random.default_rng(3).random(n)
+    out = {}
+    for sigma in (0, 128, 256):
+        with KfspContext(0) as c:
+            c.set_option("state_order", 1)
+            c.set_option("state_order_min", 1)
+            c.set_option("state_order_products", 0)
+            c.set_option("small_kernel", 0)
+            c.set_option("sell_sigma", sigma)
+            c.set_state_coords(g["state"])
+            c.set_matrix_ell(g["adj"], g["offdiag"], g["diag"])
+            assert c.state_order_active()
+            c.set_vector(x)
+            c.begin_step()
+            out[sigma] = (c.spmv_w(), c.matrix_info()["slots"], c.get_vector())
+    assert np.array_equal(out[0][0], out[128][0]) and np.array_equal(out[0][0], out[256][0])
+    assert np.array_equal(out[0][2], x) and np.array_equal(out[256][2], x)
+    assert out[256][1] < out[128][1] < out[0][1]
