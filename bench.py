@@ -19,10 +19,15 @@ GPU; rank 0's JSON line is relayed.  Under torch.distributed.run it joins the ra
 
 The same JSON line carries
   roofline      the SpMV kernel against the HBM roofline (HIP events on the
-                library's own stream, measured over the timed region): `frac` is the
-                SURVEY 8(d) figure (CSR algorithmic bytes / time / peak); `frac_traffic` the
-                same with the bytes the kernel's own layout moves (the banded form stores no
-                column indices, so this is the physically meaningful fraction)
+                library's own stream, measured over the timed region): `achieved` / `frac`
+                count the bytes that really cross the HBM interface per launch - the
+                kernel's own layout (kfsp_matrix_bytes) or the rocprofv3 PMC traffic
+                where that is larger - so frac <= 1 by construction; `alg_GBps` /
+                `frac_alg_csr` keep the SURVEY 8(d) CSR model (what `value` reports),
+                which the banded form does not move (it stores no column indices)
+  spmv_1e7      (default run) the same product at 10^7 states per GPU - the size of the
+                60 % target: c3x = repressilator box 216^3, generator written out ON THE
+                DEVICE from the propensity tables, stored and matrix-free, same fields
   self_check    the product that is timed, checked in this process against numpy on sampled
                 rows of every rank (always, also on one GPU)
   expv          the exp(tA)v half of the metric: BASELINE configs[1] (toggle box
@@ -30,6 +35,9 @@ The same JSON line carries
                 time per step and its l1 error against the CPU path
   cpu_baseline  the oracle (plain-C port of the reference loops) on this host,
                 1 core, on a bounded sample of the same workload
+--workload c5 is BASELINE configs[4] at its stated size (22^6 = 1.13e8 states, 1.41e9 nnz):
+the whole generator on however many ranks there are, each rank's rows written out by its
+own device (no host arrays of that size exist); "scaling": "strong".
 Inputs are synthetic and resident in HBM before the timed region starts.
 """
 import argparse
@@ -52,7 +60,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c3x", "c4", "c5s", "tiny"])
+    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c3x", "c4", "c5s", "c5", "tiny"])
+    ap.add_argument("--device-build", action="store_true",
+                    help="box workloads: the stored generator is written out by the device from the propensity tables "
+                         "(kfsp_set_matrix_box, option box_store) instead of uploading gather rows made by numpy; always on for c5")
+    ap.add_argument("--no-1e7", action="store_true", help="skip the spmv_1e7 block (c3x, 10^7 states per GPU) of the default run")
     ap.add_argument("--variant", type=int, default=0, choices=[0, 2], help="SpMV kernel variant (0 auto: DIA/SELL, 2 SELL-64)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-expv", action="store_true")
@@ -80,21 +92,32 @@ def spmv_model(workload, nranks):
         # of the slowest species per rank, i.e. 22^5 x 24 = 1.24e8 states on 8 GPUs
         return (synth.birth_death((22, 22, 22, 22, 22, 3 * nranks)),
                 "synthetic 6-species birth-death network, box 22^5 x (3*ranks) (1.55e7 states per GPU)")
+    if workload == "c5":
+        # BASELINE config 5 as stated: the whole 22^6 box (1.13e8 states, 1.41e9 nonzeros), row-partitioned over
+        # however many ranks there are (strong scaling; on one GPU the whole generator is resident: 10.9 GB stored)
+        return (synth.birth_death((22,) * 6),
+                "synthetic 6-species birth-death network, box 22^6 = 113 379 904 states, 12 reactions, rows partitioned over the ranks")
     if workload == "c2":
         return synth.toggle(1000, 1000 * nranks), "toggle_model.input propensities, box 1000x(1000*ranks)"
     return synth.repressilator(dims=(40, 40, 40 * nranks)), "tiny repressilator box 40x40x(40*ranks)"
 
 
-def spawn_ranks(nranks, argv, script=None, env=None, popen=None):
+def spawn_ranks(nranks, argv, script=None, env=None, popen=None, deadline_s=None, poll_s=0.2):
     """Start `nranks` copies of this script as child processes, one per GPU (RANK / LOCAL_RANK /
     WORLD_SIZE / MASTER_ADDR / MASTER_PORT in their environment, as torch.distributed.run would
-    set them), wait for all, relay rank 0's stdout (the JSON line).  The parent never touches the
-    GPU and never exec()s.  -> exit code (0 only if every rank succeeded)."""
+    set them), relay rank 0's stdout (the JSON line).  The parent never touches the GPU and never
+    exec()s.  All children are polled together: the first one that exits non-zero - or the overall
+    deadline (KFSP_BENCH_DEADLINE_S, default 1500 s) - ends the job at once; the others, which would
+    otherwise sit in the rendezvous or a collective waiting for it for ever, are terminated (then
+    killed), and the failing rank is named.  -> exit code (0 only if every rank succeeded)."""
     import socket
     import subprocess
+    import tempfile
     popen = popen or subprocess.Popen
     script = script or os.path.abspath(__file__)
     base = dict(os.environ if env is None else env)
+    if deadline_s is None:
+        deadline_s = float(base.get("KFSP_BENCH_DEADLINE_S", "1500"))
     if "MASTER_PORT" not in base:
         with socket.socket() as s:
             s.bind(("127.0.0.1", 0))
@@ -102,19 +125,48 @@ def spawn_ranks(nranks, argv, script=None, env=None, popen=None):
     base.setdefault("MASTER_ADDR", "127.0.0.1")
     base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     procs = []
-    for r in range(nranks):
-        e = dict(base, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nranks), LOCAL_WORLD_SIZE=str(nranks))
-        procs.append(popen([sys.executable, script] + list(argv), env=e,
-                           stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    if out0:
-        sys.stdout.write(out0.decode() if isinstance(out0, bytes) else out0)
+    # rank 0's stdout goes to a file, not a pipe: nothing has to drain it while all ranks are polled
+    with tempfile.TemporaryFile() as out0:
+        for r in range(nranks):
+            e = dict(base, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nranks), LOCAL_WORLD_SIZE=str(nranks))
+            procs.append(popen([sys.executable, script] + list(argv), env=e,
+                               stdout=out0 if r == 0 else subprocess.DEVNULL))
+        t_end = time.monotonic() + deadline_s
+        codes = [None] * nranks
+        why = None
+        while True:
+            for r, p in enumerate(procs):
+                if codes[r] is None:
+                    codes[r] = p.poll()
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                why = f"ranks failed: {bad}"
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.monotonic() > t_end:
+                why = f"deadline of {deadline_s:.0f} s passed; still running: {[r for r, c in enumerate(codes) if c is None]}"
+                break
+            time.sleep(poll_s)
+        if why is not None:
+            # fresh children of this process, by their own handles (never by pattern)
+            alive = [p for r, p in enumerate(procs) if codes[r] is None]
+            for p in alive:
+                p.terminate()
+            t_kill = time.monotonic() + 5.0
+            for p in alive:
+                try:
+                    p.wait(timeout=max(0.1, t_kill - time.monotonic()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+            print(f"[bench] {why}" + (f"; terminated {len(alive)} other rank(s)" if alive else ""), file=sys.stderr)
+            return 1
+        out0.seek(0)
+        text = out0.read()
+    if text:
+        sys.stdout.write(text.decode())
         sys.stdout.flush()
-    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
-    if bad:
-        print(f"[bench] ranks failed: {bad}", file=sys.stderr)
-        return 1
     return 0
 
 
@@ -179,21 +231,44 @@ def main():
     if mdl is None:
         sys.exit(f"workload {args.workload} is defined for one GPU")
     row0, nrows = ctx.row_block(mdl.n)
+    device_build = (args.device_build or args.workload == "c5") and hasattr(mdl, "rows_at") and not args.matrix_free
     t0 = time.time()
-    rowptr, col, val = mdl.csr_rows(row0, nrows)
+    if device_build or args.matrix_free and hasattr(mdl, "rows_at"):
+        rowptr = col = val = None                     # no host arrays of the size of the FSP at all
+        nnz_local = mdl.nnz() if world == 1 else mdl.nnz_rows(row0, nrows)
+    else:
+        rowptr, col, val = mdl.csr_rows(row0, nrows)
+        nnz_local = int(rowptr[-1])
     t_gen = time.time() - t0
     nnz_global = mdl.nnz()
-    nnz_local = int(rowptr[-1])
     x = np.random.default_rng(12345 + rank).random(nrows)
+
+    def sampled_rows(model, r0, nr, csr, xg, k=2048):
+        """(local rows, A x there, |A||x| there) in numpy: from the uploaded gather rows, or - when there are none -
+        from the model itself at those states"""
+        rows = np.unique(np.concatenate([np.arange(min(nr, 256)), np.arange(max(nr - 256, 0), nr),
+                                         np.random.default_rng(7).integers(0, nr, k)]))
+        if csr is not None:
+            rp, cc, vv = csr
+            ref = np.array([vv[rp[r]:rp[r + 1]] @ xg[cc[rp[r]:rp[r + 1]]] for r in rows])
+            mag = np.array([np.abs(vv[rp[r]:rp[r + 1]]) @ np.abs(xg[cc[rp[r]:rp[r + 1]]]) for r in rows])
+            return rows, ref, mag
+        cols, vals = model.rows_at(r0 + rows)
+        xs = xg[np.where(cols != np.iinfo(np.int64).max, cols, 0)]
+        return rows, (vals * xs).sum(axis=1), (np.abs(vals) * np.abs(xs)).sum(axis=1)
 
     def load_generator():
         if args.matrix_free:
-            ctx.set_matrix_box(mdl)
+            ctx.set_matrix_box(mdl, store=False)
+        elif device_build:
+            ctx.set_matrix_box(mdl, store=True)
         else:
             ctx.set_matrix_csr(mdl.n, rowptr, col, val)
         ctx.set_vector(x)
         ctx.begin_step()                  # source column of the SpMV = x
 
+    if args.workload == "c5":
+        ctx.set_option("m_max", 30)       # 33 basis columns instead of 105 (0.9 GB each at 1.13e8 states)
     load_generator()
     info = ctx.matrix_info()
     b_alg_global = synth.spmv_alg_bytes(nnz_global, mdl.n)
@@ -202,10 +277,25 @@ def main():
     inject = [int(v) for v in os.environ.get("KFSP_BENCH_INJECT_RAISE", "").split(",") if v]   # (tests: attempts that "raise")
     attempts = [0]
 
-    def product_check():
+    def gathered(xloc, Lblk, nloc):
+        """the whole source vector as every rank's kernel sees it (global index of row k of rank p = p L + k)"""
+        if world == 1:
+            return xloc
+        xs = torch.zeros(Lblk, dtype=torch.float64, device="cuda")
+        xs[:nloc] = torch.from_numpy(xloc).cuda()
+        xall = torch.zeros(world * Lblk, dtype=torch.float64, device="cuda")
+        dist.all_gather_into_tensor(xall, xs)
+        return xall.cpu().numpy()
+
+    def product_check(model=None, r0=None, nr=None, csr="main", xloc=None):
         """y = A x through the solver's own path (plain launch on one rank; halo strips or
         all-gather with more) against numpy on a sample of this rank's rows.
         -> (worst relative error over all ranks, some rank's product raised)"""
+        model = mdl if model is None else model
+        r0, nr = (row0, nrows) if r0 is None else (r0, nr)
+        if csr == "main":
+            csr = None if rowptr is None else (rowptr, col, val)
+        xloc = x if xloc is None else xloc
         failed = None
         attempts[0] += 1
         try:
@@ -221,25 +311,14 @@ def main():
                 return float("inf"), True
         elif failed is not None:
             raise failed
-        if world > 1:
-            xs = torch.zeros(L, dtype=torch.float64, device="cuda")
-            xs[:nrows] = torch.from_numpy(x).cuda()
-            xall = torch.zeros(world * L, dtype=torch.float64, device="cuda")
-            dist.all_gather_into_tensor(xall, xs)
-            xg = xall.cpu().numpy()
-        else:
-            xg = x
+        xg = gathered(xloc, _host.partition(model.n, world, rank)[2], nr)
         bad = 0.0
-        if nrows > 0:
-            rows = np.unique(np.concatenate([np.arange(min(nrows, 256)), np.arange(max(nrows - 256, 0), nrows),
-                                             np.random.default_rng(7).integers(0, nrows, 2048)]))
-            ref = np.array([val[rowptr[r]:rowptr[r + 1]] @ xg[col[rowptr[r]:rowptr[r + 1]]] for r in rows])
-            mag = np.array([np.abs(val[rowptr[r]:rowptr[r + 1]]) @ np.abs(xg[col[rowptr[r]:rowptr[r + 1]]]) for r in rows])
+        if nr > 0:
+            rows, ref, mag = sampled_rows(model, r0, nr, csr, xg)
             bad = float(np.max(np.abs(y[rows] - ref) / (mag + 1e-300)))
         return max_over_ranks(bad), False
 
     from krylovfspssa_amd import host as _host
-    L = _host.partition(mdl.n, world, rank)[2]
     exchange = "none (single rank)"
     check_err, raised = product_check()
     if world > 1 or args.force_comm:
@@ -274,22 +353,52 @@ def main():
     ms_events = max_over_ranks(ms_events)
     value = args.steps * b_alg_global / elapsed / 1e9
     kern_ms = ms_events / args.steps
-    achieved = b_alg_local / (kern_ms * 1e-3) / 1e9
 
-    # bytes the kernel's own layout moves per launch (kfsp_matrix_bytes) and, when this run is the
-    # profiled configuration, the HBM bytes rocprofv3 counted for it (profiles/, NOT this run)
-    real_bytes = ctx.matrix_bytes(force_sell=(args.variant == 2))
-    traffic, traffic_src = None, None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     plain_run = world == 1 and not args.opt and not args.force_comm and args.variant in (0, 2) and not args.matrix_free
-    if plain_run and os.path.exists(tpath):
+
+    def pmc_traffic(key):
+        """HBM bytes per launch rocprofv3 counted for this workload (profiles/, NOT this run), or None"""
+        if not (plain_run and os.path.exists(tpath)):
+            return None, None
         try:
-            key = args.workload + ("_sell64" if args.variant == 2 else "")
-            traffic = json.load(open(tpath)).get(key, {}).get("hbm_bytes_per_launch")
-            if traffic is not None:
-                traffic_src = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, not this run)"
+            t = json.load(open(tpath)).get(key, {}).get("hbm_bytes_per_launch")
         except Exception:
-            traffic = None
+            t = None
+        return t, (None if t is None else
+                   "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, not this run)")
+
+    def roofline(ms, alg_bytes, real_bytes, traffic, traffic_src, kernel="k_spmv"):
+        """The kernel against the HBM roofline.  `achieved` / `frac` count the bytes that really cross the HBM
+        interface per launch - max(the layout's own byte count, the PMC-measured traffic) - so the fraction can
+        not exceed 1; the SURVEY 8(d) CSR-model rate is kept beside it as alg_GBps (the banded and matrix-free forms
+        store no column indices, so that model overstates what they move)."""
+        moved = max(real_bytes, traffic or 0)
+        sec = ms * 1e-3
+        return {
+            "bound": "hbm", "achieved": round(moved / sec / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(moved / sec / 1e9 / HBM_PEAK_GBS, 4),
+            "traffic": traffic, "traffic_source": traffic_src,
+            "kernel": kernel, "avg_launch_ms": round(ms, 5),
+            "bytes_counted": "max(real_bytes_per_launch, traffic)",
+            "real_bytes_per_launch": int(real_bytes),
+            "real_GBps": round(real_bytes / sec / 1e9, 2),
+            "frac_traffic": round(real_bytes / sec / 1e9 / HBM_PEAK_GBS, 4),
+            "alg_bytes_per_launch": int(alg_bytes),
+            "alg_GBps": round(alg_bytes / sec / 1e9, 2),
+            "frac_alg_csr": round(alg_bytes / sec / 1e9 / HBM_PEAK_GBS, 4),
+        }
+
+    # bytes the kernel's own layout moves per launch (kfsp_matrix_bytes) and, when this run is the
+    # profiled configuration, the HBM bytes rocprofv3 counted for it
+    real_bytes = ctx.matrix_bytes(force_sell=(args.variant == 2))
+    traffic, traffic_src = pmc_traffic(args.workload + ("_sell64" if args.variant == 2 else ""))
+    roof = roofline(kern_ms, b_alg_local, real_bytes, traffic, traffic_src)
+    roof["note"] = ("achieved/frac: bytes that cross the HBM interface per launch (the layout's own count: generator as stored + "
+                    "24 B/row, or the rocprofv3 PMC traffic where it is larger) / HIP-event time of the timed launches / 8 TB/s. "
+                    "alg_GBps / frac_alg_csr: the SURVEY 8(d) CSR model (12 nnz + 20 N) over the same time - the figure `value` "
+                    "reports; it may exceed the peak because the banded kernel stores no column indices"
+                    + ("; the time includes the exchange of the source vector" if world > 1 else ""))
 
     out = {
         "metric": "cme_generator_spmv_GBps",
@@ -300,7 +409,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 5),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if args.workload == "c5" else "weak",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
@@ -308,28 +417,18 @@ def main():
             "workload": f"{args.workload}: {desc}; generator SpMV y=A x (FMATVEC) per step",
             "states_per_gpu": int(nrows), "states_total": int(mdl.n),
             "nnz_total": int(nnz_global), "alg_bytes_per_launch_total": int(b_alg_global),
+            "value_is": "SURVEY 8(d) algorithmic bytes (12 nnz + 20 N) of the whole job / wall time of the timed launches",
             "partition": f"rows x{world}" if world > 1 else "single GPU",
             "exchange": exchange,
             "kernel_variant": "matrix-free box (no stored generator; factor tables in LDS)" if args.matrix_free else
                               {0: "auto (banded DIA when the rows allow it, else SELL-64)", 2: "sell64"}[args.variant],
+            "generator_built": "on the device from the propensity tables (kfsp_set_matrix_box, box_store)" if device_build else
+                               ("nothing stored" if args.matrix_free else "gather rows made by numpy, uploaded (kfsp_set_matrix_csr)"),
             "stored_slots_local": info["slots"],
         },
         "self_check": {"ok": bool(check_ok), "max_rel_err": check_err,
                        "what": "the timed product (same context, same exchange) vs numpy on 2.5k sampled rows per rank"},
-        "roofline": {
-            "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-            "kernel": "k_spmv", "avg_launch_ms": round(kern_ms, 5),
-            "alg_bytes_per_launch": int(b_alg_local),
-            "real_bytes_per_launch": real_bytes,
-            "real_GBps": round(real_bytes / (kern_ms * 1e-3) / 1e9, 2),
-            "frac_traffic": round(real_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            "note": "achieved/frac: per-GPU algorithmic bytes (CSR figure 12 nnz + 20 N, SURVEY 8d) / HIP-event time of "
-                    "the timed launches.  The banded kernel stores no column indices, so it moves fewer bytes than "
-                    "that: real_bytes_per_launch is the layout's own byte count (generator as stored + 24 B/row), "
-                    "frac_traffic = real_GBps / peak is the fraction of HBM bandwidth actually sustained"
-                    + ("; includes the exchange of the source vector" if world > 1 else ""),
-        },
+        "roofline": roof,
         "input_generation_s": round(t_gen, 2),
     }
 
@@ -337,7 +436,7 @@ def main():
     # (box workloads with separable propensities: no stored generator, kfsp_set_matrix_box; reported
     # next to the headline number, which stays the stored generator every FSP can use)
     if not args.matrix_free and getattr(mdl, "deps", None) is not None and args.variant == 0:
-        ctx.set_matrix_box(mdl)
+        ctx.set_matrix_box(mdl, store=False)
         ctx.set_vector(x)
         ctx.begin_step()
         mf_err, mf_raised = product_check()
@@ -362,11 +461,43 @@ def main():
                 "real_GBps": round(mf_bytes / (mf_ms * 1e-3) / 1e9, 2),
                 "speedup_vs_stored": round(kern_ms / mf_ms, 3),
                 "self_check": {"ok": bool(mf_err < 1e-12), "max_rel_err": mf_err},
-                "bound": "memory latency / vector-memory issue (16 B/state of HBM traffic, about half of the HBM rate sustained; DESIGN 4.1b)",
+                "frac": round(mf_bytes / (mf_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "bound": "memory latency / vector-memory issue (16 B/state of HBM traffic; DESIGN 4.1b)",
             }
+
+    # ------------------------------------------- the 10^7-state product (the size of the 60 % target)
+    # c3x: repressilator box 216 x 216 x (216 * ranks), 1.0e7 states per GPU, built on the device from the
+    # propensity tables (no host arrays), stored (banded) and matrix-free, both byte counts
+    if args.workload == "c3" and not args.no_1e7 and not args.matrix_free and args.variant == 0:
+        big, _ = spmv_model("c3x", world)
+        br0, bnr = ctx.row_block(big.n)
+        xb = np.random.default_rng(54321 + rank).random(bnr)
+        blk = {"workload": f"c3x: repressilator_model.input propensities, box 216x216x(216*ranks), {bnr} states per GPU, "
+                           "stored generator written out on the device (box_store)"}
+        for label, store in (("stored", True), ("matrix_free", False)):
+            ctx.set_matrix_box(big, store=store)
+            ctx.set_vector(xb)
+            ctx.begin_step()
+            e7, r7 = product_check(big, br0, bnr, None, xb)
+            if r7:
+                blk[label] = {"failed": "the product raised on some rank"}
+                comm_setup()
+                continue
+            ctx.set_vector(xb)
+            ctx.begin_step()
+            ctx.spmv_bench(max(args.warmup, 1), 0)
+            barrier()
+            ms7 = max_over_ranks(ctx.spmv_bench(args.steps, 0)) / args.steps
+            barrier()
+            nnz7 = big.nnz() if world == 1 else big.nnz_rows(br0, bnr)
+            t7, t7src = pmc_traffic("c3x") if store else (None, None)
+            blk[label] = roofline(ms7, synth.spmv_alg_bytes(nnz7, bnr), ctx.matrix_bytes(), t7, t7src)
+            blk[label]["self_check"] = {"ok": bool(e7 < 1e-12), "max_rel_err": e7}
+        out["spmv_1e7"] = blk
 
     # ---------------------------------------------------------------- expv
     if not args.no_expv:
+        ctx.set_option("m_max", 100)
         tg = synth.toggle(1000, 1000 * world) if args.workload != "tiny" else synth.toggle(100, 80 * world)
         r0, nr = ctx.row_block(tg.n)
         rp, cc, vv = tg.csr_rows(r0, nr)
@@ -395,7 +526,7 @@ def main():
         }
         if not args.matrix_free:
             # the same recipe on the matrix-free form of the same box
-            ctx.set_matrix_box(tg)
+            ctx.set_matrix_box(tg, store=False)
             ctx.set_vector(p0[r0:r0 + nr])
             ctx.expv_fixed(m, tau, 1)
             ctx.set_vector(p0[r0:r0 + nr])
@@ -414,9 +545,14 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu:
         from oracle import oracle as O
         O.lib()
-        adj, off, diag = mdl.ell()
+        cpu_mdl, cpu_what = mdl, f"the same {args.workload} matrix"
+        if args.workload == "c5":
+            # bounded sample: the per-GPU slab of the same network (22^5 x 3 = 1.55e7 states, 1.9e8 nonzeros)
+            cpu_mdl, cpu_what = synth.birth_death((22, 22, 22, 22, 22, 3)), "the 22^5 x 3 slab of the same network (c5s)"
+        adj, off, diag = cpu_mdl.ell()
         A = O.EllMatrix(adj, off, diag)
-        xc = np.random.default_rng(12345).random(mdl.n)
+        xc = np.random.default_rng(12345).random(cpu_mdl.n)
+        b_cpu = synth.spmv_alg_bytes(cpu_mdl.nnz(), cpu_mdl.n)
         O.spmv_ell(A, xc)
         reps = 0
         t0 = time.perf_counter()
@@ -426,11 +562,11 @@ def main():
             dt = time.perf_counter() - t0
             if dt > 12.0 or reps >= 400:
                 break
-        cpu_gbs = reps * b_alg_global / dt / 1e9
+        cpu_gbs = reps * b_cpu / dt / 1e9
         out["cpu_baseline"] = {
             "value": round(cpu_gbs, 3), "unit": "GB/s", "cores": 1, "kind": "port",
-            "sample": f"{reps} scatter-form SpMVs (KrylovSolver.f90:593-606 loop order) on the same {args.workload} "
-                      f"matrix, {dt:.1f} s, 1 of {os.cpu_count()} host cores",
+            "sample": f"{reps} scatter-form SpMVs (KrylovSolver.f90:593-606 loop order) on {cpu_what}, "
+                      f"{dt:.1f} s, 1 of {os.cpu_count()} host cores",
             "ms_per_spmv": round(dt / reps * 1e3, 3),
         }
         del A, adj, off, diag

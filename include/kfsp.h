@@ -125,7 +125,10 @@ int kfsp_set_matrix_csr(kfsp_ctx *ctx, int64_t n, int64_t row0, int64_t nrows,
  *   tables       the factors, concatenated reaction by reaction, factor by factor; factor (k, i) has
  *                dims[dep_species[k][i]] entries (a constant propensity is one table of equal entries)
  * Works with a communicator like a banded generator (halo strips).  ns <= 8, nr <= 16, every reaction
- * changes <= 3 species, all tables together <= 6000 entries. */
+ * changes <= 3 species, all tables together <= 6000 entries.
+ * Option "box_store" = 1: the same call WRITES THE GENERATOR OUT on the device as stored diagonals (the banded
+ * form kfsp_set_matrix_csr would build from the gather rows of this box - with one factor per propensity the
+ * very same entries) - a stored generator of any size without host arrays of that size. */
 int kfsp_set_matrix_box(kfsp_ctx *ctx, int32_t ns, const int32_t *dims, int32_t nr, const int32_t *stoich,
                         const int32_t *ndep, const int32_t *dep_species, const double *tables);
 /* what the device holds: rows (local), stored off-diagonal slots incl. padding,
@@ -362,9 +365,10 @@ int kfsp_selftest_stream(kfsp_ctx *ctx, int64_t nbytes, int elem_bytes, int reps
  * the last reset: Arnoldi passes (product + orthogonalisation kernels and the
  * copy of H), combine calls, begin_step calls, host Pade, generator uploads
  * (host->device copy + device build), time spent inside the drop / expand
- * callbacks of kfsp_dgexpv. */
+ * callbacks of kfsp_dgexpv, and - a part of the callbacks' time when they use it -
+ * the device work of kfsp_onestep incl. its copies. */
 enum { KFSP_T_ARNOLDI = 0, KFSP_T_COMBINE = 1, KFSP_T_BEGIN = 2, KFSP_T_CALLBACKS = 3,
-       KFSP_T_HOST_PADE = 4, KFSP_T_UPLOAD = 5, KFSP_T_COUNT = 6 };
+       KFSP_T_HOST_PADE = 4, KFSP_T_UPLOAD = 5, KFSP_T_ONESTEP = 6, KFSP_T_COUNT = 7 };
 int kfsp_get_timers(kfsp_ctx *ctx, double *ms /* [KFSP_T_COUNT] */, int reset);
 /* add ms to a phase (used by kfsp_dgexpv, which is a client of this ABI) */
 int kfsp_add_timer(kfsp_ctx *ctx, int phase, double ms);
@@ -372,7 +376,9 @@ int kfsp_add_timer(kfsp_ctx *ctx, int phase, double ms);
 /* tuning knobs (name/value); unknown name -> -2: "grid_blocks",
  * "vec_grid_blocks", "nt_loads", "format", "fused_ortho",
  * "host_build", "halo", "halo_p2p" (1: halo strips travel between neighbouring ranks only, ncclSend/ncclRecv straight into the
- * column margins; 0, default: one all-gather of every rank's strips), "overlap", "small_kernel", "small_lds", "dia_mask", "box_generic" (1: matrix-free boxes take
+ * column margins; 0, default: one all-gather of every rank's strips), "overlap", "small_kernel", "small_lds", "dia_mask", "m_max" (largest Krylov dimension the basis is allocated for, default and maximum 100 = M_MAX of
+ * KrylovSolver.f90:47; a smaller value saves 8 * rows bytes per column - 90 GB at 10^8 states - and makes kfsp_arnoldi refuse
+ * a larger m; kfsp_dgexpv needs the default), "box_store" (1: kfsp_set_matrix_box stores the generator as diagonals), "box_generic" (1: matrix-free boxes take
  * the run-time interpreted kernel even when the single-factor fast path applies), "state_order" (1: use
  * kfsp_set_state_coords, the default; 0: never), "state_order_min" (smallest generator that is
  * reordered, default 32768), "state_order_products" (products the previous

@@ -24,6 +24,17 @@ def _hipcc():
     raise RuntimeError("hipcc not found (ROCm toolchain required; there is no CPU build of this library)")
 
 
+def _objects():
+    return [(os.path.join(CSRC, s), os.path.join(LIBDIR, "obj", s.rsplit(".", 1)[0] + ".o")) for s in SOURCES]
+
+
+def _obj_stale(src, obj):
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    return any(os.path.getmtime(d) > t for d in [src] + [os.path.join(CSRC, h) for h in HEADERS])
+
+
 def stale():
     if not os.path.exists(LIB):
         return True
@@ -33,12 +44,24 @@ def stale():
 
 
 def build_lib(force=False, verbose=False):
+    """One object per source (only the stale ones are recompiled, in parallel), then one link."""
     if not force and not stale():
         return LIB
-    os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [_hipcc(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
-           "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES] + \
-          ["-I/opt/rocm/include", "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+    os.makedirs(os.path.join(LIBDIR, "obj"), exist_ok=True)
+    cc = _hipcc()
+    jobs = []
+    for src, obj in _objects():
+        if force or _obj_stale(src, obj):
+            cmd = [cc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-c", src, "-o", obj, "-I/opt/rocm/include",
+                   "-Wno-ignored-attributes"]
+            if verbose:
+                print(" ".join(cmd))
+            jobs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in jobs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    cmd = [cc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB] + [o for _, o in _objects()] + \
+          ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

@@ -431,7 +431,8 @@ int setup_exchange(kfsp_ctx *ctx)
 }
 
 // (Re)size everything that depends on the number of states.
-constexpr int kNumCols = kMMax + 3;   // M_MAX + 2 basis columns and one scratch column
+// M_MAX + 2 basis columns and one scratch column (option m_max caps it: at 10^8 states 105 columns are 90 GB)
+inline int num_cols(const kfsp_ctx *c) { return (int)c->opt_mmax + 3; }
 
 // column j (0-based) of the basis: `margin` halo rows sit on either side of it
 inline double *vcol(const kfsp_ctx *c, int j) { return c->d_V.p + (size_t)j * (size_t)c->ldv + (size_t)c->margin; }
@@ -452,13 +453,14 @@ int resize(kfsp_ctx *ctx, int64_t n)
     int64_t ldv = ctx->ldv;
     if (need > ctx->ldv || ctx->relayout) {
         if (ctx->w_pending) return fail(ctx, -2, "the FSP grew between kfsp_drop_compact and the next generator");
-        ldv = ctx->relayout ? need : round_up(need + need / 2, 256);
+        // (head room: half as much again, but no more than 2^24 rows - at 10^8 states 50 % would be 70 GB)
+        ldv = ctx->relayout ? need : round_up(need + std::min<int64_t>(need / 2, (int64_t)1 << 24), 256);
         ctx->relayout = false;
-        HIP_TRY(ctx->d_V.reserve((size_t)ldv * kNumCols, false));
+        HIP_TRY(ctx->d_V.reserve((size_t)ldv * num_cols(ctx), false));
         HIP_TRY(ctx->d_w.reserve((size_t)ldv, false));
         HIP_TRY(ctx->d_tmp.reserve((size_t)ldv, false));
         ctx->ldv = ldv;
-        HIP_TRY(hipMemsetAsync(ctx->d_V.p, 0, (size_t)ldv * kNumCols * sizeof(double), ctx->stream));
+        HIP_TRY(hipMemsetAsync(ctx->d_V.p, 0, (size_t)ldv * num_cols(ctx) * sizeof(double), ctx->stream));
         HIP_TRY(hipMemsetAsync(ctx->d_w.p, 0, (size_t)ldv * sizeof(double), ctx->stream));
         HIP_TRY(hipMemsetAsync(ctx->d_tmp.p, 0, (size_t)ldv * sizeof(double), ctx->stream));
     }
@@ -773,7 +775,7 @@ int kfsp_comm_init_loopback(kfsp_ctx *ctx, void *group, int rank)
     if (rank < 0 || rank >= g->n) return fail(ctx, -3, "rank out of range");
     HIP_TRY(hipSetDevice(ctx->device));
     if (ctx->comm) {
-        (void)ncclCommDestroy(ctx->comm);
+        (void)ncclCommAbort(ctx->comm);   // as kfsp_comm_init: destroying a failed communicator can wait for ever
         ctx->comm = nullptr;
     }
     ctx->loop = g;
@@ -1143,6 +1145,15 @@ int kfsp_set_matrix_box(kfsp_ctx *ctx, int32_t ns, const int32_t *dims, int32_t 
         for (int p = 0; p < nr; ++p) ctx->delta[p] = B.delta[p];
         ctx->dia_ld = round_up(ctx->nchunks * kChunk, 2 * kChunk);
         HIP_TRY(ctx->d_diag.reserve((size_t)ctx->dia_ld + 2 * kChunk, true));
+        if (ctx->opt_box_store) {
+            // the same generator as STORED diagonals, written by the device from the tables: from here on an
+            // ordinary banded generator (no host arrays of the size of the FSP ever exist)
+            if (int rc = kfsp::box_materialize(ctx)) return rc;
+            ctx->use_box = false;
+            ctx->box_fast = false;
+            ctx->box_lds_bytes = 0;
+            if (int rc = kfsp::build_dia_mask(ctx)) return rc;
+        }
         if (int rc = setup_exchange(ctx)) return rc;
         if (int rc = adopt_pending_vector(ctx)) return rc;
         ctx->t_ms[KFSP_T_UPLOAD] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -1282,6 +1293,7 @@ int kfsp_arnoldi(kfsp_ctx *ctx, int m, int jold, int qiop, double break_tol, dou
     // m >= n is legal: the reference only caps M at N-1 when a step starts (:211),
     // a dimension change (:404) may exceed it and runs into a breakdown instead
     if (m < 1 || m > kMMax) return fail(ctx, -2, "bad m (need 1 <= m <= 100)");
+    if (m > ctx->opt_mmax) return fail(ctx, -2, "m exceeds option m_max (the basis was allocated for fewer columns)");
     if (jold < 1 || jold > kMMax) return fail(ctx, -3, "bad jold");
     if (qiop < 0) return fail(ctx, -4, "bad qiop");
     if (!H) return fail(ctx, -6, "null H");
@@ -1442,7 +1454,7 @@ int kfsp_combine(kfsp_ctx *ctx, int mx, double beta, const double *y, double *ws
 {
     if (!ctx) return -1;
     if (ctx->ldv == 0) return fail(ctx, -1, "no matrix set");
-    if (mx < 1 || mx > kMMax + 2) return fail(ctx, -2, "bad mx");
+    if (mx < 1 || mx > ctx->opt_mmax + 2) return fail(ctx, -2, "bad mx");
     if (!y) return fail(ctx, -4, "null y");
     if (!wsum) return fail(ctx, -5, "null wsum");
     PhaseTimer timer(ctx, KFSP_T_COMBINE);
@@ -1532,7 +1544,7 @@ int kfsp_spmv_w(kfsp_ctx *ctx, double *y)
     const double *src = ctx->d_w.p;
     if (ctx->use_halo) {
         // w carries no halo margins: stage it in the scratch column
-        double *scratch = vcol(ctx, kNumCols - 1);
+        double *scratch = vcol(ctx, num_cols(ctx) - 1);
         HIP_TRY(hipMemcpyAsync(scratch, ctx->d_w.p, (size_t)ctx->L * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
         src = scratch;
     }
@@ -1561,7 +1573,7 @@ int kfsp_onestep(kfsp_ctx *ctx, int32_t ns, int32_t nr, const int32_t *stoich, i
         const auto t0 = std::chrono::steady_clock::now();
         const int rc = kfsp::onestep_device(ctx, ns, nr, stoich, n, state, ld_state, adj, ld_adj, max_count, capacity, n_new,
                                             state_new, adj_out);
-        ctx->t_ms[KFSP_T_CALLBACKS] += 0.0 * std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        ctx->t_ms[KFSP_T_ONESTEP] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         return rc;
     });
 }
@@ -1684,7 +1696,7 @@ int kfsp_get_basis(kfsp_ctx *ctx, int j, int64_t nlocal, double *v)
 {
     if (!ctx) return -1;
     if (ctx->ldv == 0) return fail(ctx, -1, "no matrix set");
-    if (j < 1 || j > kMMax + 2) return fail(ctx, -2, "bad column");
+    if (j < 1 || j > ctx->opt_mmax + 2) return fail(ctx, -2, "bad column");
     if (nlocal != ctx->nloc) return fail(ctx, -3, "nlocal is not this rank's block size");
     if (!v && nlocal > 0) return fail(ctx, -4, "null v");
     HIP_TRY(hipSetDevice(ctx->device));
@@ -1702,7 +1714,7 @@ int kfsp_expv_fixed(kfsp_ctx *ctx, int m, double tau, int nsteps, double *wsums)
     return no_throw(ctx, [&]() -> int {
         if (!ctx) return -1;
         if (ctx->ldv == 0) return fail(ctx, -1, "no matrix set");
-        if (m < 1 || m > kMMax || (int64_t)m >= ctx->n) return fail(ctx, -2, "bad m");
+        if (m < 1 || m > ctx->opt_mmax || (int64_t)m >= ctx->n) return fail(ctx, -2, "bad m");
         if (nsteps < 0) return fail(ctx, -4, "bad nsteps");
         const int mh = m + 2;
         std::vector<double> H((size_t)mh * mh), E((size_t)mh * mh);
@@ -1798,6 +1810,7 @@ int kfsp_set_option(kfsp_ctx *ctx, const char *name, int64_t value)
     else if (k == "host_build") ctx->opt_host_build = value;
     else if (k == "dia_mask") ctx->opt_dia_mask = value;
     else if (k == "box_generic") ctx->opt_box_generic = value;
+    else if (k == "box_store") ctx->opt_box_store = value;
     else if (k == "small_lds") ctx->opt_small_lds = value;
     else if (k == "state_order") ctx->opt_state_order = value;
     else if (k == "state_order_min") ctx->opt_state_order_min = value;
@@ -1807,6 +1820,11 @@ int kfsp_set_option(kfsp_ctx *ctx, const char *name, int64_t value)
     else if (k == "sell_sigma") ctx->opt_sell_sigma = value;
     else if (k == "overlap") ctx->opt_overlap = value;
     else if (k == "small_kernel") ctx->opt_small = value;
+    else if (k == "m_max") {
+        if (value < 2 || value > kMMax) return fail(ctx, -3, "2 <= m_max <= 100");
+        if (value != ctx->opt_mmax) ctx->relayout = true;      // the next generator re-lays the basis
+        ctx->opt_mmax = value;
+    }
     else return fail(ctx, -2, "unknown option");
     return 0;
 }

@@ -583,6 +583,75 @@ int build_dia_mask(kfsp_ctx *ctx)
     return 0;
 }
 
+// A box generator (kfsp_set_matrix_box) written out as stored diagonals, on the device: row r of the block
+// (global state g = row0 + r) gets, for the reaction at sorted position p, val[p * ld + r] = a_p(x - nu_p) when the
+// source state x - nu_p lies in the box (else 0) - the product of the factor tables in the order the kernel of
+// the matrix-free form multiplies them - and diag[r] = sum of ALL propensities at x in the model's reaction
+// order (StateSpace.f90:207-212).  With one factor per propensity the entries are the table entries themselves,
+// i.e. exactly what kfsp_set_matrix_csr would be given for this box.  One lane per row; runs once per generator.
+__global__ __launch_bounds__(kBlock) void k_box_materialize(BoxDev B, const double *__restrict__ tab, int64_t row0,
+                                                            int64_t nloc, int64_t ld, double *__restrict__ val,
+                                                            double *__restrict__ diag)
+{
+    const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= ld) return;
+    if (r >= nloc) {                                        // padding rows of the last 128-row group
+        for (int p = 0; p < B.nr; ++p) val[(int64_t)p * ld + r] = 0.0;
+        diag[r] = 0.0;
+        return;
+    }
+    int x[kBoxMaxS];
+    uint64_t q = (uint64_t)(row0 + r);
+    for (int s = 0; s < kBoxMaxS; ++s) {
+        x[s] = 0;
+        if (s < B.ns) {
+            x[s] = (int)(q % (uint64_t)B.dims[s]);
+            q /= (uint64_t)B.dims[s];
+        }
+    }
+    double ax[kBoxMaxR];
+    for (int p = 0; p < B.nr; ++p) {
+        // a_p at x itself (for DIAG) and at the source state x - nu_p (the stored entry)
+        double a0 = 1.0, a1 = 1.0;
+        for (int i = 0; i < B.ndep[p]; ++i) {
+            const int xs = x[B.dep_s[p][i]];
+            const double f0 = tab[B.dep_off[p][i] + xs];
+            a0 = i == 0 ? f0 : a0 * f0;
+            const int xsrc = xs - B.dep_nu[p][i];
+            const double f1 = (xsrc >= 0 && xsrc < B.dims[B.dep_s[p][i]]) ? tab[B.dep_off[p][i] + xsrc] : 0.0;
+            a1 = i == 0 ? f1 : a1 * f1;
+        }
+        bool in = true;
+        for (int i = 0; i < B.nmov[p]; ++i) {
+            const int v = x[B.mov_s[p][i]] - B.mov_nu[p][i];
+            in = in && v >= 0 && v < B.mov_dim[p][i];
+        }
+        ax[p] = a0;
+        val[(int64_t)p * ld + r] = in ? a1 : 0.0;
+    }
+    double dsum = 0.0;
+    for (int k = 0; k < B.nr; ++k) {
+        const int p = B.dorder[k];
+        double a = ax[0];
+        for (int j = 1; j < kBoxMaxR; ++j) a = (p == j) ? ax[j] : a;
+        dsum += a;
+    }
+    diag[r] = dsum;
+}
+
+int box_materialize(kfsp_ctx *ctx)
+{
+    hipStream_t st = ctx->stream;
+    const int64_t ld = ctx->dia_ld;
+    HIP_TRY_B(ctx->d_dia.reserve((size_t)ctx->box.nr * (size_t)ld, false));
+    HIP_TRY_B(ctx->d_diag.reserve((size_t)ld + 2 * kChunk, true));
+    if (ld > 0)
+        hipLaunchKernelGGL(k_box_materialize, dim3((int)((ld + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, ctx->box,
+                           ctx->d_box.p, ctx->row0, ctx->nloc, ld, ctx->d_dia.p, ctx->d_diag.p);
+    HIP_TRY_B(hipStreamSynchronize(st));
+    return 0;
+}
+
 void launch_gather_index(int64_t n, const int32_t *index, const double *src, double *dst, hipStream_t st)
 {
     if (n > 0)

@@ -249,10 +249,12 @@ struct kfsp_ctx {
     int64_t lds_per_block = 65536;        // device limit (hipDeviceAttributeMaxSharedMemoryPerBlock)
     int64_t opt_dia_mask = 1;             // 0: never skip empty diagonal segments
     int64_t opt_box_generic = 0;          // 1: matrix-free boxes always take the run-time interpreted kernel
+    int64_t opt_mmax = kfsp::kMMax;        // largest Krylov dimension the basis is allocated for (m_max + 3 columns)
+    int64_t opt_box_store = 0;            // 1: kfsp_set_matrix_box writes the generator out as stored diagonals on the device (banded form)
     int64_t opt_state_order = 1;          // 1: use kfsp_set_state_coords for large, long-lived generators (0: never)
     int64_t opt_state_order_min = 32768;  // smallest generator that is reordered
     int64_t opt_state_order_products = 48;   // ... and only if its predecessor saw this many products
-    double t_ms[KFSP_T_COUNT] = {0, 0, 0, 0, 0, 0};
+    double t_ms[KFSP_T_COUNT] = {0, 0, 0, 0, 0, 0, 0};
 };
 
 namespace kfsp {
@@ -263,6 +265,8 @@ int build_from_ell_device(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, cons
 // after a banded generator was stored: find the empty (diagonal, 128-row group) segments and
 // switch the masked kernel variant on if they are worth skipping
 int build_dia_mask(kfsp_ctx *ctx);
+// kfsp_set_matrix_box with option box_store: the box generator written out as stored diagonals (d_dia, d_diag)
+int box_materialize(kfsp_ctx *ctx);
 // lexicographic order of n states given as ns coordinates each (host array, leading
 // dimension ld): fills d_perm / d_iperm; *ok = false when the packed key needs > 64 bits
 int state_order_from_coords(kfsp_ctx *ctx, int32_t n, int32_t ns, int32_t ld, const int32_t *state, bool *ok);

@@ -27,7 +27,7 @@ constexpr int kMH = kMMax + 2;     // leading dimension of the device H image
 // of two slots as one 8-byte and their values as one 16-byte load (a CU issues vector-memory instructions
 // at a fixed rate whatever their width); the last slot of an odd width stands alone, 64 entries.  A row's
 // slots stay in FMATVEC's order.
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 __host__ __device__
 #endif
 inline int64_t sell_pos(int64_t chunk_off, int w, int k, int lane)

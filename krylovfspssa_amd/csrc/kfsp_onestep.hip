@@ -294,7 +294,9 @@ int onestep_device(kfsp_ctx *ctx, int32_t ns, int32_t nr, const int32_t *stoich,
     OS_TRY(hipStreamSynchronize(st));
 
     // phase 2 buffers: the link array being completed, candidates, unique targets
-    const size_t ncp = (size_t)nc + 64, capn = (size_t)cap + 64;
+    // at most one new state per candidate: the arenas follow the work, not the caller's capacity (MAX_SIZE - 1 of the
+    // Fortran host = 6.3e6 states whatever the FSP's size)
+    const size_t ncp = (size_t)nc + 64, capn = (size_t)std::min<int64_t>(cap, (int64_t)n + nc) + 64;
     size_t need2 = capn * lda * 4 + capn * lds * 4 + 4 * ncp * 8 + 10 * ncp * 4 + 8192;
     OS_TRY(ctx->d_os2.reserve(need2, false));
     Carver c2{ctx->d_os2.p};

@@ -94,7 +94,7 @@ CONTAINS
     TYPE(KFSP_FSP_OPS) :: OPS
     TYPE(KFSP_REPLAY) :: RP
     DOUBLE PRECISION, ALLOCATABLE :: P0(:)
-    REAL(C_DOUBLE) :: TMS(6)
+    REAL(C_DOUBLE) :: TMS(7)
     INTEGER :: I, N0, RC
     INTEGER(8) :: C0, C1, CRATE
 
@@ -157,9 +157,9 @@ CONTAINS
        ! code (DROP_STATES / SSA_EXTENDER / ONESTEP_EXTENDER) incl. its uploads
        CALL SYSTEM_CLOCK(C1)
        RC = KFSP_GET_TIMERS(CTX, TMS, 0_C_INT)
-       PRINT '(A,F12.1,A,6(1X,A,F11.1))', ' KFSP WALL MS =', 1.0D3 * DBLE(C1 - C0) / DBLE(CRATE), ' :', &
+       PRINT '(A,F12.1,A,7(1X,A,F11.1))', ' KFSP WALL MS =', 1.0D3 * DBLE(C1 - C0) / DBLE(CRATE), ' :', &
             'ARNOLDI', TMS(1), 'COMBINE', TMS(2), 'BEGIN_STEP', TMS(3), 'FSP_CALLBACKS', TMS(4), &
-            'HOST_PADE', TMS(5), 'UPLOAD', TMS(6)
+            'HOST_PADE', TMS(5), 'UPLOAD', TMS(6), 'DEVICE_ONESTEP', TMS(7)
        PRINT '(A,I8,A,I8,A,I8,A,I6,A,I6)', ' KFSP STATS: NMULT =', LAST_SOLVE_STATS%NMULT, ' NEXPH =', &
             LAST_SOLVE_STATS%NEXPH, ' WSUM_EVALS =', LAST_SOLVE_STATS%N_WSUM, ' EXPANSIONS =', &
             LAST_SOLVE_STATS%N_EXPAND, ' DROP_CALLS =', LAST_SOLVE_STATS%N_DROP_CALLS
@@ -196,10 +196,13 @@ CONTAINS
     ENDIF
     ! from now on ONESTEP_EXTENDER has a device for the integer work of its sweeps
     ONESTEP_DEVICE => DEVICE_ONESTEP
-    ! KFSP_STATE_ORDER=1 lets the device keep large, long-lived FSPs in its own state
-    ! order (off by default: it changes the order of the sums); KFSP_STATE_ORDER_MIN:
-    ! smallest FSP that is reordered (library default 32768), KFSP_STATE_ORDER_PRODUCTS:
-    ! products the previous generator must have seen (default 48)
+    ! The device keeps large, long-lived FSPs in its own (lexicographic) state order - ON by
+    ! default.  Every row is still summed in FMATVEC's order (KrylovSolver.f90:598-604), so products
+    ! are bit-identical to the plain path; the reductions over states (DNRM2 / DDOT / DASUM and the
+    ! FIND_DROPTOL sums on the device) add their terms in the internal order.  KFSP_STATE_ORDER=0
+    ! restores the caller's order everywhere; KFSP_STATE_ORDER_MIN: smallest FSP that is reordered
+    ! (library default 32768), KFSP_STATE_ORDER_PRODUCTS: products the previous generator must
+    ! have seen (default 48)
     CALL GET_ENVIRONMENT_VARIABLE('KFSP_STATE_ORDER_MIN', ENV, L, STAT)
     IF (STAT == 0 .AND. L > 0) THEN
        READ(ENV(1:L), *, IOSTAT=STAT) V8

@@ -14,7 +14,7 @@ import numpy as np
 from . import build as _build
 
 M_MAX = 100
-T_NAMES = ("arnoldi", "combine", "begin_step", "fsp_callbacks", "host_pade", "upload")
+T_NAMES = ("arnoldi", "combine", "begin_step", "fsp_callbacks", "host_pade", "upload", "device_onestep")
 
 _lib = None
 
@@ -293,8 +293,11 @@ class KfspContext:
         self.n = int(n)
         self.row0, self.nloc = r0, nr
 
-    def set_matrix_box(self, model):
-        """Matrix-free generator of a synth.BoxModel with separable propensities (model.factors())."""
+    def set_matrix_box(self, model, store=None):
+        """Matrix-free generator of a synth.BoxModel with separable propensities (model.factors()).
+        store=True: the device writes the same generator out as stored diagonals (option box_store)."""
+        if store is not None:
+            self.set_option("box_store", 1 if store else 0)
         dims = np.ascontiguousarray(model.dims, dtype=np.int32)
         stoich = np.ascontiguousarray(np.asarray(model.stoich).T, dtype=np.int32)      # [nr][ns]
         ndep, deps, tables = model.factors()

@@ -66,11 +66,13 @@ class BoxModel:
             diag += off[:, r]            # sequential over reactions, as StateSpace.f90:207-212
         return adj, off, diag
 
-    # ---- gather rows of a block --------------------------------------------
-    def csr_rows(self, row0=0, nrows=None):
-        if nrows is None:
-            nrows = self.n - row0
-        rows = np.arange(row0, row0 + nrows, dtype=np.int64)
+    # ---- gather rows ----------------------------------------------------------
+    def rows_at(self, rows):
+        """gather rows of A at the global state indices `rows` (any order): (cols, vals), both
+        [len(rows)][R + 1], entries sorted by column, absent entries have column int64 max and value 0;
+        the diagonal -(sum of all propensities) is stored in place."""
+        rows = np.asarray(rows, dtype=np.int64)
+        nrows = len(rows)
         X = self.coords(rows)
         Xf = [x.astype(np.float64) for x in X]
         big = np.iinfo(np.int64).max
@@ -95,9 +97,36 @@ class BoxModel:
         order = np.argsort(cols, axis=1, kind="stable")
         cols = np.take_along_axis(cols, order, axis=1)
         vals = np.take_along_axis(vals, order, axis=1)
-        valid = cols != big
+        return cols, vals
+
+    def csr_rows(self, row0=0, nrows=None):
+        if nrows is None:
+            nrows = self.n - row0
+        cols, vals = self.rows_at(np.arange(row0, row0 + nrows, dtype=np.int64))
+        valid = cols != np.iinfo(np.int64).max
         rowptr = np.concatenate(([0], np.cumsum(valid.sum(axis=1)))).astype(np.int64)
         return rowptr, cols[valid].astype(np.int32), vals[valid]
+
+    def colsum_dot(self, x, chunk=1 << 22):
+        """1^T A x without A: column j of A sums to -(propensities of the reactions that LEAVE the box from
+        state j) - the probability flux into the absorbing sink (KrylovSolver.f90:446-458) - so
+        1^T A x = -sum_j x_j * sum_{r: x_j + nu_r outside the box} a_r(x_j).  Evaluated in chunks."""
+        total = 0.0
+        for b in range(0, self.n, chunk):
+            idx = np.arange(b, min(self.n, b + chunk), dtype=np.int64)
+            X = self.coords(idx)
+            Xf = [c.astype(np.float64) for c in X]
+            leak = np.zeros(len(idx))
+            for r in range(self.R):
+                out = np.zeros(len(idx), dtype=bool)
+                for k in range(self.d):
+                    s = self.stoich[k, r]
+                    if s:
+                        y = X[k] + s
+                        out |= (y < 0) | (y >= self.dims[k])
+                leak += np.where(out, self.prop(r, Xf) * np.ones(len(idx)), 0.0)
+            total -= float(leak @ x[b:b + len(idx)])
+        return total
 
     # ---- matrix-free form ---------------------------------------------------
     def factors(self):
@@ -135,6 +164,22 @@ class BoxModel:
             assert np.all(np.abs(got - want) <= 4e-16 * np.abs(want) * len(sp)), f"{self.name}: propensity {r} is not separable"
             tabs += mine
         return ndep, dep, np.concatenate(tabs)
+
+    def nnz_rows(self, row0, nrows, chunk=1 << 23):
+        """true nonzeros incl. the diagonal of the gather rows [row0, row0 + nrows) (counted, no values)"""
+        total = int(nrows)
+        for b in range(row0, row0 + nrows, chunk):
+            idx = np.arange(b, min(row0 + nrows, b + chunk), dtype=np.int64)
+            X = self.coords(idx)
+            for r in range(self.R):
+                ok = np.ones(len(idx), dtype=bool)
+                for k in range(self.d):
+                    s = self.stoich[k, r]
+                    if s:
+                        y = X[k] - s
+                        ok &= (y >= 0) & (y < self.dims[k])
+                total += int(ok.sum())
+        return total
 
     def nnz(self):
         """true nonzeros incl. the diagonal"""

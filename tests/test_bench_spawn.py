@@ -19,6 +19,9 @@ def _child(tmp_path):
         r = int(os.environ["RANK"])
         if os.environ.get("FAIL_RANK") == str(r):
             sys.exit(7)
+        if os.environ.get("HANG_RANK") == str(r):
+            import time
+            time.sleep(600)            # a peer blocked in the rendezvous / a collective
         if r == 0:
             print(json.dumps({k: os.environ.get(k) for k in
                   ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY")}
@@ -46,6 +49,31 @@ def test_a_failing_rank_fails_the_job(tmp_path, capfd):
     env = dict(os.environ, FAIL_RANK="2")
     env.pop("WORLD_SIZE", None)
     assert bench.spawn_ranks(3, [], script=_child(tmp_path), env=env) == 1
+
+
+def test_a_failing_rank_ends_ranks_that_would_wait_for_it_for_ever(tmp_path, capfd):
+    """one rank exits 7 while another never returns (blocked in a collective with the dead rank): the job
+    ends at once with the failing rank named, the blocked one is terminated - not waited for"""
+    import time
+    import bench
+    env = dict(os.environ, FAIL_RANK="1", HANG_RANK="2")
+    env.pop("WORLD_SIZE", None)
+    t0 = time.monotonic()
+    assert bench.spawn_ranks(3, [], script=_child(tmp_path), env=env) == 1
+    assert time.monotonic() - t0 < 30.0
+    err = capfd.readouterr().err
+    assert "(1, 7)" in err and "terminated" in err
+
+
+def test_the_overall_deadline_ends_a_job_whose_ranks_all_hang(tmp_path, capfd):
+    import time
+    import bench
+    env = dict(os.environ, HANG_RANK="1")
+    env.pop("WORLD_SIZE", None)
+    t0 = time.monotonic()
+    assert bench.spawn_ranks(2, [], script=_child(tmp_path), env=env, deadline_s=2.0) == 1
+    assert time.monotonic() - t0 < 30.0
+    assert "deadline" in capfd.readouterr().err
 
 
 def test_main_spawns_only_without_a_launcher(monkeypatch):

@@ -29,7 +29,8 @@ def test_bench_line_through_a_one_rank_communicator():
     j = json.loads(lines[0])
     assert j["n_gpus"] == 1 and j["steps"] == 5 and j["warmup"] == 2 and j["unit"] == "GB/s"
     assert j["self_check"]["ok"] and j["config"]["exchange"].startswith("halo strips (banded generator)")
-    assert set(j["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "frac_traffic"}
+    assert set(j["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "frac_traffic", "alg_GBps"}
+    assert 0.0 < j["roofline"]["frac"] <= 1.0                      # bytes that really move / peak: never above 1
 
 
 def test_a_raising_product_recreates_the_communicator_and_steps_down():

@@ -98,6 +98,49 @@ def test_matrix_free_rows_are_partitioned_like_banded_ones(oracle, P):
     assert np.abs(res[0][1][:11, :10] - Href[:11, :10]).max() <= 1e-11 * np.abs(Href).max()
 
 
+@pytest.mark.parametrize("name", list(_models()))
+def test_box_written_out_on_the_device_equals_the_uploaded_rows(oracle, name):
+    """option box_store: kfsp_set_matrix_box writes the generator out as stored diagonals on the device.  With
+    one factor per propensity the entries are the table entries = the very numbers kfsp_set_matrix_csr gets for
+    the same box, and both are banded generators summed in the same order: products bit-identical.  Goutsias
+    (two-factor propensities: the product of the factor tables instead of the model's own evaluation): to
+    1e-13 |A||x|.  Also under a 2-rank partition (row0 != 0, a short last block)."""
+    from krylovfspssa_amd import KfspContext, host
+    mdl = _models()[name]
+    rng = np.random.default_rng(8)
+    x = rng.random(mdl.n)
+    adj, off, diag = mdl.ell()
+    scale = oracle.spmv_ell(oracle.EllMatrix(adj, np.abs(off), -np.abs(diag)), np.abs(x))
+    one_factor = max(len(d) for d in mdl.deps) == 1
+    with KfspContext(0) as c, KfspContext(0) as b:
+        c.set_matrix_box(mdl, store=True)
+        b.set_matrix_csr(mdl.n, *mdl.csr_rows())
+        ic, ib = c.matrix_info(), b.matrix_info()
+        assert ic["slots"] > 0 and ic["nnz"] == mdl.nnz() == ib["nnz"]
+        y, yb = c.spmv(x), b.spmv(x)
+        if one_factor:
+            assert np.array_equal(y, yb)
+        assert np.all(np.abs(y - yb) <= 1e-13 * np.abs(scale) + 1e-300)
+        p0 = rng.random(mdl.n)
+        p0 /= p0.sum()
+        for ctx in (c, b):
+            ctx.set_option("small_kernel", 0)
+            ctx.set_vector(p0)
+        wc, wb = c.expv_fixed(12, 0.004, 2), b.expv_fixed(12, 0.004, 2)
+        if one_factor:
+            assert np.array_equal(wc, wb) and np.array_equal(c.get_vector(), b.get_vector())
+        assert np.abs(c.get_vector() - b.get_vector()).sum() < 1e-12
+
+    def body(ctx, rank):
+        ctx.set_matrix_box(mdl, store=True)
+        r0, nr = ctx.row_block(mdl.n)
+        ctx.set_vector(x[r0:r0 + nr])
+        return ctx.spmv_w()
+
+    y2 = np.concatenate(host.run_loopback_ranks(2, body))
+    assert np.array_equal(y2, y)
+
+
 def test_bad_boxes_are_rejected():
     from krylovfspssa_amd import KfspContext, KfspError, synth
     with KfspContext(0) as c:

@@ -94,6 +94,111 @@ def test_config5_slab_at_full_size():
         assert ws[-1] == pytest.approx(w.sum(), rel=1e-13)
 
 
+def _c5_samples(mdl, x, rng, k=8192):
+    """rows of A x recomputed in numpy from the model at sampled states (first / last 512 and k random ones)"""
+    n = mdl.n
+    rows = np.unique(np.concatenate([np.arange(512), np.arange(n - 512, n), rng.integers(0, n, k)]))
+    cols, vals = mdl.rows_at(rows)
+    ok = cols != np.iinfo(np.int64).max
+    xs = x[np.where(ok, cols, 0)]
+    return rows, (vals * xs).sum(axis=1), (np.abs(vals) * np.abs(xs)).sum(axis=1)
+
+
+def test_config5_at_full_size_on_one_context():
+    """BASELINE config 5 at its STATED size: the 6-species birth-death network on 22^6 = 113 379 904 states,
+    12 reactions, nnz = 1.41e9.  Matrix-free form (no generator arrays anywhere) and the stored form written
+    out on the device (12 diagonals, 10.9 GB), both on ONE context: linearity, the mass-balance identity
+    1^T A x = -(flux into the sink), determinism, >= 8k sampled rows recomputed in numpy from the model, the
+    two forms against each other, and two fixed-(m, tau) steps."""
+    from krylovfspssa_amd import KfspContext, synth
+    mdl = synth.birth_death((22,) * 6)
+    assert mdl.n == 113_379_904 and mdl.R == 12 and mdl.nnz() > 1.4e9
+    rng = np.random.default_rng(55)
+    x, z = rng.random(mdl.n), rng.random(mdl.n)
+    rows, ref, scale = _c5_samples(mdl, x, rng)
+    assert len(rows) >= 8192
+    flux = mdl.colsum_dot(x)
+    with KfspContext(0) as c:
+        c.set_option("m_max", 24)                        # 27 basis columns of 0.9 GB instead of 105
+        c.set_matrix_box(mdl)
+        assert c.matrix_info() == dict(rows=mdl.n, slots=0, nnz=mdl.nnz())
+        ax = c.spmv(x)
+        mag = np.abs(ax).max()
+        assert np.all(np.abs(ax[rows] - ref) <= 1e-13 * scale)
+        assert abs(ax.sum() - flux) <= 1e-7 * np.abs(ax).sum()
+        assert np.array_equal(ax, c.spmv(x))
+        az = c.spmv(z)
+        lin = c.spmv(2.0 * x - 3.0 * z)
+        assert np.abs(lin - (2.0 * ax - 3.0 * az)).max() <= 1e-9 * mag
+        del az, lin
+        mf_bytes = c.matrix_bytes()
+        # the stored form of the same generator, on the same context
+        c.set_matrix_box(mdl, store=True)
+        info = c.matrix_info()
+        assert info["slots"] >= 12 * mdl.n and info["nnz"] == mdl.nnz()
+        assert c.matrix_bytes() > 5 * mf_bytes
+        ay = c.spmv(x)
+        assert np.all(np.abs(ay[rows] - ref) <= 1e-13 * scale)
+        assert np.abs(ay - ax).max() <= 1e-12 * mag          # (the fast matrix-free path sums a row species by species)
+        del ay
+        # two steps of exp(tau A) from the Poisson product: mass and sign, stored against matrix-free
+        p0 = synth.poisson_p0(mdl, 4.0)
+        c.set_vector(p0)
+        ws = c.expv_fixed(20, 0.01, 2)
+        w = c.get_vector()
+        assert np.all(w >= 0) and 0.99 < ws[1] <= ws[0] <= 1.0 + 1e-12
+        assert ws[-1] == pytest.approx(w.sum(), rel=1e-12)
+        c.set_matrix_box(mdl, store=False)
+        c.set_vector(p0)
+        ws2 = c.expv_fixed(20, 0.01, 2)
+        assert np.abs(ws2 - ws).max() < 1e-12 and np.abs(c.get_vector() - w).sum() < 1e-10
+
+
+def test_config5_at_full_size_row_partitioned_over_8_ranks():
+    """The same generator as BASELINE states it: 1.13e8 states row-partitioned over 8 ranks - here the 8 contexts
+    of a loop-back group on the one GPU.  Every rank builds ONLY its 22^5 x ~2.75 slab of gather rows
+    (synth csr_rows(row0, nrows), numpy) and uploads it; the partitioned product (halo strips) is compared with
+    the matrix-free product of the whole box, and one Arnoldi pass must leave bit-identical scalars on all ranks
+    that agree with the single-context pass."""
+    from krylovfspssa_amd import KfspContext, host, synth
+    mdl = synth.birth_death((22,) * 6)
+    rng = np.random.default_rng(56)
+    x = rng.random(mdl.n)
+    m = 6
+    with KfspContext(0) as c:
+        c.set_option("m_max", 8)
+        c.set_matrix_box(mdl)
+        c.set_vector(x)
+        y1 = c.spmv_w()
+        beta1 = c.begin_step()
+        H1, mb1, k11, av1 = c.arnoldi(m)
+    mag = np.abs(y1).max()
+
+    def body(ctx, rank):
+        ctx.set_option("m_max", 8)
+        r0, nr = ctx.row_block(mdl.n)
+        rowptr, col, val = mdl.csr_rows(r0, nr)
+        nnz = int(rowptr[-1])
+        ctx.set_matrix_csr(mdl.n, rowptr, col, val)
+        del rowptr, col, val
+        ctx.set_vector(x[r0:r0 + nr])
+        y = ctx.spmv_w()
+        err = float(np.abs(y - y1[r0:r0 + nr]).max()) if nr else 0.0
+        beta = ctx.begin_step()
+        H, mb, k1, av = ctx.arnoldi(m)
+        return err, beta, H.copy(), mb, k1, av, nnz, nr
+
+    res = host.run_loopback_ranks(8, body)
+    assert sum(r[7] for r in res) == mdl.n and sum(r[6] for r in res) == mdl.nnz()
+    assert max(r[0] for r in res) <= 1e-12 * mag
+    for r in res[1:]:                                             # every rank holds the same scalars, bit for bit
+        assert r[1] == res[0][1] and np.array_equal(r[2], res[0][2]) and r[3:6] == res[0][3:6]
+    assert abs(res[0][1] - beta1) <= 1e-13 * beta1
+    assert (res[0][3], res[0][4]) == (mb1, k11)
+    assert np.abs(res[0][2] - H1).max() <= 1e-10 * np.abs(H1).max()
+    assert abs(res[0][5] - av1) <= 1e-10 * av1
+
+
 @pytest.mark.parametrize("dims", [(5, 5, 5, 5, 5, 5), (7, 6, 5, 4, 3, 3)])
 def test_six_species_network_matches_the_oracle(oracle, dims):
     """config 5's model (6 species, 12 reactions, 12 diagonals) at 5^6 = 15 625 and 7 560 states:
