@@ -148,7 +148,8 @@ void set_matrix_args(const kfsp_ctx *c, SpmvArgs &a)
 }
 
 // ---- the two collectives of the data path, over RCCL or the loop-back transport ----
-constexpr int kLoopScratch = 64 * 4;   // doubles: up to 64 ranks x 3 scalars (+ result)
+constexpr int kLoopVals = 16;                              // values one all-reduce may carry (the 16 FIND_DROPTOL sums)
+constexpr int kLoopScratch = 64 * kLoopVals + kLoopVals;   // doubles: up to 64 ranks x 16 scalars (+ result)
 
 // buf[0..count) <- sum (or max) over ranks, in place, on stream st
 int comm_allreduce(kfsp_ctx *ctx, double *buf, int count, bool take_max, hipStream_t st)
@@ -158,19 +159,19 @@ int comm_allreduce(kfsp_ctx *ctx, double *buf, int count, bool take_max, hipStre
         return 0;
     }
     kfsp::LoopGroup *g = ctx->loop;
-    if (count > 3 || g->n > 64) return fail(ctx, -1, "loop-back all-reduce: too many values");
+    if (count > kLoopVals || g->n > 64) return fail(ctx, -1, "loop-back all-reduce: too many values");
     HIP_TRY(hipStreamSynchronize(st));                  // this rank's contribution is in memory
     g->slot[(size_t)ctx->rank] = buf;
     if (!g->barrier()) return fail(ctx, 2999, "loop-back barrier timed out");
     double *h = ctx->h_loop;
     for (int p = 0; p < g->n; ++p)
-        HIP_TRY(hipMemcpyAsync(h + 4 * p, g->slot[(size_t)p], (size_t)count * sizeof(double), hipMemcpyDefault, st));
+        HIP_TRY(hipMemcpyAsync(h + kLoopVals * p, g->slot[(size_t)p], (size_t)count * sizeof(double), hipMemcpyDefault, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (!g->barrier()) return fail(ctx, 2999, "loop-back barrier timed out");   // everyone has read
-    double *r = h + 4 * g->n;
+    double *r = h + kLoopVals * g->n;
     for (int i = 0; i < count; ++i) {
         double a = h[i];
-        for (int p = 1; p < g->n; ++p) a = take_max ? std::max(a, h[4 * p + i]) : a + h[4 * p + i];   // rank order: same bits on every rank
+        for (int p = 1; p < g->n; ++p) a = take_max ? std::max(a, h[kLoopVals * p + i]) : a + h[kLoopVals * p + i];   // rank order: same bits on every rank
         r[i] = a;
     }
     HIP_TRY(hipMemcpyAsync(buf, r, (size_t)count * sizeof(double), hipMemcpyHostToDevice, st));
@@ -193,6 +194,24 @@ int comm_allgather(kfsp_ctx *ctx, const double *send, double *recv, size_t count
         HIP_TRY(hipMemcpyAsync(recv + (size_t)p * count, g->slot[(size_t)p], count * sizeof(double), hipMemcpyDefault, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (!g->barrier()) return fail(ctx, 2999, "loop-back barrier timed out");   // nobody reuses its send buffer before all have copied
+    return 0;
+}
+
+// the same for raw bytes (flags)
+int comm_allgather_bytes(kfsp_ctx *ctx, const void *send, void *recv, size_t bytes, hipStream_t st)
+{
+    if (!ctx->loop) {
+        NCCL_TRY(ncclAllGather(send, recv, bytes, ncclUint8, ctx->comm, st));
+        return 0;
+    }
+    kfsp::LoopGroup *g = ctx->loop;
+    HIP_TRY(hipStreamSynchronize(st));
+    g->slot[(size_t)ctx->rank] = send;
+    if (!g->barrier()) return fail(ctx, 2999, "loop-back barrier timed out");
+    for (int p = 0; p < g->n; ++p)
+        HIP_TRY(hipMemcpyAsync(static_cast<char *>(recv) + (size_t)p * bytes, g->slot[(size_t)p], bytes, hipMemcpyDefault, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (!g->barrier()) return fail(ctx, 2999, "loop-back barrier timed out");
     return 0;
 }
 
@@ -452,7 +471,7 @@ int resize(kfsp_ctx *ctx, int64_t n)
     const int64_t need = round_up(ctx->L + 2 * ctx->margin, 256);
     int64_t ldv = ctx->ldv;
     if (need > ctx->ldv || ctx->relayout) {
-        if (ctx->w_pending) return fail(ctx, -2, "the FSP grew between kfsp_drop_compact and the next generator");
+        if (ctx->w_pending && !ctx->use_comm) return fail(ctx, -2, "the FSP grew between kfsp_drop_compact and the next generator");
         // (head room: half as much again, but no more than 2^24 rows - at 10^8 states 50 % would be 70 GB)
         ldv = ctx->relayout ? need : round_up(need + std::min<int64_t>(need / 2, (int64_t)1 << 24), 256);
         ctx->relayout = false;
@@ -575,43 +594,99 @@ int maybe_upload_dia(kfsp_ctx *ctx, const HostSell &S, const std::vector<int32_t
     return kfsp::build_dia_mask(ctx);
 }
 
-// Host array (caller's state order) -> device vector (internal order) and back.
-// Without an internal order these are plain copies.
-int upload_states(kfsp_ctx *ctx, const double *host, double *dev, int64_t count)
+// ---- the caller's state order <-> what the device keeps ----------------------------------------------
+// Without an internal order and without a communicator a vector is a plain copy.  With an internal order
+// (perm[new] = old, GLOBAL indices) a rank owns the block [row0, row0 + nloc) of the INTERNAL order, while
+// the C ABI speaks of the same block of the CALLER's order: the two meet in a full-length vector that every
+// rank assembles with one all-gather (set / get of vectors happen a few times per FSP change, not per product).
+
+// full vector in the caller's order (device, n entries) -> this rank's block of a w-like vector
+int scatter_from_full(kfsp_ctx *ctx, const double *full_caller, double *dev_local)
 {
-    if (count <= 0) return 0;
+    if (ctx->nloc <= 0) return 0;
+    if (ctx->perm_on)
+        kfsp::launch_gather_index(ctx->nloc, ctx->d_perm.p + ctx->row0, full_caller, dev_local, ctx->stream);
+    else
+        HIP_TRY(hipMemcpyAsync(dev_local, full_caller + ctx->row0, (size_t)ctx->nloc * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    return 0;
+}
+
+// this rank's block of a w-like vector (readable for L entries) -> the full vector in the caller's order on
+// every rank; *full points into d_xg or d_full (valid until either is used again)
+int gather_to_full(kfsp_ctx *ctx, const double *dev_local, const double **full)
+{
+    const double *xg = dev_local;
+    if (ctx->use_comm) {
+        if (int rc = comm_allgather(ctx, dev_local, ctx->d_xg.p, (size_t)ctx->L, ctx->stream)) return rc;
+        xg = ctx->d_xg.p;                                   // entry g of the internal order (blocks are contiguous: row0 = rank * L)
+    }
     if (!ctx->perm_on) {
-        HIP_TRY(hipMemcpyAsync(dev, host, (size_t)count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        *full = xg;
         return 0;
     }
-    HIP_TRY(ctx->d_pstage.reserve((size_t)count, false));
-    HIP_TRY(hipMemcpyAsync(ctx->d_pstage.p, host, (size_t)count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    kfsp::launch_gather_index(count, ctx->d_perm.p, ctx->d_pstage.p, dev, ctx->stream);
+    HIP_TRY(ctx->d_full.reserve((size_t)ctx->n + 64, false));
+    kfsp::launch_gather_index(ctx->n, ctx->d_iperm.p, xg, ctx->d_full.p, ctx->stream);      // full[old] = xg[iperm[old]]
+    *full = ctx->d_full.p;
     return 0;
+}
+
+// Host array (this rank's block of the caller's order) -> device vector and back.
+int upload_states(kfsp_ctx *ctx, const double *host, double *dev, int64_t count)
+{
+    if (!ctx->perm_on) {
+        if (count > 0)
+            HIP_TRY(hipMemcpyAsync(dev, host, (size_t)count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        return 0;
+    }
+    if (!ctx->use_comm) {
+        if (count <= 0) return 0;
+        HIP_TRY(ctx->d_pstage.reserve((size_t)count, false));
+        HIP_TRY(hipMemcpyAsync(ctx->d_pstage.p, host, (size_t)count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        kfsp::launch_gather_index(count, ctx->d_perm.p, ctx->d_pstage.p, dev, ctx->stream);
+        return 0;
+    }
+    // blocks of the caller's order from all ranks, then this rank's block of the internal order
+    HIP_TRY(ctx->d_pstage.reserve((size_t)ctx->L, false));
+    HIP_TRY(hipMemsetAsync(ctx->d_pstage.p, 0, (size_t)ctx->L * sizeof(double), ctx->stream));
+    if (count > 0)
+        HIP_TRY(hipMemcpyAsync(ctx->d_pstage.p, host, (size_t)count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if (int rc = comm_allgather(ctx, ctx->d_pstage.p, ctx->d_xg.p, (size_t)ctx->L, ctx->stream)) return rc;
+    return scatter_from_full(ctx, ctx->d_xg.p, dev);
 }
 
 int download_states(kfsp_ctx *ctx, const double *dev, double *host, int64_t count)
 {
-    if (count <= 0) return 0;
     if (!ctx->perm_on) {
-        HIP_TRY(hipMemcpyAsync(host, dev, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        if (count > 0)
+            HIP_TRY(hipMemcpyAsync(host, dev, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         return 0;
     }
-    HIP_TRY(ctx->d_pstage.reserve((size_t)count, false));
-    kfsp::launch_gather_index(count, ctx->d_iperm.p, dev, ctx->d_pstage.p, ctx->stream);
-    HIP_TRY(hipMemcpyAsync(host, ctx->d_pstage.p, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (!ctx->use_comm) {
+        if (count <= 0) return 0;
+        HIP_TRY(ctx->d_pstage.reserve((size_t)count, false));
+        kfsp::launch_gather_index(count, ctx->d_iperm.p, dev, ctx->d_pstage.p, ctx->stream);
+        HIP_TRY(hipMemcpyAsync(host, ctx->d_pstage.p, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        return 0;
+    }
+    const double *full = nullptr;
+    if (int rc = gather_to_full(ctx, dev, &full)) return rc;
+    if (count > 0)
+        HIP_TRY(hipMemcpyAsync(host, full + ctx->row0, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     return 0;
 }
 
 // A vector compacted on the device (kfsp_drop_compact) becomes the resident w of the generator
-// that was just set: caller's order -> the order the device keeps this generator in.
+// that was just set: caller's order -> the order the device keeps this generator in.  With a communicator the
+// pending vector is the FULL compacted vector (every rank holds it) and each rank takes its new block.
 int adopt_pending_vector(kfsp_ctx *ctx)
 {
     if (!ctx->w_pending) return 0;
     ctx->w_pending = false;
     if (ctx->w_pending_n != ctx->n) return fail(ctx, -2, "generator size does not match the vector compacted by kfsp_drop_compact");
     HIP_TRY(hipMemsetAsync(ctx->d_w.p, 0, (size_t)ctx->ldv * sizeof(double), ctx->stream));
-    if (ctx->perm_on)
+    if (ctx->use_comm) {
+        if (int rc = scatter_from_full(ctx, ctx->d_wfull.p, ctx->d_w.p)) return rc;
+    } else if (ctx->perm_on)
         kfsp::launch_gather_index(ctx->n, ctx->d_perm.p, ctx->d_tmp.p, ctx->d_w.p, ctx->stream);
     else
         HIP_TRY(hipMemcpyAsync(ctx->d_w.p, ctx->d_tmp.p, (size_t)ctx->n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
@@ -683,6 +758,7 @@ int kfsp_destroy(kfsp_ctx *ctx)
     if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);
     ctx->d_off.release(); ctx->d_col.release(); ctx->d_val.release(); ctx->d_diag.release();
     ctx->d_V.release(); ctx->d_w.release(); ctx->d_xg.release(); ctx->d_tmp.release();
+    ctx->d_full.release(); ctx->d_wfull.release(); ctx->d_flagloc.release();
     ctx->d_part.release(); ctx->d_stage.release(); ctx->d_H.release(); ctx->d_sq.release();
     ctx->d_y.release(); ctx->d_flag.release(); ctx->d_g.release(); ctx->d_dia.release();
     ctx->d_ell_adj.release(); ctx->d_ell_off.release(); ctx->d_ell_diag.release(); ctx->d_cnt.release();
@@ -833,7 +909,7 @@ static int set_matrix_ell_impl(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld,
         if (int rc = resize(ctx, n)) return rc;
         const int64_t row0 = ctx->row0, nloc = ctx->nloc;
         // coordinates handed over for exactly this generator switch the internal order on
-        ctx->perm_on = ctx->perm_pending_n == n && !ctx->use_comm && !ctx->opt_host_build;
+        ctx->perm_on = ctx->perm_pending_n == n && !ctx->opt_host_build;
         ctx->perm_pending_n = 0;
         ctx->prod_last = ctx->prod_count;
         ctx->prod_count = 0;
@@ -1170,7 +1246,7 @@ int kfsp_set_state_coords(kfsp_ctx *ctx, int32_t n, int32_t ns, int32_t ld, cons
         if (ld < ns) return fail(ctx, -4, "ld < ns");
         if (!state) return fail(ctx, -5, "null state");
         ctx->perm_pending_n = 0;
-        if (!ctx->opt_state_order || n < ctx->opt_state_order_min || ctx->use_comm) return 0;
+        if (!ctx->opt_state_order || n < ctx->opt_state_order_min) return 0;
         // Sorting, relabelling and the extra upload cost about as much as 20 products (at 10^6 states)
         // save: worth it only while generators live that long.  The generator being
         // replaced is the best predictor there is.
@@ -1519,15 +1595,13 @@ int kfsp_spmv(kfsp_ctx *ctx, const double *x, double *y)
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     HIP_TRY(hipMemsetAsync(ctx->d_xg.p, 0, ctx->d_xg.cap * sizeof(double), st));
-    if (ctx->nranks == 1) {
-        if (int rc = upload_states(ctx, x, ctx->d_xg.p, ctx->n)) return rc;
+    // x is the WHOLE vector in the caller's order on every rank; global index g of the internal order lives at d_xg[g]
+    if (ctx->perm_on) {
+        HIP_TRY(ctx->d_pstage.reserve((size_t)ctx->n, false));
+        HIP_TRY(hipMemcpyAsync(ctx->d_pstage.p, x, (size_t)ctx->n * sizeof(double), hipMemcpyHostToDevice, st));
+        kfsp::launch_gather_index(ctx->n, ctx->d_perm.p, ctx->d_pstage.p, ctx->d_xg.p, st);
     } else {
-        // global index of row k of rank p is p*L + k
-        for (int p = 0; p < ctx->nranks; ++p) {
-            const int64_t b = (int64_t)p * ctx->L, cnt = std::min<int64_t>(ctx->L, ctx->n - b);
-            if (cnt > 0)
-                HIP_TRY(hipMemcpyAsync(ctx->d_xg.p + b, x + b, (size_t)cnt * sizeof(double), hipMemcpyHostToDevice, st));
-        }
+        HIP_TRY(hipMemcpyAsync(ctx->d_xg.p, x, (size_t)ctx->n * sizeof(double), hipMemcpyHostToDevice, st));
     }
     if (int rc = spmv_plain(ctx, ctx->d_xg.p, true, ctx->d_tmp.p)) return rc;
     if (int rc = download_states(ctx, ctx->d_tmp.p, y, ctx->nloc)) return rc;
@@ -1584,12 +1658,13 @@ int kfsp_drop_plan(kfsp_ctx *ctx, double dsum, double *droptol, int64_t *drop_co
     if (ctx->ldv == 0) return fail(ctx, -1, "no matrix set");
     if (!(dsum > 0.0)) return fail(ctx, -2, "dsum must be positive (FIND_DROPTOL would not terminate)");
     if (!droptol || !drop_count || !n_flagged) return fail(ctx, -3, "null output");
-    if (ctx->use_comm) return fail(ctx, -9, "kfsp_drop_* is not available with a communicator");
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const int64_t n = ctx->n;
+    const bool comm = ctx->use_comm;
     ctx->drop_planned = false;
-    // FIND_DROPTOL: thresholds 1e-8, /10, /10, ... (the same divisions, so the same doubles), sixteen per pass
+    // FIND_DROPTOL: thresholds 1e-8, /10, /10, ... (the same divisions, so the same doubles), sixteen per pass.
+    // With a communicator every rank sums its block and ONE all-reduce carries the sixteen sums.
     double *part = ctx->d_part.p;                       // kDropLevels * grid partials: the rotating buffers are idle between steps
     const int grid = (int)std::min<int64_t>(vec_grid(ctx), (int64_t)kNumPartial * kMaxGrid / kfsp::kDropLevels);
     double *sums_dev = ctx->d_H.p;                      // scratch: the H image is rewritten by the next pass anyway
@@ -1601,6 +1676,8 @@ int kfsp_drop_plan(kfsp_ctx *ctx, double dsum, double *droptol, int64_t *drop_co
             tol = tol / 10.0;
         }
         kfsp::launch_drop_sums(grid, act_pairs(ctx), ctx->d_w.p, L, part, sums_dev, st);
+        if (comm)
+            if (int rc = comm_allreduce(ctx, sums_dev, kfsp::kDropLevels, false, st)) return rc;
         HIP_TRY(hipMemcpyAsync(ctx->h_pin, sums_dev, kfsp::kDropLevels * sizeof(double), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         for (int k = 0; k < kfsp::kDropLevels; ++k)
@@ -1613,15 +1690,45 @@ int kfsp_drop_plan(kfsp_ctx *ctx, double dsum, double *droptol, int64_t *drop_co
     *droptol = found;
     // A w into a basis column nobody needs between two steps, then the flags
     double *aw = vcol(ctx, 1);
-    if (int rc = spmv_plain(ctx, ctx->d_w.p, false, aw)) return rc;
+    {
+        const double *src = ctx->d_w.p;
+        if (ctx->use_halo) {                            // w carries no halo margins: stage it in the scratch column
+            double *scratch = vcol(ctx, num_cols(ctx) - 1);
+            HIP_TRY(hipMemcpyAsync(scratch, ctx->d_w.p, (size_t)ctx->L * sizeof(double), hipMemcpyDeviceToDevice, st));
+            src = scratch;
+        }
+        if (int rc = spmv_plain(ctx, src, false, aw)) return rc;
+    }
     HIP_TRY(ctx->d_dropflag.reserve(2 * (size_t)(n + 256), false));
     HIP_TRY(ctx->d_dropcnt.reserve(8, true));
     HIP_TRY(hipMemsetAsync(ctx->d_dropcnt.p, 0, 4 * sizeof(unsigned long long), st));
-    kfsp::launch_drop_flags(n, ctx->d_w.p, aw, found, ctx->perm_on ? ctx->d_perm.p : nullptr, ctx->d_dropflag.p,
-                            ctx->d_dropcnt.p, st);
     unsigned long long cnt[4] = {0, 0, 0, 0};
-    HIP_TRY(hipMemcpyAsync(cnt, ctx->d_dropcnt.p, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    if (!comm) {
+        kfsp::launch_drop_flags(n, ctx->d_w.p, aw, found, ctx->perm_on ? ctx->d_perm.p : nullptr, ctx->d_dropflag.p,
+                                ctx->d_dropcnt.p, st);
+        HIP_TRY(hipMemcpyAsync(cnt, ctx->d_dropcnt.p, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    } else {
+        // flags of this rank's block (internal order), all blocks to every rank, then into the caller's order:
+        // every rank ends up with the flags of ALL states, as the host that compacts its lists needs them
+        const size_t Lb = (size_t)ctx->L;
+        HIP_TRY(ctx->d_flagloc.reserve(Lb * (size_t)(ctx->nranks + 1) + 256, false));
+        uint8_t *mine = ctx->d_flagloc.p, *all = ctx->d_flagloc.p + Lb;
+        HIP_TRY(hipMemsetAsync(mine, 0, Lb, st));
+        if (ctx->nloc > 0) kfsp::launch_drop_flags(ctx->nloc, ctx->d_w.p, aw, found, nullptr, mine, ctx->d_dropcnt.p, st);
+        HIP_TRY(hipMemcpyAsync(cnt, ctx->d_dropcnt.p, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        double *stg = ctx->d_stage.p;                                     // counts as doubles (exact below 2^53)
+        const double hc[3] = {(double)cnt[0], (double)cnt[1], (double)cnt[2]};
+        HIP_TRY(hipMemcpyAsync(stg, hc, sizeof(hc), hipMemcpyHostToDevice, st));
+        if (int rc = comm_allreduce(ctx, stg, 3, false, st)) return rc;
+        double hr[3] = {0, 0, 0};
+        HIP_TRY(hipMemcpyAsync(hr, stg, sizeof(hr), hipMemcpyDeviceToHost, st));
+        if (int rc = comm_allgather_bytes(ctx, mine, all, Lb, st)) return rc;
+        kfsp::launch_flags_to_caller(n, all, ctx->perm_on ? ctx->d_perm.p : nullptr, ctx->d_dropflag.p, st);
+        HIP_TRY(hipStreamSynchronize(st));
+        for (int i = 0; i < 3; ++i) cnt[i] = (unsigned long long)hr[i];
+    }
     *drop_count = (int64_t)cnt[0] - (int64_t)cnt[1];     // the reference's DROP_COUNT (:476-495)
     *n_flagged = (int64_t)cnt[2];
     ctx->drop_planned = true;
@@ -1651,14 +1758,21 @@ int kfsp_drop_compact(kfsp_ctx *ctx, int64_t *n_new)
     hipStream_t st = ctx->stream;
     const int64_t n = ctx->n;
     const double *src = ctx->d_w.p;
-    if (ctx->perm_on) {                                  // back to the caller's order first
+    double *dst = ctx->d_tmp.p;
+    if (ctx->use_comm) {
+        // the partition of the compacted FSP is another one: every rank assembles the WHOLE vector in the caller's
+        // order, compacts it (all ranks hold all flags), and takes its new block when the next generator arrives
+        if (int rc = gather_to_full(ctx, ctx->d_w.p, &src)) return rc;
+        HIP_TRY(ctx->d_wfull.reserve((size_t)n + 64, false));
+        dst = ctx->d_wfull.p;
+    } else if (ctx->perm_on) {                           // back to the caller's order first
         HIP_TRY(ctx->d_pstage.reserve((size_t)n, false));
         kfsp::launch_gather_index(n, ctx->d_iperm.p, ctx->d_w.p, ctx->d_pstage.p, st);
         src = ctx->d_pstage.p;
     }
-    HIP_TRY(hipMemsetAsync(ctx->d_tmp.p, 0, (size_t)ctx->ldv * sizeof(double), st));
+    if (!ctx->use_comm) HIP_TRY(hipMemsetAsync(ctx->d_tmp.p, 0, (size_t)ctx->ldv * sizeof(double), st));
     int *nk_dev = reinterpret_cast<int *>(ctx->d_dropcnt.p + 3);
-    if (int rc = kfsp::drop_compact_vector(ctx, n, src, ctx->d_tmp.p, nk_dev)) return fail(ctx, rc, "device compaction failed");
+    if (int rc = kfsp::drop_compact_vector(ctx, n, src, dst, nk_dev)) return fail(ctx, rc, "device compaction failed");
     int nk = 0;
     HIP_TRY(hipMemcpyAsync(&nk, nk_dev, sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));

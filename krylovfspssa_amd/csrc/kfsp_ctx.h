@@ -218,6 +218,9 @@ struct kfsp_ctx {
     DevBuf<double> d_w;    // probability vector, ldv
     DevBuf<double> d_xg;   // nranks*L gathered source (nranks > 1) or scratch x (kfsp_spmv)
     DevBuf<double> d_tmp;  // ldv scratch (kfsp_spmv output)
+    DevBuf<double> d_full;   // n: a whole vector in the caller's order (internal state order under a communicator)
+    DevBuf<double> d_wfull;  // n: the whole compacted w between kfsp_drop_compact and the next generator (communicator)
+    DevBuf<uint8_t> d_flagloc;   // L * nranks: flags of the blocks in the internal order (communicator)
 
     // scalars
     DevBuf<double> d_part;   // kNumPartial * kMaxGrid
@@ -276,6 +279,7 @@ void launch_gather_index(int64_t n, const int32_t *index, const double *src, dou
 void launch_drop_sums(int grid, int64_t npairs, const double *w, const DropLevels &L, double *partial, double *out, hipStream_t st);
 void launch_drop_flags(int64_t n, const double *w, const double *aw, double droptol, const int32_t *perm, uint8_t *flag,
                        unsigned long long *cnt, hipStream_t st);
+void launch_flags_to_caller(int64_t n, const uint8_t *all, const int32_t *perm, uint8_t *flag, hipStream_t st);
 int drop_compact_vector(kfsp_ctx *ctx, int64_t n, const double *src, double *dst, int *n_keep_dev);
 // ONESTEP_EXTENDER's integer work (kfsp_onestep.hip); all arrays are host memory
 int onestep_device(kfsp_ctx *ctx, int32_t ns, int32_t nr, const int32_t *stoich, int32_t n, const int32_t *state, int32_t lds,

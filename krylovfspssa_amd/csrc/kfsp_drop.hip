@@ -109,7 +109,20 @@ __global__ __launch_bounds__(kBlock) void k_keep_from_drop(int64_t n, const uint
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) keep[i] = drop[i] ? 0 : 1;
 }
 
+// flags of all blocks in the device's order (entry g at all[g]: blocks are contiguous) -> the caller's order
+__global__ __launch_bounds__(kBlock) void k_flags_to_caller(int64_t n, const uint8_t *__restrict__ all, const int32_t *__restrict__ perm,
+                                                            uint8_t *__restrict__ flag)
+{
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) flag[perm ? perm[i] : i] = all[i];
+}
+
 }  // namespace
+
+void launch_flags_to_caller(int64_t n, const uint8_t *all, const int32_t *perm, uint8_t *flag, hipStream_t st)
+{
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (n + kBlock - 1) / kBlock));
+    hipLaunchKernelGGL(k_flags_to_caller, dim3(grid), dim3(kBlock), 0, st, n, all, perm, flag);
+}
 
 void launch_drop_sums(int grid, int64_t npairs, const double *w, const DropLevels &L, double *partial, double *out, hipStream_t st)
 {
