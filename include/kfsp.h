@@ -67,6 +67,19 @@ int kfsp_row_block(const kfsp_ctx *ctx, int64_t n, int64_t *row0, int64_t *nrows
  * block of `rank` out of `nranks` for n states, and the padded block length L */
 int kfsp_partition(int64_t n, int nranks, int rank, int64_t *row0, int64_t *nrows, int64_t *block_len);
 
+/* ONE host thread driving the whole partition: a GROUP context is a head handle over nranks ordinary contexts,
+ * one worker thread each, on devices[0..nranks) - distinct devices talk RCCL, a device named more than once (or
+ * devices == NULL: all on device 0) makes the group a loop-back group on that device (one-GPU rehearsal).  The
+ * head behaves like a ONE-RANK context: whole vectors, whole arrays, GLOBAL sizes in and out, while generator
+ * rows, Krylov basis and w are partitioned over the ranks.  This is how a serial caller - DGEXPV_FSP's Fortran
+ * host (KrylovSolver.f90:40) is one - uses several GPUs: every entry point below accepts a head; kfsp_dgexpv and
+ * its drop / expand callbacks (KrylovSolver.f90:509-534) run once, on the caller's thread and the caller's one copy
+ * of the state space.  Scalars all ranks must agree on (beta, H, AVNORM, WSUM, the drop plan) are compared bit
+ * for bit on the way back: 4002 if they ever differ.  Not on a head: kfsp_comm_init*, kfsp_selftest_stream. */
+int kfsp_create_group(int nranks, const int *devices, kfsp_ctx **out);
+/* ranks behind a context: 1 for an ordinary one */
+int kfsp_group_size(const kfsp_ctx *ctx, int *nranks);
+
 /* ---- generator ------------------------------------------------------- */
 /* TYPE FSP_MATRIX verbatim (StateSpace.f90:13-17): ADJ(bw,n) int32 1-based
  * (0 = successor outside the FSP, -1 = illegal), OFFDIAG(bw,n), DIAG(n)
@@ -99,9 +112,13 @@ int kfsp_update_matrix_ell(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, con
  * only the reductions over states (dot products, norms, WSUM) add their terms in another
  * order.  ON by default (option state_order = 0 switches it off); it applies to the next
  * kfsp_set_matrix_ell with the same n only, and not below option state_order_min states
- * (default 32768), with a communicator, or while generators are short-lived (the one being
+ * (default 32768) or while generators are short-lived (the one being
  * replaced saw fewer than option state_order_products products, default 48: reordering costs
- * about 20 of them at 10^6 states). */
+ * about 20 of them at 10^6 states).
+ * With a communicator the order is GLOBAL: every rank sorts all n keys (same input, same result), owns the
+ * block [row0, row0 + nloc) of the internal order, and a vector handed in or out as "this rank's block of the
+ * caller's order" passes through one all-gather of the whole vector (kfsp_set_vector / kfsp_get_vector /
+ * kfsp_spmv / kfsp_get_basis; a few times per FSP change, never per product). */
 int kfsp_set_state_coords(kfsp_ctx *ctx, int32_t n, int32_t ns, int32_t ld, const int32_t *state);
 /* 1 if the generator last set is held in the internal state order */
 int kfsp_state_order_active(const kfsp_ctx *ctx, int *active);
@@ -187,14 +204,20 @@ int kfsp_spmv_w(kfsp_ctx *ctx, double *y);
  *   drop_count the reference's DROP_COUNT (:476-495) = #(w < droptol) - #((A w) > 1e-8), its
  *              counting quirk included: the caller compacts iff drop_count / n > 0.1 (:497)
  *   n_flagged  states actually flagged: w < droptol and not (A w) > 1e-8
- * The flags stay on the device for the two calls below.  Single context only (-9 with a communicator). */
+ * The flags stay on the device for the two calls below.
+ * With a communicator (all ranks call): every rank sums the thresholds over its block, ONE all-reduce carries
+ * the sixteen sums of a pass; marks and counts per block, counts all-reduced, the flag bytes of all blocks
+ * all-gathered - every rank then holds the plan and the flags of ALL states (its host copy of the state
+ * lists needs them all). */
 int kfsp_drop_plan(kfsp_ctx *ctx, double dsum, double *droptol, int64_t *drop_count, int64_t *n_flagged);
 /* the flags of the last plan, one byte per state in the caller's order (1 = dropped) */
 int kfsp_drop_flags(kfsp_ctx *ctx, int64_t n, uint8_t *dropped);
 /* Compacts the resident w by those flags (kept entries keep their order, :500-546 for W); *n_new =
  * n - n_flagged.  The context then WAITS for the generator of the compacted FSP: the next
  * kfsp_set_matrix_ell / _csr must have n_new states and makes the compacted vector its w (do not
- * call kfsp_set_vector in between, it would replace it). */
+ * call kfsp_set_vector in between, it would replace it).
+ * With a communicator the compacted FSP has another partition: every rank assembles the whole vector (one
+ * all-gather), compacts it with the flags it holds, and takes its new block when the generator arrives. */
 int kfsp_drop_compact(kfsp_ctx *ctx, int64_t *n_new);
 
 /* ---- ONESTEP_EXTENDER on the device (StateSpace.f90:347-396 with ADD_STATE :136-246) ---- */

@@ -746,9 +746,27 @@ int kfsp_create(int device, kfsp_ctx **out)
     return 0;
 }
 
+int kfsp_create_group(int nranks, const int *devices, kfsp_ctx **out)
+{
+    try {
+        return kfsp::group_create(nranks, devices, out);
+    } catch (...) {
+        return 4000;
+    }
+}
+
+int kfsp_group_size(const kfsp_ctx *ctx, int *nranks)
+{
+    if (!ctx) return -1;
+    if (!nranks) return -2;
+    *nranks = ctx->group ? kfsp::group_size(ctx) : 1;
+    return 0;
+}
+
 int kfsp_destroy(kfsp_ctx *ctx)
 {
     if (!ctx) return 0;
+    if (ctx->group) return kfsp::group_destroy(ctx);
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->comm_stream) (void)hipStreamSynchronize(ctx->comm_stream);
@@ -796,6 +814,7 @@ int kfsp_comm_init(kfsp_ctx *ctx, int nranks, int rank, const void *id_bytes)
     if (nranks < 1) return fail(ctx, -2, "nranks < 1");
     if (rank < 0 || rank >= nranks) return fail(ctx, -3, "rank out of range");
     if (nranks > 1 && !id_bytes) return fail(ctx, -4, "null unique id");
+    if (ctx->group) return fail(ctx, -9, "a group context makes its own communicator");
     HIP_TRY(hipSetDevice(ctx->device));
     if (ctx->comm) {
         // (abort, not destroy: the usual reason to come here twice is a communicator that returned an
@@ -849,6 +868,7 @@ int kfsp_comm_init_loopback(kfsp_ctx *ctx, void *group, int rank)
     if (!group) return fail(ctx, -2, "null group");
     kfsp::LoopGroup *g = static_cast<kfsp::LoopGroup *>(group);
     if (rank < 0 || rank >= g->n) return fail(ctx, -3, "rank out of range");
+    if (ctx->group) return fail(ctx, -9, "a group context makes its own communicator");
     HIP_TRY(hipSetDevice(ctx->device));
     if (ctx->comm) {
         (void)ncclCommAbort(ctx->comm);   // as kfsp_comm_init: destroying a failed communicator can wait for ever
@@ -888,6 +908,7 @@ int kfsp_row_block(const kfsp_ctx *ctx, int64_t n, int64_t *row0, int64_t *nrows
 {
     if (!ctx) return -1;
     if (n < 0) return -2;
+    // (a group head owns all rows, like a one-rank context: nranks = 1, rank = 0)
     return kfsp_partition(n, ctx->nranks, ctx->rank, row0, nrows, nullptr) ? -2 : 0;
 }
 
@@ -902,6 +923,7 @@ static int set_matrix_ell_impl(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld,
         if (!adj) return fail(ctx, -5, "null adj");
         if (!offdiag) return fail(ctx, -6, "null offdiag");
         if (!diag) return fail(ctx, -7, "null diag");
+        if (ctx->group) return kfsp::group_update_matrix_ell(ctx, n, bw, ld, adj, offdiag, diag, (int32_t)keep);
         HIP_TRY(hipSetDevice(ctx->device));
         auto t0 = std::chrono::steady_clock::now();
         ctx->use_box = false;
@@ -989,6 +1011,7 @@ int kfsp_set_matrix_csr(kfsp_ctx *ctx, int64_t n, int64_t row0, int64_t nrows, c
     return no_throw(ctx, [&]() -> int {
         if (!ctx) return -1;
         if (n < 1 || n > 2147483647LL - 512) return fail(ctx, -2, "n out of range");
+        if (ctx->group) return kfsp::group_set_matrix_csr(ctx, n, row0, nrows, rowptr, col, val);
         HIP_TRY(hipSetDevice(ctx->device));
         ctx->perm_on = false;
         ctx->perm_pending_n = 0;
@@ -1052,6 +1075,7 @@ int kfsp_set_matrix_box(kfsp_ctx *ctx, int32_t ns, const int32_t *dims, int32_t 
         if (nr < 1 || nr > kfsp::kBoxMaxR) return fail(ctx, -4, "1 <= nr <= 16");
         if (!stoich || !ndep || !dep_species) return fail(ctx, -5, "null reaction description");
         if (!tables) return fail(ctx, -8, "null tables");
+        if (ctx->group) return kfsp::group_set_matrix_box(ctx, ns, dims, nr, stoich, ndep, dep_species, tables);
         int64_t n = 1, stride[kfsp::kBoxMaxS];
         for (int s = 0; s < ns; ++s) {
             if (dims[s] < 1) return fail(ctx, -3, "dims must be positive");
@@ -1245,6 +1269,7 @@ int kfsp_set_state_coords(kfsp_ctx *ctx, int32_t n, int32_t ns, int32_t ld, cons
         if (ns < 1) return fail(ctx, -3, "ns < 1");
         if (ld < ns) return fail(ctx, -4, "ld < ns");
         if (!state) return fail(ctx, -5, "null state");
+        if (ctx->group) return kfsp::group_set_state_coords(ctx, n, ns, ld, state);
         ctx->perm_pending_n = 0;
         if (!ctx->opt_state_order || n < ctx->opt_state_order_min) return 0;
         // Sorting, relabelling and the extra upload cost about as much as 20 products (at 10^6 states)
@@ -1266,6 +1291,7 @@ int kfsp_state_order_active(const kfsp_ctx *ctx, int *active)
 {
     if (!ctx) return -1;
     if (!active) return -2;
+    if (ctx->group) return kfsp::group_state_order_active(ctx, active);
     *active = ctx->perm_on ? 1 : 0;
     return 0;
 }
@@ -1273,6 +1299,7 @@ int kfsp_state_order_active(const kfsp_ctx *ctx, int *active)
 int kfsp_matrix_info(const kfsp_ctx *ctx, int64_t *nrows, int64_t *slots, int64_t *nnz)
 {
     if (!ctx) return -1;
+    if (ctx->group) return kfsp::group_matrix_info(ctx, nrows, slots, nnz);
     if (nrows) *nrows = ctx->nloc;
     if (slots) *slots = ctx->use_box ? 0 : (ctx->use_dia ? (int64_t)ctx->nd * ctx->dia_ld : ctx->slots);
     if (nnz) *nnz = ctx->nnz;
@@ -1284,6 +1311,7 @@ int kfsp_matrix_bytes(const kfsp_ctx *ctx, int force_sell, int64_t *bytes)
     if (!ctx) return -1;
     if (!bytes) return -3;
     if (ctx->ldv == 0) return -1;
+    if (ctx->group) return kfsp::group_matrix_bytes(ctx, force_sell, bytes);
     const int64_t rows = ctx->nchunks * kChunk;
     int64_t b = rows * 24;                                    // diag, x (once), y
     if (ctx->use_box && !force_sell) {
@@ -1310,6 +1338,7 @@ int kfsp_set_vector(kfsp_ctx *ctx, int64_t nlocal, const double *w)
 {
     if (!ctx) return -1;
     if (ctx->ldv == 0) return fail(ctx, -1, "no matrix set");
+    if (ctx->group) return kfsp::group_set_vector(ctx, nlocal, w);
     if (nlocal != ctx->nloc) return fail(ctx, -2, "nlocal is not this rank's block size");
     if (!w && nlocal > 0) return fail(ctx, -3, "null w");
     HIP_TRY(hipSetDevice(ctx->device));
@@ -1324,6 +1353,7 @@ int kfsp_set_vector(kfsp_ctx *ctx, int64_t nlocal, const double *w)
 int kfsp_get_vector(kfsp_ctx *ctx, int64_t nlocal, double *w)
 {
     if (!ctx) return -1;
+    if (ctx->group) return kfsp::group_get_vector(ctx, nlocal, w);
     if (nlocal != ctx->nloc) return fail(ctx, -2, "nlocal is not this rank's block size");
     if (!w && nlocal > 0) return fail(ctx, -3, "null w");
     HIP_TRY(hipSetDevice(ctx->device));
@@ -1337,6 +1367,7 @@ int kfsp_begin_step(kfsp_ctx *ctx, double *beta)
     if (!ctx) return -1;
     if (ctx->ldv == 0) return fail(ctx, -1, "no matrix set");
     if (!beta) return fail(ctx, -2, "null beta");
+    if (ctx->group) return kfsp::group_begin_step(ctx, beta);
     PhaseTimer timer(ctx, KFSP_T_BEGIN);
     static const bool trace = std::getenv("KFSP_TRACE_BEGIN") != nullptr;   // diagnostics: profiles/begin_step_trace.sh
     const auto t0 = std::chrono::steady_clock::now();
@@ -1375,6 +1406,7 @@ int kfsp_arnoldi(kfsp_ctx *ctx, int m, int jold, int qiop, double break_tol, dou
     if (!H) return fail(ctx, -6, "null H");
     if (ldh < m + 2) return fail(ctx, -7, "ldh < m+2");
     if (!mbrkdwn || !k1 || !avnorm) return fail(ctx, -8, "null output");
+    if (ctx->group) return kfsp::group_arnoldi(ctx, m, jold, qiop, break_tol, H, ldh, mbrkdwn, k1, avnorm);
     PhaseTimer timer(ctx, KFSP_T_ARNOLDI);
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
@@ -1533,6 +1565,7 @@ int kfsp_combine(kfsp_ctx *ctx, int mx, double beta, const double *y, double *ws
     if (mx < 1 || mx > ctx->opt_mmax + 2) return fail(ctx, -2, "bad mx");
     if (!y) return fail(ctx, -4, "null y");
     if (!wsum) return fail(ctx, -5, "null wsum");
+    if (ctx->group) return kfsp::group_combine(ctx, mx, beta, y, wsum);
     PhaseTimer timer(ctx, KFSP_T_COMBINE);
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
@@ -1565,6 +1598,7 @@ int kfsp_restore_w(kfsp_ctx *ctx, double beta)
 {
     if (!ctx) return -1;
     if (ctx->ldv == 0) return fail(ctx, -1, "no matrix set");
+    if (ctx->group) return kfsp::group_restore_w(ctx, beta);
     HIP_TRY(hipSetDevice(ctx->device));
     launch_scale_copy(vec_grid(ctx), act_pairs(ctx), vcol(ctx, 0), ctx->d_sq.p + 1, beta, ctx->d_w.p, ctx->stream);
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -1591,6 +1625,7 @@ int kfsp_spmv(kfsp_ctx *ctx, const double *x, double *y)
     if (!ctx) return -1;
     if (ctx->ldv == 0) return fail(ctx, -1, "no matrix set");
     if (!x) return fail(ctx, -2, "null x");
+    if (ctx->group) return kfsp::group_spmv(ctx, x, y);
     if (!y && ctx->nloc > 0) return fail(ctx, -3, "null y");
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
@@ -1613,6 +1648,7 @@ int kfsp_spmv_w(kfsp_ctx *ctx, double *y)
 {
     if (!ctx) return -1;
     if (ctx->ldv == 0) return fail(ctx, -1, "no matrix set");
+    if (ctx->group) return kfsp::group_spmv_w(ctx, y);
     if (!y && ctx->nloc > 0) return fail(ctx, -2, "null y");
     HIP_TRY(hipSetDevice(ctx->device));
     const double *src = ctx->d_w.p;
@@ -1643,6 +1679,8 @@ int kfsp_onestep(kfsp_ctx *ctx, int32_t ns, int32_t nr, const int32_t *stoich, i
         if (max_count < 1) return fail(ctx, -10, "max_count < 1");
         if (capacity < n) return fail(ctx, -11, "capacity < n");
         if (!n_new || !state_new || !adj_out) return fail(ctx, -12, "null output");
+        if (ctx->group)
+            return kfsp::group_onestep(ctx, ns, nr, stoich, n, state, ld_state, adj, ld_adj, max_count, capacity, n_new, state_new, adj_out);
         HIP_TRY(hipSetDevice(ctx->device));
         const auto t0 = std::chrono::steady_clock::now();
         const int rc = kfsp::onestep_device(ctx, ns, nr, stoich, n, state, ld_state, adj, ld_adj, max_count, capacity, n_new,
@@ -1658,6 +1696,7 @@ int kfsp_drop_plan(kfsp_ctx *ctx, double dsum, double *droptol, int64_t *drop_co
     if (ctx->ldv == 0) return fail(ctx, -1, "no matrix set");
     if (!(dsum > 0.0)) return fail(ctx, -2, "dsum must be positive (FIND_DROPTOL would not terminate)");
     if (!droptol || !drop_count || !n_flagged) return fail(ctx, -3, "null output");
+    if (ctx->group) return kfsp::group_drop_plan(ctx, dsum, droptol, drop_count, n_flagged);
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const int64_t n = ctx->n;
@@ -1740,6 +1779,7 @@ int kfsp_drop_plan(kfsp_ctx *ctx, double dsum, double *droptol, int64_t *drop_co
 int kfsp_drop_flags(kfsp_ctx *ctx, int64_t n, uint8_t *dropped)
 {
     if (!ctx) return -1;
+    if (ctx->group) return kfsp::group_drop_flags(ctx, n, dropped);
     if (!ctx->drop_planned || ctx->drop_n != ctx->n) return fail(ctx, -1, "no drop plan for the current FSP");
     if (n != ctx->n) return fail(ctx, -2, "n is not the size of the planned FSP");
     if (!dropped) return fail(ctx, -3, "null flags");
@@ -1752,6 +1792,7 @@ int kfsp_drop_flags(kfsp_ctx *ctx, int64_t n, uint8_t *dropped)
 int kfsp_drop_compact(kfsp_ctx *ctx, int64_t *n_new)
 {
     if (!ctx) return -1;
+    if (ctx->group) return n_new ? kfsp::group_drop_compact(ctx, n_new) : -2;
     if (!ctx->drop_planned || ctx->drop_n != ctx->n) return fail(ctx, -1, "no drop plan for the current FSP");
     if (!n_new) return fail(ctx, -2, "null n_new");
     HIP_TRY(hipSetDevice(ctx->device));
@@ -1790,6 +1831,7 @@ static int reduce_w(kfsp_ctx *ctx, int squared, double *out)
     if (!ctx) return -1;
     if (ctx->ldv == 0) return fail(ctx, -1, "no matrix set");
     if (!out) return fail(ctx, -2, "null out");
+    if (ctx->group) return kfsp::group_reduce_w(ctx, squared, out);
     HIP_TRY(hipSetDevice(ctx->device));
     double *part = next_partial(ctx);
     const int g = vec_grid(ctx);
@@ -1810,6 +1852,7 @@ int kfsp_get_basis(kfsp_ctx *ctx, int j, int64_t nlocal, double *v)
 {
     if (!ctx) return -1;
     if (ctx->ldv == 0) return fail(ctx, -1, "no matrix set");
+    if (ctx->group) return kfsp::group_get_basis(ctx, j, nlocal, v);
     if (j < 1 || j > ctx->opt_mmax + 2) return fail(ctx, -2, "bad column");
     if (nlocal != ctx->nloc) return fail(ctx, -3, "nlocal is not this rank's block size");
     if (!v && nlocal > 0) return fail(ctx, -4, "null v");
@@ -1857,8 +1900,9 @@ int kfsp_spmv_bench(kfsp_ctx *ctx, int reps, int variant, float *ms_total)
     if (ctx->ldv == 0) return fail(ctx, -1, "no matrix set");
     if (reps < 1) return fail(ctx, -2, "reps < 1");
     if (variant != 0 && variant != 2) return fail(ctx, -3, "unknown variant (0 auto, 2 SELL)");
-    if (variant == 2 && !ctx->have_sell) return fail(ctx, -3, "no SELL image resident (banded matrix built on the device)");
     if (!ms_total) return fail(ctx, -4, "null ms_total");
+    if (ctx->group) return kfsp::group_spmv_bench(ctx, reps, variant, ms_total);
+    if (variant == 2 && !ctx->have_sell) return fail(ctx, -3, "no SELL image resident (banded matrix built on the device)");
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const double *src = vcol(ctx, 0);
@@ -1879,6 +1923,7 @@ int kfsp_selftest_stream(kfsp_ctx *ctx, int64_t nbytes, int elem_bytes, int reps
     if (nbytes < 4096 || nbytes % 4096) return fail(ctx, -2, "nbytes must be a positive multiple of 4096");
     if (elem_bytes != 4 && elem_bytes != 8 && elem_bytes != 16) return fail(ctx, -3, "elem_bytes must be 4, 8 or 16");
     if (reps < 1) return fail(ctx, -4, "reps < 1");
+    if (ctx->group) return fail(ctx, -9, "not available on a group context");
     HIP_TRY(hipSetDevice(ctx->device));
     DevBuf<char> buf;
     HIP_TRY(buf.reserve((size_t)nbytes, true));
@@ -1905,6 +1950,7 @@ int kfsp_get_timers(kfsp_ctx *ctx, double *ms, int reset)
 {
     if (!ctx) return -1;
     if (!ms) return -2;
+    if (ctx->group) return kfsp::group_get_timers(ctx, ms, reset);
     for (int i = 0; i < KFSP_T_COUNT; ++i) ms[i] = ctx->t_ms[i];
     if (reset)
         for (double &t : ctx->t_ms) t = 0.0;
@@ -1915,6 +1961,7 @@ int kfsp_set_option(kfsp_ctx *ctx, const char *name, int64_t value)
 {
     if (!ctx) return -1;
     if (!name) return -2;
+    if (ctx->group) return kfsp::group_set_option(ctx, name, value);
     const std::string k(name);
     if (k == "grid_blocks") ctx->opt_grid = value;
     else if (k == "vec_grid_blocks") ctx->opt_vgrid = value;

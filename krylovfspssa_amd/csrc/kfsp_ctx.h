@@ -124,7 +124,14 @@ struct LoopGroup {
 using kfsp::DevBuf;
 using kfsp::kMaxDiag;
 
+namespace kfsp {
+struct Group;
+}
+
 struct kfsp_ctx {
+    // a head handle over a row partition driven by ONE host thread (kfsp_create_group, kfsp_group.cpp): no device
+    // resources of its own; every entry point fans out to the ranks' contexts
+    kfsp::Group *group = nullptr;
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -261,6 +268,39 @@ struct kfsp_ctx {
 };
 
 namespace kfsp {
+// group contexts (kfsp_group.cpp): what each entry point of include/kfsp.h does when it is handed a head
+int group_create(int nranks, const int *devices, kfsp_ctx **out);
+int group_destroy(kfsp_ctx *h);
+int group_size(const kfsp_ctx *h);
+int group_set_option(kfsp_ctx *h, const char *name, int64_t value);
+int group_update_matrix_ell(kfsp_ctx *h, int32_t n, int32_t bw, int32_t ld, const int32_t *adj, const double *offdiag,
+                            const double *diag, int32_t n_unchanged);
+int group_set_matrix_csr(kfsp_ctx *h, int64_t n, int64_t row0, int64_t nrows, const int64_t *rowptr, const int32_t *col,
+                         const double *val);
+int group_set_matrix_box(kfsp_ctx *h, int32_t ns, const int32_t *dims, int32_t nr, const int32_t *stoich, const int32_t *ndep,
+                         const int32_t *dep_species, const double *tables);
+int group_set_state_coords(kfsp_ctx *h, int32_t n, int32_t ns, int32_t ld, const int32_t *state);
+int group_state_order_active(const kfsp_ctx *h, int *active);
+int group_matrix_info(const kfsp_ctx *h, int64_t *nrows, int64_t *slots, int64_t *nnz);
+int group_matrix_bytes(const kfsp_ctx *h, int force_sell, int64_t *bytes);
+int group_set_vector(kfsp_ctx *h, int64_t n, const double *w);
+int group_get_vector(kfsp_ctx *h, int64_t n, double *w);
+int group_begin_step(kfsp_ctx *h, double *beta);
+int group_arnoldi(kfsp_ctx *h, int m, int jold, int qiop, double break_tol, double *H, int ldh, int *mbrkdwn, int *k1, double *avnorm);
+int group_combine(kfsp_ctx *h, int mx, double beta, const double *y, double *wsum);
+int group_restore_w(kfsp_ctx *h, double beta);
+int group_spmv(kfsp_ctx *h, const double *x, double *y);
+int group_spmv_w(kfsp_ctx *h, double *y);
+int group_onestep(kfsp_ctx *h, int32_t ns, int32_t nr, const int32_t *stoich, int32_t n, const int32_t *state, int32_t ld_state,
+                  const int32_t *adj, int32_t ld_adj, int32_t max_count, int32_t capacity, int32_t *n_new, int32_t *state_new,
+                  int32_t *adj_out);
+int group_drop_plan(kfsp_ctx *h, double dsum, double *droptol, int64_t *drop_count, int64_t *n_flagged);
+int group_drop_flags(kfsp_ctx *h, int64_t n, uint8_t *dropped);
+int group_drop_compact(kfsp_ctx *h, int64_t *n_new);
+int group_reduce_w(kfsp_ctx *h, int squared, double *out);
+int group_get_basis(kfsp_ctx *h, int j, int64_t n, double *v);
+int group_spmv_bench(kfsp_ctx *h, int reps, int variant, float *ms_total);
+int group_get_timers(kfsp_ctx *h, double *ms, int reset);
 // generator build on the device from the reference layout (kfsp_build.hip)
 // keep: leading columns whose OFFDIAG / DIAG are resident and unchanged (only the rest is uploaded)
 int build_from_ell_device(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, const int32_t *adj,

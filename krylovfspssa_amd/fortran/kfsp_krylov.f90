@@ -183,13 +183,29 @@ CONTAINS
     CHARACTER(LEN=16) :: ENV
     CHARACTER(LEN=512) :: OPTS
     INTEGER :: P0, P1, PE
-    INTEGER :: DEV, L, STAT, RC
+    INTEGER :: DEV, L, STAT, RC, NRANKS
+    INTEGER(C_INT) :: DEVS(64)
     INTEGER(C_INT64_T) :: V8
     IF (C_ASSOCIATED(CTX)) RETURN
     DEV = 0
     CALL GET_ENVIRONMENT_VARIABLE('KFSP_DEVICE', ENV, L, STAT)
     IF (STAT == 0 .AND. L > 0) READ(ENV(1:L), *, IOSTAT=STAT) DEV
-    RC = KFSP_CREATE(INT(DEV, C_INT), CTX)
+    ! KFSP_NRANKS = P > 1: the FSP is row-partitioned over P contexts behind one head handle (a group context,
+    ! include/kfsp.h); this program stays what it is - one thread, one copy of the state space.  KFSP_DEVICES
+    ! = "d1,d2,..." names their devices (distinct devices: RCCL over xGMI); without it all P sit on KFSP_DEVICE
+    ! and exchange through the loop-back transport (one-GPU rehearsal of the partition).
+    NRANKS = 1
+    CALL GET_ENVIRONMENT_VARIABLE('KFSP_NRANKS', ENV, L, STAT)
+    IF (STAT == 0 .AND. L > 0) READ(ENV(1:L), *, IOSTAT=STAT) NRANKS
+    IF (NRANKS > 1) THEN
+       NRANKS = MIN(NRANKS, SIZE(DEVS))
+       DEVS = DEV
+       CALL GET_ENVIRONMENT_VARIABLE('KFSP_DEVICES', OPTS, L, STAT)
+       IF (STAT == 0 .AND. L > 0) READ(OPTS(1:L), *, IOSTAT=STAT) DEVS(1:NRANKS)
+       RC = KFSP_CREATE_GROUP(INT(NRANKS, C_INT), DEVS, CTX)
+    ELSE
+       RC = KFSP_CREATE(INT(DEV, C_INT), CTX)
+    ENDIF
     IF (RC /= 0) THEN
        PRINT *, 'KFSP: NO USABLE HIP DEVICE (kfsp_create returned', RC, '); THE SOLVER HAS NO CPU PATH.'
        STOP 2

@@ -41,6 +41,8 @@ def load_library():
     sig = {
         "kfsp_create": [C.c_int, C.POINTER(vp)],
         "kfsp_destroy": [vp],
+        "kfsp_create_group": [C.c_int, vp, C.POINTER(vp)],
+        "kfsp_group_size": [vp, C.POINTER(C.c_int)],
         "kfsp_abi_version": [],
         "kfsp_comm_unique_id": [vp],
         "kfsp_comm_init": [vp, C.c_int, C.c_int, vp],
@@ -186,13 +188,23 @@ def run_loopback_ranks(nranks, body, device=0):
 class KfspContext:
     """One device context = one rank's share of the solver workspace."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, group=None):
+        """group = P (int: P ranks, all on `device`, loop-back) or a list of device ids (distinct: RCCL):
+        a head handle over a row partition driven by this one thread (kfsp_create_group); it behaves like
+        a one-rank context with whole vectors in and out."""
         self._lib = load_library()
         self._h = C.c_void_p()
-        rc = self._lib.kfsp_create(int(device), C.byref(self._h))
+        if group is not None:
+            devs = [int(device)] * int(group) if isinstance(group, int) else [int(d) for d in group]
+            arr = (C.c_int * len(devs))(*devs)
+            rc = self._lib.kfsp_create_group(len(devs), arr, C.byref(self._h))
+            self.group_size = len(devs)
+        else:
+            rc = self._lib.kfsp_create(int(device), C.byref(self._h))
+            self.group_size = 1
         if rc:
             self._h = C.c_void_p()
-            raise KfspError(f"kfsp_create(device={device}) -> {rc}: no usable HIP device; "
+            raise KfspError(f"kfsp_create(device={device}, group={group}) -> {rc}: no usable HIP device; "
                             "the exp(tA)v hot path has no CPU fallback")
         self.n = 0
         self.nranks, self.rank = 1, 0

@@ -323,6 +323,35 @@ def test_cme_solve_adaptive_fsp(dump, tmp_path, fixture, case):
         assert np.abs(d["vector"] - g["vector"]).sum() < 1e-9
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("state_order", [0, 1])
+@pytest.mark.parametrize("ranks", [2, 3])
+@pytest.mark.parametrize("fixture,case,exact", [("goutsias_input_T40", "goutsias_input", True),
+                                                ("repressilator_input_T1", "repressilator_input", True),
+                                                ("toggle_input_T2", "toggle_input", False)])
+def test_cme_solve_on_a_row_partition(dump, tmp_path, fixture, case, exact, ranks, state_order):
+    """CME_SOLVE itself over P ranks (KFSP_NRANKS = P: the Fortran host creates a group context - P contexts of a
+    loop-back group on the one GPU): Arnoldi passes with partitioned rows and all-reduced scalars, DROP_STATES
+    decided per block (kfsp_drop_plan under the partition), the compacted vector re-partitioned, SSA / one-step
+    expansions on the host's one state space with the generator of every new FSP uploaded block by block - also
+    with the device keeping the GLOBAL lexicographic state order.  The run reproduces the single-rank step log,
+    the state list bit for bit, probabilities to l1 < 1e-10; where the single-rank run reproduces the
+    reference's fixture exactly, so does this one."""
+    order = {"KFSP_STATE_ORDER": str(state_order), "KFSP_STATE_ORDER_MIN": "1", "KFSP_STATE_ORDER_PRODUCTS": "0"}
+    g, d1, log1 = _solve(dump, tmp_path, fixture, case, env=order)
+    g, d, log = _solve(dump, tmp_path, fixture, case, env=dict(order, KFSP_NRANKS=str(ranks)))
+    assert np.array_equal(log["step_n"], log1["step_n"])
+    assert np.array_equal(log["step_tau"], log1["step_tau"]) and np.array_equal(log["step_m"], log1["step_m"])
+    assert int(log["n_ssa"]) == int(log1["n_ssa"]) and d["n"] == d1["n"]
+    assert np.array_equal(d["state"], d1["state"]) and np.array_equal(d["adj"], d1["adj"])
+    assert np.abs(log["wsum"] - log1["wsum"]).max() < 1e-10
+    assert np.abs(d["vector"] - d1["vector"]).sum() < 1e-10
+    if exact:
+        assert np.array_equal(log["step_tau"], g["step_tau"]) and np.array_equal(log["step_n"], g["step_n"])
+        assert np.array_equal(d["state"], g["state"]) and np.array_equal(d["adj"], g["adj"])
+        assert np.abs(d["vector"] - g["vector"]).sum() < 1e-10
+
+
 def test_compute_rkey_returns_the_reference_key_changes(tmp_path):
     """COMPUTE_RKEY (StateSpace.f90:635-669) of our STATESPACE: for every reaction of the Goutsias
     model the integers the reference's big-integer routine returns (restated here with Python

@@ -50,15 +50,18 @@ def test_find_droptol_thresholds(golden_dir):
 DROP_CASES = [("toggle", 20, 1e-6), ("goutsias", 16, 1e-12), ("repressilator", 10, 1e-4)]
 
 
+@pytest.mark.parametrize("ranks", [1, 2, 3])
 @pytest.mark.parametrize("state_order", [0, 1])
 @pytest.mark.parametrize("name,k,dsum", DROP_CASES)
-def test_drop_decision_and_compaction_match_the_reference(golden_dir, name, k, dsum, state_order):
+def test_drop_decision_and_compaction_match_the_reference(golden_dir, name, k, dsum, state_order, ranks):
     """The FSP of `k` one-step sweeps as the reference assembles it (fixture assembly_*), the
     decaying vector of oracle/ref_dump.f90 DO_DROP, DROP_STATES on the device: the states kept and
     the compacted vector are what the reference leaves behind (fixture drop_*: its list starts
     with the kept states in order, its vector is the compacted W), the drop count obeys the
     reference's counting rule, and after kfsp_set_matrix_ell of the compacted FSP the resident
-    vector IS the compacted one - also with the device keeping its own state order."""
+    vector IS the compacted one - also with the device keeping its own state order, and also with the FSP
+    row-partitioned over 2 and 3 ranks (a group context over a loop-back group: per-rank threshold sums + one
+    all-reduce, flags per block all-gathered, the compacted vector re-partitioned)."""
     from krylovfspssa_amd import KfspContext
     from oracle import make_golden as MG
     a = np.load(os.path.join(golden_dir, f"assembly_{name}_k{k}.npz"))
@@ -68,7 +71,7 @@ def test_drop_decision_and_compaction_match_the_reference(golden_dir, name, k, d
     i = np.arange(1, n + 1, dtype=np.float64)
     w = 10.0 ** (-2.0 - 18.0 * (i - 1.0) / max(n - 1, 1))
     w[6::7] *= 1.0e3
-    with KfspContext(0) as c:
+    with KfspContext(0, group=ranks if ranks > 1 else None) as c:
         if state_order:
             c.set_option("state_order", 1)
             c.set_option("state_order_min", 1)
