@@ -353,6 +353,22 @@ def main():
     ms_events = max_over_ranks(ms_events)
     value = args.steps * b_alg_global / elapsed / 1e9
     kern_ms = ms_events / args.steps
+    # the exchange of the source vector alone, per rank (what every product of the partition pays before its rows)
+    exch = None
+    if world > 1 or args.force_comm:
+        ex_ms, ex_bytes = ctx.exchange_bench(args.steps)
+        ex_ms /= args.steps
+        t = torch.tensor([ex_ms, float(ex_bytes)], dtype=torch.float64, device="cuda")
+        if world > 1:
+            allv = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(allv, t)
+        else:
+            allv = [t]
+        exch = {"per_rank_exchange_ms": [round(float(v[0]), 5) for v in allv],
+                "per_rank_bytes_in": [int(v[1]) for v in allv],
+                "per_rank_link_GBps": [round(float(v[1]) / max(float(v[0]), 1e-9) / 1e6, 2) for v in allv],
+                "what": "the exchange that precedes every product (halo strips or all-gather), timed alone with HIP events on "
+                        "each rank; link GB/s = bytes a rank receives per exchange / that time"}
 
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     plain_run = world == 1 and not args.opt and not args.force_comm and args.variant in (0, 2) and not args.matrix_free
@@ -429,6 +445,7 @@ def main():
         "self_check": {"ok": bool(check_ok), "max_rel_err": check_err,
                        "what": "the timed product (same context, same exchange) vs numpy on 2.5k sampled rows per rank"},
         "roofline": roof,
+        "exchange": exch,
         "input_generation_s": round(t_gen, 2),
     }
 

@@ -155,8 +155,17 @@ int kfsp_matrix_info(const kfsp_ctx *ctx, int64_t *nrows, int64_t *slots, int64_
  * stored generator (banded: 8 B per stored diagonal entry, minus the empty 128-row segments the
  * masked kernel skips, plus its mask words; SELL-64: 12 B per slot incl. padding plus chunk
  * offsets) + 24 B per row (DIAG, x once, y).  x re-fetches are not in it; the rocprofv3 counters
- * are.  force_sell = 1: the figure for kfsp_spmv_bench variant 2. */
+ * are.  force_sell = 1: the figure for kfsp_spmv_bench variant 2; 3: for variant 3 (plain columns).
+ * SELL-64 with dictionary-coded columns (format 5): coded chunks count 8 B per entry + their code words + their
+ * offset tables (in 64-byte lines) instead of 12 B per entry. */
 int kfsp_matrix_bytes(const kfsp_ctx *ctx, int force_sell, int64_t *bytes);
+/* what the device holds and how a partitioned product exchanges its source vector, v[8]:
+ *   v[0] kernel format: 0 SELL-64, 1 banded, 2 banded with group masks, 3 / 4 matrix-free box (interpreted / fast path),
+ *        5 SELL-64 with dictionary-coded columns (option "sell_code")
+ *   v[1] exchange: 0 none (no communicator), 1 halo strips, 2 all-gather of the whole vector;  v[2] halo rows
+ *   v[3] reach max |col - row| of the local SELL rows (-1: not a SELL generator)
+ *   v[4] chunks with coded columns, v[5] chunks, v[6] 64-bit code words, v[7] internal state order active */
+int kfsp_layout_info(const kfsp_ctx *ctx, int64_t *v);
 /* global number of states of the generator last set (FSP%SIZE) */
 int kfsp_num_states(const kfsp_ctx *ctx, int64_t *n);
 
@@ -376,8 +385,14 @@ int kfsp_expv_fixed(kfsp_ctx *ctx, int m, double tau, int nsteps, double *wsums)
  * stream, bracketed by HIP events: *ms_total = elapsed GPU time.  With
  * nranks > 1 every launch is preceded by the all-gather of the source slab,
  * as in the solver.  variant: 0 = the format the library chose (banded DIA when
- * the rows allow it, else SELL-64), 2 = SELL-64 even when DIA is active. */
+ * the rows allow it, else SELL-64), 2 = SELL-64 even when DIA is active, 3 = SELL-64 reading its plain
+ * 4-byte columns even when the dictionary-coded form is active (A/B of format 5 against format 0). */
 int kfsp_spmv_bench(kfsp_ctx *ctx, int reps, int variant, float *ms_total);
+
+/* reps exchanges of the source vector ALONE (what precedes every product of a partitioned generator: halo strips
+ * or the all-gather of the whole vector), bracketed by HIP events; *bytes_in = bytes this rank receives per
+ * exchange (0 and 0 ms without a communicator).  bench.py reports exchange time and link GB/s from it. */
+int kfsp_exchange_bench(kfsp_ctx *ctx, int reps, float *ms_total, int64_t *bytes_in);
 
 /* diagnostics: reps launches that read exactly nbytes from a scratch buffer
  * with elem_bytes (4, 8, 16) per lane in the SpMV's access shape; used to
@@ -399,7 +414,10 @@ int kfsp_add_timer(kfsp_ctx *ctx, int phase, double ms);
 /* tuning knobs (name/value); unknown name -> -2: "grid_blocks",
  * "vec_grid_blocks", "nt_loads", "format", "fused_ortho",
  * "host_build", "halo", "halo_p2p" (1: halo strips travel between neighbouring ranks only, ncclSend/ncclRecv straight into the
- * column margins; 0, default: one all-gather of every rank's strips), "overlap", "small_kernel", "small_lds", "dia_mask", "m_max" (largest Krylov dimension the basis is allocated for, default and maximum 100 = M_MAX of
+ * column margins; 0, default: one all-gather of every rank's strips), "halo_sell" (0: SELL generators always all-gather the whole source
+ * vector; 1, default: a SELL generator whose reach max |col - row| is at most one block - bounded under the internal state order -
+ * exchanges halo strips like a banded one), "overlap", "small_kernel", "small_lds", "dia_mask", "sell_code" (dictionary-coded SELL columns, DESIGN.md 4.1c: -1 auto = under the internal state order,
+ * 0 never, 1 always try), "m_max" (largest Krylov dimension the basis is allocated for, default and maximum 100 = M_MAX of
  * KrylovSolver.f90:47; a smaller value saves 8 * rows bytes per column - 90 GB at 10^8 states - and makes kfsp_arnoldi refuse
  * a larger m; kfsp_dgexpv needs the default), "box_store" (1: kfsp_set_matrix_box stores the generator as diagonals), "box_generic" (1: matrix-free boxes take
  * the run-time interpreted kernel even when the single-factor fast path applies), "state_order" (1: use

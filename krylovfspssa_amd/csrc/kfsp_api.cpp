@@ -123,7 +123,8 @@ double *next_partial(kfsp_ctx *c)
 
 SellDev sell_of(const kfsp_ctx *c)
 {
-    return SellDev{c->nloc, c->nchunks, c->d_off.p, c->d_col.p, c->d_val.p, c->d_diag.p};
+    return SellDev{c->nloc, c->nchunks, c->d_off.p, c->d_col.p, c->d_val.p, c->d_diag.p,
+                   c->d_dtab.p, c->d_dtlen.p, c->d_code.p, c->d_codeoff.p};
 }
 
 // generator part of the product kernel's arguments
@@ -248,7 +249,7 @@ int trips_grid(int64_t trips, int64_t cap)
 // exchanged on the communication stream; the few boundary trips follow once
 // the halo has landed.  p1/p2 receive the block partials (modes 1-3).
 int run_product(kfsp_ctx *ctx, int mode, SpmvArgs a, const double *src, bool src_is_global, Pending *p1, Pending *p2,
-                bool force_sell = false)
+                bool force_sell = false, bool force_plain_sell = false)
 {
     hipStream_t st = ctx->stream;
     ++ctx->prod_count;
@@ -267,12 +268,16 @@ int run_product(kfsp_ctx *ctx, int mode, SpmvArgs a, const double *src, bool src
     double *P2 = mode == 3 ? next_partial(ctx) : nullptr;
     a.row0 = ctx->row0;
 
+    const int fmt = (ctx->use_box && dia) ? (ctx->box_fast && !ctx->opt_box_generic ? 4 : 3)
+                                          : (dia ? (ctx->dia_masked ? 2 : 1) : (ctx->sell_coded && !force_plain_sell ? 5 : 0));
     const int64_t H = ctx->halo, L = ctx->L;
+    const int64_t trip_rows = dia ? 128 : 64;
     int64_t lo = 0, hi = 0;
-    bool split = !src_is_global && dia && ctx->use_halo && ctx->opt_overlap != 0 && ctx->comm_stream != nullptr;
+    // (a SELL generator takes part when its reach is bounded - the internal state order - and the halo mode was agreed)
+    bool split = !src_is_global && !force_sell && ctx->use_halo && ctx->opt_overlap != 0 && ctx->comm_stream != nullptr;
     if (split) {
-        lo = (H + 127) / 128;                        // first trip whose rows all lie >= H
-        hi = std::min<int64_t>((L - H) / 128, trips); // trips [lo, hi) end below L - H
+        lo = (H + trip_rows - 1) / trip_rows;                        // first trip whose rows all lie >= H
+        hi = std::min<int64_t>((L - H) / trip_rows, trips);          // trips [lo, hi) end below L - H
         // Three launches and two cross-stream waits cost ~10-15 us; that only pays once
         // the product itself is several times longer (>= ~2M rows per rank), or when
         // the caller insists (overlap = 2, used by the tests)
@@ -291,7 +296,7 @@ int run_product(kfsp_ctx *ctx, int mode, SpmvArgs a, const double *src, bool src
         a.trip_split = INT64_MAX;
         a.trip_jump = 0;
         const int g = trips_grid(trips, cap);
-        launch_spmv(mode, g, a, nt, (ctx->use_box && dia) ? (ctx->box_fast && !ctx->opt_box_generic ? 4 : 3) : (dia ? (ctx->dia_masked ? 2 : 1) : 0), st, ctx->box_lds_bytes);
+        launch_spmv(mode, g, a, nt, fmt, st, ctx->box_lds_bytes);
         if (p1) *p1 = Pending{P1, g};
         if (p2) *p2 = Pending{P2, g};
         return 0;
@@ -312,7 +317,7 @@ int run_product(kfsp_ctx *ctx, int mode, SpmvArgs a, const double *src, bool src
         a.trip_end = e;
         a.trip_split = split;
         a.trip_jump = jump;
-        launch_spmv(mode, g, a, nt, ctx->use_box ? (ctx->box_fast && !ctx->opt_box_generic ? 4 : 3) : (ctx->dia_masked ? 2 : 1), st, ctx->box_lds_bytes);
+        launch_spmv(mode, g, a, nt, fmt, st, ctx->box_lds_bytes);
         used += g;
     };
     launch_range(lo, hi, INT64_MAX, 0, std::min<int64_t>(cap, kMaxGrid - 512));   // interior: no halo row is read
@@ -424,8 +429,12 @@ int setup_exchange(kfsp_ctx *ctx)
     if (!ctx->use_comm) return 0;
     int64_t reach = 0;
     for (int d = 0; d < ctx->nd; ++d) reach = std::max<int64_t>(reach, std::llabs((long long)ctx->delta[d]));
+    // a SELL generator with a bounded reach max |col - row| (known from its build; small under the internal
+    // lexicographic state order) reads only boundary rows of its neighbours too
+    const bool sell_ok = !ctx->use_dia && ctx->have_sell && ctx->sell_reach >= 0 && ctx->opt_halo_sell != 0;
+    if (sell_ok) reach = ctx->sell_reach;
     // ranks without rows take part with neutral values
-    const bool ok_local = ctx->opt_halo != 0 && (ctx->nloc == 0 || ctx->use_dia);
+    const bool ok_local = ctx->opt_halo != 0 && (ctx->nloc == 0 || ctx->use_dia || sell_ok);
     double h[2] = {ok_local ? 0.0 : 1.0, (double)reach};          // max over ranks of (not ok, reach)
     double *st = ctx->d_stage.p;
     HIP_TRY(hipMemcpyAsync(st, h, sizeof(h), hipMemcpyHostToDevice, ctx->stream));
@@ -540,7 +549,7 @@ int upload_sell(kfsp_ctx *ctx, const HostSell &S)
         HIP_TRY(hipMemcpyAsync(ctx->d_diag.p, S.diag.data(), S.diag.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->have_sell = true;
-    return 0;
+    return kfsp::build_sell_code(ctx);
 }
 
 // Banded form: accepted when the local rows use at most kMaxDiag distinct
@@ -777,6 +786,7 @@ int kfsp_destroy(kfsp_ctx *ctx)
     ctx->d_off.release(); ctx->d_col.release(); ctx->d_val.release(); ctx->d_diag.release();
     ctx->d_V.release(); ctx->d_w.release(); ctx->d_xg.release(); ctx->d_tmp.release();
     ctx->d_full.release(); ctx->d_wfull.release(); ctx->d_flagloc.release();
+    ctx->d_dtab.release(); ctx->d_dtlen.release(); ctx->d_code.release(); ctx->d_codeoff.release();
     ctx->d_part.release(); ctx->d_stage.release(); ctx->d_H.release(); ctx->d_sq.release();
     ctx->d_y.release(); ctx->d_flag.release(); ctx->d_g.release(); ctx->d_dia.release();
     ctx->d_ell_adj.release(); ctx->d_ell_off.release(); ctx->d_ell_diag.release(); ctx->d_cnt.release();
@@ -1241,6 +1251,7 @@ int kfsp_set_matrix_box(kfsp_ctx *ctx, int32_t ns, const int32_t *dims, int32_t 
         ctx->ell_cols = 0;
         ctx->dia_masked = false;
         ctx->have_sell = false;
+        ctx->sell_coded = false;
         ctx->nd = nr;
         for (int p = 0; p < nr; ++p) ctx->delta[p] = B.delta[p];
         ctx->dia_ld = round_up(ctx->nchunks * kChunk, 2 * kChunk);
@@ -1321,8 +1332,27 @@ int kfsp_matrix_bytes(const kfsp_ctx *ctx, int force_sell, int64_t *bytes)
         if (ctx->dia_masked) b += (ctx->dia_ld >> 7) * 4 - ctx->dia_empty_segments * 128 * 8;
     } else {
         b += ctx->slots * 12 + (ctx->nchunks + 1) * 8;
+        // dictionary-coded chunks: no column bytes, code words and offset tables instead (+ 12 B of chunk header)
+        if (ctx->sell_coded && force_sell != 3)
+            b += -4 * ctx->coded_slots + 8 * ctx->code_words + ctx->coded_tab_bytes + 12 * ctx->coded_chunks;
     }
     *bytes = b;
+    return 0;
+}
+
+int kfsp_layout_info(const kfsp_ctx *ctx, int64_t *v)
+{
+    if (!ctx) return -1;
+    if (!v) return -2;
+    if (ctx->group) return kfsp::group_layout_info(ctx, v);
+    v[0] = ctx->use_box ? (ctx->box_fast && !ctx->opt_box_generic ? 4 : 3) : ctx->use_dia ? (ctx->dia_masked ? 2 : 1) : (ctx->sell_coded ? 5 : 0);
+    v[1] = !ctx->use_comm ? 0 : (ctx->use_halo ? 1 : 2);
+    v[2] = ctx->halo;
+    v[3] = ctx->use_dia ? -1 : ctx->sell_reach;
+    v[4] = ctx->sell_coded ? ctx->coded_chunks : 0;
+    v[5] = ctx->nchunks;
+    v[6] = ctx->sell_coded ? ctx->code_words : 0;
+    v[7] = ctx->perm_on ? 1 : 0;
     return 0;
 }
 
@@ -1606,7 +1636,7 @@ int kfsp_restore_w(kfsp_ctx *ctx, double beta)
 }
 
 static int spmv_plain(kfsp_ctx *ctx, const double *src_local_or_full, bool src_is_full, double *y_dev,
-                      bool force_sell = false)
+                      bool force_sell = false, bool force_plain_sell = false)
 {
     SpmvArgs a;
     set_matrix_args(ctx, a);
@@ -1617,7 +1647,7 @@ static int spmv_plain(kfsp_ctx *ctx, const double *src_local_or_full, bool src_i
     a.udot = nullptr;
     a.break_tol = -1.0;
     a.brk_flag = ctx->d_flag.p;
-    return run_product(ctx, 0, a, src_local_or_full, src_is_full, nullptr, nullptr, force_sell);
+    return run_product(ctx, 0, a, src_local_or_full, src_is_full, nullptr, nullptr, force_sell, force_plain_sell);
 }
 
 int kfsp_spmv(kfsp_ctx *ctx, const double *x, double *y)
@@ -1899,21 +1929,48 @@ int kfsp_spmv_bench(kfsp_ctx *ctx, int reps, int variant, float *ms_total)
     if (!ctx) return -1;
     if (ctx->ldv == 0) return fail(ctx, -1, "no matrix set");
     if (reps < 1) return fail(ctx, -2, "reps < 1");
-    if (variant != 0 && variant != 2) return fail(ctx, -3, "unknown variant (0 auto, 2 SELL)");
+    if (variant != 0 && variant != 2 && variant != 3) return fail(ctx, -3, "unknown variant (0 auto, 2 SELL, 3 SELL with plain columns)");
     if (!ms_total) return fail(ctx, -4, "null ms_total");
     if (ctx->group) return kfsp::group_spmv_bench(ctx, reps, variant, ms_total);
-    if (variant == 2 && !ctx->have_sell) return fail(ctx, -3, "no SELL image resident (banded matrix built on the device)");
+    if (variant >= 2 && !ctx->have_sell) return fail(ctx, -3, "no SELL image resident (banded matrix built on the device)");
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const double *src = vcol(ctx, 0);
     double *dst = vcol(ctx, 1);
     HIP_TRY(hipEventRecord(ctx->ev0, st));
     for (int r = 0; r < reps; ++r) {
-        if (int rc = spmv_plain(ctx, src, false, dst, variant == 2)) return rc;
+        if (int rc = spmv_plain(ctx, src, false, dst, variant >= 2, variant == 3)) return rc;
     }
     HIP_TRY(hipEventRecord(ctx->ev1, st));
     HIP_TRY(hipEventSynchronize(ctx->ev1));
     HIP_TRY(hipEventElapsedTime(ms_total, ctx->ev0, ctx->ev1));
+    return 0;
+}
+
+int kfsp_exchange_bench(kfsp_ctx *ctx, int reps, float *ms_total, int64_t *bytes_in)
+{
+    if (!ctx) return -1;
+    if (ctx->group) return fail(ctx, -9, "not available on a group context");
+    if (ctx->ldv == 0) return fail(ctx, -1, "no matrix set");
+    if (reps < 1) return fail(ctx, -2, "reps < 1");
+    if (!ms_total || !bytes_in) return fail(ctx, -3, "null output");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    *ms_total = 0.f;
+    *bytes_in = 0;
+    if (!ctx->use_comm) return 0;
+    const double *src = vcol(ctx, 0), *xg = nullptr;
+    HIP_TRY(hipEventRecord(ctx->ev0, st));
+    for (int r = 0; r < reps; ++r)
+        if (int rc = gather_source(ctx, src, &xg)) return rc;
+    HIP_TRY(hipEventRecord(ctx->ev1, st));
+    HIP_TRY(hipEventSynchronize(ctx->ev1));
+    HIP_TRY(hipEventElapsedTime(ms_total, ctx->ev0, ctx->ev1));
+    const int64_t peers = ctx->nranks - 1;
+    if (ctx->use_halo)
+        *bytes_in = ctx->opt_halo_p2p ? 8 * ctx->halo * ((ctx->rank > 0) + (ctx->rank + 1 < ctx->nranks)) : 8 * 2 * ctx->halo * peers;
+    else
+        *bytes_in = 8 * ctx->L * peers;
     return 0;
 }
 
@@ -1972,12 +2029,14 @@ int kfsp_set_option(kfsp_ctx *ctx, const char *name, int64_t value)
     else if (k == "dia_mask") ctx->opt_dia_mask = value;
     else if (k == "box_generic") ctx->opt_box_generic = value;
     else if (k == "box_store") ctx->opt_box_store = value;
+    else if (k == "sell_code") ctx->opt_sell_code = value;
     else if (k == "small_lds") ctx->opt_small_lds = value;
     else if (k == "state_order") ctx->opt_state_order = value;
     else if (k == "state_order_min") ctx->opt_state_order_min = value;
     else if (k == "state_order_products") ctx->opt_state_order_products = value;
     else if (k == "halo") ctx->opt_halo = value;
     else if (k == "halo_p2p") ctx->opt_halo_p2p = value;
+    else if (k == "halo_sell") ctx->opt_halo_sell = value;
     else if (k == "sell_sigma") ctx->opt_sell_sigma = value;
     else if (k == "overlap") ctx->opt_overlap = value;
     else if (k == "small_kernel") ctx->opt_small = value;

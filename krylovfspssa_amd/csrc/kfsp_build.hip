@@ -469,6 +469,8 @@ int build_from_ell_device(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, cons
     ctx->dia_masked = false;
     ctx->nd = 0;
     ctx->have_sell = false;
+    ctx->sell_coded = false;
+    ctx->sell_reach = -1;
     if (banded) {
         std::sort(dl, dl + nd);
         DiaDev D;
@@ -556,7 +558,7 @@ int build_from_ell_device(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, cons
     }
     HIP_TRY_B(hipStreamSynchronize(st));
     ctx->have_sell = true;
-    return 0;
+    return build_sell_code(ctx);
 }
 
 int build_dia_mask(kfsp_ctx *ctx)
@@ -580,6 +582,141 @@ int build_dia_mask(kfsp_ctx *ctx)
     // the masked variant trades a little address arithmetic for the skipped bytes: worth it from ~3 % on
     ctx->dia_masked = (double)empty >= 0.03 * (double)ctx->nd * (double)ngroups;
     ctx->dia_empty_segments = (int64_t)empty;
+    return 0;
+}
+
+// Dictionary-coded columns of a SELL chunk (kSellCode*, kfsp_internal.h): one wavefront per chunk collects the distinct
+// offsets col - row of the chunk's entries, slot by slot in the rows' stored (FMATVEC) order, into a table held
+// one entry per lane, and writes every entry's 6-bit index into the code words.  More than 64 distinct offsets:
+// the chunk keeps its plain columns (dtlen = 0).
+__global__ __launch_bounds__(kBlock) void k_sell_code(int64_t nchunks, int64_t row0, const int64_t *__restrict__ off,
+                                                      const int32_t *__restrict__ col, const int64_t *__restrict__ codeoff,
+                                                      int32_t *__restrict__ dtab, int32_t *__restrict__ dtlen,
+                                                      unsigned long long *__restrict__ code, unsigned long long *__restrict__ stats)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= nchunks) return;
+    const int64_t o = off[c];
+    const int w = (int)((off[c + 1] - o) >> 6);
+    const int64_t g = row0 + (c << 6) + lane;
+    const int64_t cbase = codeoff[c];
+    int tab = 0, cnt = 0;
+    bool overflow = false;
+    unsigned long long word = 0;
+    for (int q = 0; q < w && !overflow; ++q) {
+        const int d = (int)((int64_t)col[sell_pos(o, w, q, lane)] - g);
+        int id = 0;
+        unsigned long long todo = __ballot(1);
+        while (todo) {
+            const int src = __ffsll((long long)todo) - 1;
+            const int dv = __builtin_amdgcn_readlane(d, src);
+            const unsigned long long hit = __ballot(lane < cnt && tab == dv);
+            int idx;
+            if (hit) {
+                idx = __ffsll((long long)hit) - 1;
+            } else {
+                if (cnt == 64) {
+                    overflow = true;
+                    break;
+                }
+                idx = cnt;
+                if (lane == cnt) tab = dv;
+                ++cnt;
+            }
+            const unsigned long long same = __ballot(d == dv);
+            if (d == dv) id = idx;
+            todo &= ~same;
+        }
+        word |= (unsigned long long)id << (kSellCodeBits * (q % kSellCodePerWord));
+        if (q % kSellCodePerWord == kSellCodePerWord - 1 || q == w - 1) {
+            code[cbase + (int64_t)(q / kSellCodePerWord) * 64 + lane] = word;
+            word = 0;
+        }
+    }
+    if (overflow || w == 0) cnt = 0;
+    dtab[(c << 6) + lane] = lane < cnt ? tab : 0;
+    if (lane == 0) {
+        dtlen[c] = cnt;
+        if (cnt > 0) {
+            atomicAdd(stats + 0, 1ull);                                          // coded chunks
+            atomicAdd(stats + 1, (unsigned long long)w * 64ull);                 // their entries
+            atomicAdd(stats + 2, (unsigned long long)((cnt * 4 + 63) / 64) * 64ull);   // table bytes in 64-byte lines
+            atomicAdd(stats + 3, (unsigned long long)((w + kSellCodePerWord - 1) / kSellCodePerWord) * 64ull);   // code words
+        }
+    }
+}
+
+// code words per chunk (then scanned in place): ceil(width / 10) words per lane
+__global__ __launch_bounds__(kBlock) void k_code_width(int64_t nchunks, const int64_t *__restrict__ off, int64_t *__restrict__ codeoff)
+{
+    const int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (c >= nchunks) return;
+    const int w = (int)((off[c + 1] - off[c]) >> 6);
+    codeoff[c + 1] = (int64_t)((w + kSellCodePerWord - 1) / kSellCodePerWord) * 64;
+}
+
+// max |col - row| over the stored entries (padding has col = row): the reach of the local rows
+__global__ __launch_bounds__(kBlock) void k_sell_reach(int64_t nchunks, int64_t row0, const int64_t *__restrict__ off,
+                                                       const int32_t *__restrict__ col, unsigned long long *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= nchunks) return;
+    const int64_t o = off[c];
+    const int w = (int)((off[c + 1] - o) >> 6);
+    const int64_t g = row0 + (c << 6) + lane;
+    long long m = 0;
+    for (int q = 0; q < w; ++q) {
+        const long long d = (long long)col[sell_pos(o, w, q, lane)] - g;
+        m = max(m, d < 0 ? -d : d);
+    }
+    for (int s = 32; s > 0; s >>= 1) m = max(m, __shfl_xor(m, s, 64));
+    if (lane == 0) atomicMax(out, (unsigned long long)m);
+}
+
+int build_sell_code(kfsp_ctx *ctx)
+{
+    ctx->sell_coded = false;
+    ctx->code_words = ctx->coded_chunks = ctx->coded_slots = ctx->coded_tab_bytes = 0;
+    ctx->sell_reach = -1;
+    if (!ctx->have_sell || ctx->nchunks < 1) return 0;
+    hipStream_t st = ctx->stream;
+    const int64_t nchunks = ctx->nchunks;
+    HIP_TRY_B(ctx->d_scan.reserve(sizeof(ScanOut), false));
+    unsigned long long *stats = reinterpret_cast<unsigned long long *>(ctx->d_scan.p);
+    HIP_TRY_B(hipMemsetAsync(stats, 0, 8 * sizeof(unsigned long long), st));
+    // the reach of the rows (a bounded reach lets a partitioned product exchange halo strips instead of whole vectors)
+    hipLaunchKernelGGL(k_sell_reach, dim3((int)((nchunks + 3) / 4)), dim3(kBlock), 0, st, nchunks, ctx->row0, ctx->d_off.p,
+                       ctx->d_col.p, stats + 4);
+    const bool want = ctx->opt_sell_code > 0 || (ctx->opt_sell_code < 0 && ctx->perm_on);
+    if (want) {
+        HIP_TRY_B(ctx->d_codeoff.reserve((size_t)nchunks + 1, false));
+        HIP_TRY_B(hipMemsetAsync(ctx->d_codeoff.p, 0, sizeof(int64_t), st));
+        hipLaunchKernelGGL(k_code_width, dim3((int)((nchunks + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, nchunks, ctx->d_off.p,
+                           ctx->d_codeoff.p);
+        hipLaunchKernelGGL(k_scan_offsets, dim3(1), dim3(1024), 0, st, nchunks, ctx->d_codeoff.p);
+        int64_t words = 0;
+        HIP_TRY_B(hipMemcpyAsync(&words, ctx->d_codeoff.p + nchunks, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY_B(hipStreamSynchronize(st));
+        HIP_TRY_B(ctx->d_code.reserve((size_t)std::max<int64_t>(words, 64), false));
+        HIP_TRY_B(ctx->d_dtab.reserve((size_t)nchunks * 64, false));
+        HIP_TRY_B(ctx->d_dtlen.reserve((size_t)nchunks, false));
+        hipLaunchKernelGGL(k_sell_code, dim3((int)((nchunks + 3) / 4)), dim3(kBlock), 0, st, nchunks, ctx->row0, ctx->d_off.p,
+                           ctx->d_col.p, ctx->d_codeoff.p, ctx->d_dtab.p, ctx->d_dtlen.p, ctx->d_code.p, stats);
+    }
+    unsigned long long h[8];
+    HIP_TRY_B(hipMemcpyAsync(h, stats, sizeof(h), hipMemcpyDeviceToHost, st));
+    HIP_TRY_B(hipStreamSynchronize(st));
+    ctx->sell_reach = (int64_t)h[4];
+    if (!want) return 0;
+    ctx->coded_chunks = (int64_t)h[0];
+    ctx->coded_slots = (int64_t)h[1];
+    ctx->coded_tab_bytes = (int64_t)h[2];
+    ctx->code_words = (int64_t)h[3];
+    // worth it when the coded chunks save bytes overall: 4 B of column per entry against 8 B per code word + the tables
+    const double saved = 4.0 * (double)ctx->coded_slots - 8.0 * (double)ctx->code_words - (double)ctx->coded_tab_bytes;
+    ctx->sell_coded = ctx->opt_sell_code > 0 ? ctx->coded_chunks > 0 : saved > 0.02 * 12.0 * (double)ctx->slots;
     return 0;
 }
 

@@ -175,6 +175,16 @@ struct kfsp_ctx {
     int32_t delta[kMaxDiag] = {0};
     int64_t dia_ld = 0;
     bool have_sell = false;
+    // dictionary-coded columns of the SELL image (kernel format 5; kfsp_internal.h kSellCode*)
+    DevBuf<int32_t> d_dtab, d_dtlen;
+    DevBuf<unsigned long long> d_code;
+    DevBuf<int64_t> d_codeoff;
+    bool sell_coded = false;
+    int64_t code_words = 0;          // 64-bit code words stored (all chunks)
+    int64_t coded_chunks = 0;        // chunks that use them
+    int64_t coded_slots = 0;         // entries (incl. padding) of those chunks
+    int64_t coded_tab_bytes = 0;     // bytes of their offset tables, in 64-byte lines
+    int64_t sell_reach = -1;         // max |col - row| over the local SELL rows (-1: unknown)
     // which 128-row groups of which diagonals hold entries at all (used when enough are empty)
     DevBuf<uint32_t> d_gmask;
     DevBuf<double> d_zero;   // 128 zeros, the stand-in for an empty segment
@@ -251,6 +261,7 @@ struct kfsp_ctx {
     int64_t opt_halo = 1;         // 0: always all-gather the whole source vector
     int64_t opt_sell_sigma = 0;           // rows per window of the SELL-sigma sort under the internal state order (0: off, the default:
                                           // measured slower - what it saves in padding it loses in gather coalescing)
+    int64_t opt_halo_sell = 1;    // 0: SELL generators always all-gather, whatever their reach
     int64_t opt_halo_p2p = 0;     // 1: a rank exchanges its strips with its two neighbours only (send/recv); 0: all-gather of all strips
     int64_t opt_small = 1;        // 1: one-launch Arnoldi pass for <= 16384 rows
     int64_t opt_overlap = 1;      // 0: exchange and product strictly one after the other
@@ -260,6 +271,7 @@ struct kfsp_ctx {
     int64_t opt_dia_mask = 1;             // 0: never skip empty diagonal segments
     int64_t opt_box_generic = 0;          // 1: matrix-free boxes always take the run-time interpreted kernel
     int64_t opt_mmax = kfsp::kMMax;        // largest Krylov dimension the basis is allocated for (m_max + 3 columns)
+    int64_t opt_sell_code = -1;            // dictionary-coded SELL columns: -1 auto (under the internal state order), 0 never, 1 always try
     int64_t opt_box_store = 0;            // 1: kfsp_set_matrix_box writes the generator out as stored diagonals on the device (banded form)
     int64_t opt_state_order = 1;          // 1: use kfsp_set_state_coords for large, long-lived generators (0: never)
     int64_t opt_state_order_min = 32768;  // smallest generator that is reordered
@@ -301,6 +313,7 @@ int group_reduce_w(kfsp_ctx *h, int squared, double *out);
 int group_get_basis(kfsp_ctx *h, int j, int64_t n, double *v);
 int group_spmv_bench(kfsp_ctx *h, int reps, int variant, float *ms_total);
 int group_get_timers(kfsp_ctx *h, double *ms, int reset);
+int group_layout_info(const kfsp_ctx *h, int64_t *v);
 // generator build on the device from the reference layout (kfsp_build.hip)
 // keep: leading columns whose OFFDIAG / DIAG are resident and unchanged (only the rest is uploaded)
 int build_from_ell_device(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, const int32_t *adj,
@@ -308,6 +321,8 @@ int build_from_ell_device(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, cons
 // after a banded generator was stored: find the empty (diagonal, 128-row group) segments and
 // switch the masked kernel variant on if they are worth skipping
 int build_dia_mask(kfsp_ctx *ctx);
+// after a SELL image was stored (d_off, d_col, d_val): try the dictionary-coded column form
+int build_sell_code(kfsp_ctx *ctx);
 // kfsp_set_matrix_box with option box_store: the box generator written out as stored diagonals (d_dia, d_diag)
 int box_materialize(kfsp_ctx *ctx);
 // lexicographic order of n states given as ns coordinates each (host array, leading

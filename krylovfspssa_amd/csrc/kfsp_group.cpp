@@ -417,6 +417,21 @@ int group_spmv_bench(kfsp_ctx *h, int reps, int variant, float *ms_total)
     return 0;
 }
 
+int group_layout_info(const kfsp_ctx *h, int64_t *v)
+{
+    // format, exchange and halo of rank 0 (agreed by all ranks); reach = max, chunks / coded chunks / code words = sums
+    int64_t t[8];
+    if (int rc = kfsp_layout_info(h->group->sub[0], v)) return rc;
+    for (int p = 1; p < h->group->n; ++p) {
+        if (int rc = kfsp_layout_info(h->group->sub[(size_t)p], t)) return rc;
+        v[3] = std::max(v[3], t[3]);
+        v[4] += t[4];
+        v[5] += t[5];
+        v[6] += t[6];
+    }
+    return 0;
+}
+
 int group_get_timers(kfsp_ctx *h, double *ms, int reset)
 {
     // device phases from rank 0 (all ranks run in lock step), host phases (Pade, callbacks) from the head itself

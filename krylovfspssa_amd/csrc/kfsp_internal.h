@@ -43,7 +43,23 @@ struct SellDev {
     const int32_t *col;  // global 0-based column
     const double *val;
     const double *diag;  // [nchunks * 64]
+    // dictionary-coded columns (kernel format 5), null otherwise: see kSellCode* below
+    const int32_t *dtab;               // [nchunks][64] column offsets (col - row) that occur in the chunk
+    const int32_t *dtlen;              // [nchunks] entries of the table in use; 0 = the chunk keeps plain columns
+    const unsigned long long *code;    // code words: word j of lane l of chunk c at codeoff[c] + 64 j + l
+    const int64_t *codeoff;            // [nchunks + 1]
 };
+
+// SELL-64 with dictionary-coded columns.  In a locality-preserving state order (the internal lexicographic order,
+// or a box) the 64 x (width) entries of a chunk use only a handful of distinct column OFFSETS col - row: the
+// reaction shifts of the lattice, a few variants of each where the chunk crosses a line end of the state set.
+// Instead of 4 bytes of column per entry the chunk stores that handful once (<= 64 offsets, lane j of the wave
+// holds entry j) and every entry a 6-bit index into it, ten to a 64-bit word per row: 8 w + 8 ceil(w / 10)
+// bytes per row and ~2 for the table, against 12 w.  The kernel turns an index back into the offset with one
+// ds_bpermute (a cross-lane read of the table register).  Values, their order in a row (FMATVEC's,
+// KrylovSolver.f90:598-604) and the addresses gathered are those of plain SELL: products are bit-identical.  A
+// chunk with more than 64 distinct offsets (discovery-ordered states) keeps its plain columns (dtlen = 0).
+constexpr int kSellCodeBits = 6, kSellCodePerWord = 10;
 
 // Banded form for state sets whose ordering makes every reaction a constant
 // index shift (lattice boxes in lexicographic order): diagonal d holds
@@ -209,7 +225,7 @@ int launch_arnoldi_small(const SmallArnoldiArgs &a, bool dia, int64_t lds_limit,
 
 // kernel launchers (kfsp_kernels.hip)
 // fmt: 0 SELL-64, 1 banded, 2 banded with group masks, 3 matrix-free box (lds_bytes = size of the factor tables),
-// 4 matrix-free box, single-factor fast path
+// 4 matrix-free box, single-factor fast path, 5 SELL-64 with dictionary-coded columns
 void launch_spmv(int mode, int grid, const SpmvArgs &a, bool nontemporal, int fmt, hipStream_t s, size_t lds_bytes = 0);
 void launch_ortho2(int grid, const Ortho2Args &a, hipStream_t s);
 void launch_ortho(int grid, const OrthoArgs &a, hipStream_t s);

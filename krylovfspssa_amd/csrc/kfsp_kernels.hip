@@ -183,6 +183,68 @@ __device__ __forceinline__ double row_sell(const SellDev &A, const double *__res
     return sum;
 }
 
+// The same row with dictionary-coded columns (kSellCode*, kfsp_internal.h): the column of an entry is
+// row + table[index], the table of the chunk's <= 64 distinct offsets sits one entry per lane in a register and
+// an index is turned into its offset by ds_bpermute.  Same values, same order, same addresses as row_sell.
+template <bool NT>
+__device__ __forceinline__ double row_sell_coded(const SellDev &A, const double *__restrict__ xg, int64_t row0,
+                                                 int64_t c, int lane)
+{
+    const int dtl = __builtin_amdgcn_readfirstlane(A.dtlen[c]);
+    if (dtl == 0) return row_sell<NT>(A, xg, row0, c, lane);          // this chunk kept its plain columns (uniform branch)
+    const int64_t off = A.off[c];
+    const int w = (int)((A.off[c + 1] - off) >> 6);
+    const int w2 = w >> 1;
+    const int64_t r = (c << 6) + lane;
+    const int tab = lane < dtl ? A.dtab[(c << 6) + lane] : 0;
+    const unsigned long long *cp = A.code + A.codeoff[c] + lane;
+    const double *vp = A.val + off + 2 * lane;
+    const double *xr = xg + row0 + r;                                 // x of the row itself; entries are xr[offset]
+    unsigned long long cw = __builtin_nontemporal_load(cp);
+    int used = 0;
+    double sum = -ld_stream<NT>(A.diag + r) * xr[0];
+#define KFSP_NEXT_X(XV)                                                                     \
+    {                                                                                       \
+        if (used == kSellCodePerWord) {                                                     \
+            cp += 64;                                                                       \
+            cw = __builtin_nontemporal_load(cp);                                            \
+            used = 0;                                                                       \
+        }                                                                                   \
+        const int d_ = __builtin_amdgcn_ds_bpermute((int)(cw & 63ull) << 2, tab);           \
+        cw >>= kSellCodeBits;                                                               \
+        ++used;                                                                             \
+        XV = xr[d_];                                                                        \
+    }
+    int k = 0;
+    for (; k + 2 <= w2; k += 2) {
+        const d2 v0 = ld_stream2<NT>(vp + (k + 0) * 128), v1 = ld_stream2<NT>(vp + (k + 1) * 128);
+        double x0, x1, x2, x3;
+        KFSP_NEXT_X(x0)
+        KFSP_NEXT_X(x1)
+        KFSP_NEXT_X(x2)
+        KFSP_NEXT_X(x3)
+        sum += v0.x * x0;
+        sum += v0.y * x1;
+        sum += v1.x * x2;
+        sum += v1.y * x3;
+    }
+    if (k < w2) {
+        const d2 v0 = ld_stream2<NT>(vp + k * 128);
+        double x0, x1;
+        KFSP_NEXT_X(x0)
+        KFSP_NEXT_X(x1)
+        sum += v0.x * x0;
+        sum += v0.y * x1;
+    }
+    if (w & 1) {
+        double x0;
+        KFSP_NEXT_X(x0)
+        sum += ld_stream<NT>(A.val + off + w2 * 128 + lane) * x0;
+    }
+#undef KFSP_NEXT_X
+    return sum;
+}
+
 // Banded form, TWO consecutive rows per lane (a wavefront covers 128 rows): the
 // value streams - the bulk of the traffic - are read 16 B per lane, which is
 // worth ~9 % of HBM rate over 8 B per lane (profiles/r01_stream_widths.log).
@@ -540,7 +602,7 @@ __device__ __forceinline__ d2 rows_box1(const BoxRegs<NS, PER> &R, const double 
 template <int MODE, bool NT, int FMT, int NS = 0, int NE = 0>
 __global__ __launch_bounds__(kBlock) void k_spmv(SpmvArgs a)
 {
-    constexpr bool DIA = FMT != 0;
+    constexpr bool DIA = FMT != 0 && FMT != 5;
     constexpr bool BOX = FMT == 3 || FMT == 4;
     __shared__ double red[12];
     const int lane = threadIdx.x & 63;
@@ -577,7 +639,8 @@ __global__ __launch_bounds__(kBlock) void k_spmv(SpmvArgs a)
         if (FMT == 4) sum = rows_box1<(NS ? NS : 1), (NE ? NE : 1)>(boxr, a.xg, a.row0, a.A.nrows, ct, lane);
         else if (BOX) sum = rows_box<0, 0>(a.B, tab, a.xg, a.row0, a.A.nrows, ct, lane);
         else if (DIA) sum = rows_dia<NT, FMT == 2>(a.D, a.xg, a.row0, ct, lane, gm);
-        else sum.x = row_sell<NT>(a.A, a.xg, a.row0, ct, lane);
+        else if (FMT == 5) sum.x = row_sell_coded<NT>(a.A, a.xg, a.row0, ct, lane);
+            else sum.x = row_sell<NT>(a.A, a.xg, a.row0, ct, lane);
     }
 
     double s = 1.0;
@@ -636,6 +699,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv(SpmvArgs a)
             if (FMT == 4) sum = rows_box1<(NS ? NS : 1), (NE ? NE : 1)>(boxr, a.xg, a.row0, a.A.nrows, ct, lane);
             else if (BOX) sum = rows_box<0, 0>(a.B, tab, a.xg, a.row0, a.A.nrows, ct, lane);
             else if (DIA) sum = rows_dia<NT, FMT == 2>(a.D, a.xg, a.row0, ct, lane, gm);
+            else if (FMT == 5) sum.x = row_sell_coded<NT>(a.A, a.xg, a.row0, ct, lane);
             else sum.x = row_sell<NT>(a.A, a.xg, a.row0, ct, lane);
         }
     }
@@ -690,10 +754,12 @@ void launch_spmv(int mode, int grid, const SpmvArgs &a, bool nt, int fmt, hipStr
     if (nt) {
         if (fmt == 2) launch_spmv_mode<true, 2>(mode, g, b, a, st);
         else if (fmt == 1) launch_spmv_mode<true, 1>(mode, g, b, a, st);
+        else if (fmt == 5) launch_spmv_mode<true, 5>(mode, g, b, a, st);
         else launch_spmv_mode<true, 0>(mode, g, b, a, st);
     } else {
         if (fmt == 2) launch_spmv_mode<false, 2>(mode, g, b, a, st);
         else if (fmt == 1) launch_spmv_mode<false, 1>(mode, g, b, a, st);
+        else if (fmt == 5) launch_spmv_mode<false, 5>(mode, g, b, a, st);
         else launch_spmv_mode<false, 0>(mode, g, b, a, st);
     }
 }

@@ -60,6 +60,7 @@ def load_library():
         "kfsp_matrix_info": [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)],
         "kfsp_matrix_bytes": [vp, C.c_int, C.POINTER(i64)],
         "kfsp_num_states": [vp, C.POINTER(i64)],
+        "kfsp_layout_info": [vp, vp],
         "kfsp_onestep": [vp, i32, i32, vp, i32, vp, i32, vp, i32, i32, i32, C.POINTER(i32), vp, vp],
         "kfsp_drop_plan": [vp, dbl, C.POINTER(dbl), C.POINTER(i64), C.POINTER(i64)],
         "kfsp_drop_flags": [vp, i64, vp],
@@ -81,6 +82,7 @@ def load_library():
         "kfsp_expv_fixed": [vp, C.c_int, dbl, C.c_int, vp],
         "kfsp_spmv_bench": [vp, C.c_int, C.c_int, C.POINTER(C.c_float)],
         "kfsp_selftest_stream": [vp, i64, C.c_int, C.c_int, C.POINTER(C.c_float)],
+        "kfsp_exchange_bench": [vp, C.c_int, C.POINTER(C.c_float), C.POINTER(i64)],
         "kfsp_add_timer": [vp, C.c_int, dbl],
         "kfsp_get_timers": [vp, vp, C.c_int],
         "kfsp_set_option": [vp, C.c_char_p, i64],
@@ -362,9 +364,16 @@ class KfspContext:
         return n.value
 
     def matrix_bytes(self, force_sell=False):
+        """force_sell: False / True (the SELL image) / 3 (the SELL image read with plain columns)"""
         b = C.c_int64(0)
-        self._chk(self._lib.kfsp_matrix_bytes(self._h, int(bool(force_sell)), C.byref(b)), "kfsp_matrix_bytes")
+        self._chk(self._lib.kfsp_matrix_bytes(self._h, int(force_sell), C.byref(b)), "kfsp_matrix_bytes")
         return b.value
+
+    def layout_info(self):
+        v = np.zeros(8, dtype=np.int64)
+        self._chk(self._lib.kfsp_layout_info(self._h, _p(v)), "kfsp_layout_info")
+        keys = ("format", "exchange", "halo_rows", "sell_reach", "coded_chunks", "chunks", "code_words", "state_order")
+        return dict(zip(keys, (int(x) for x in v)))
 
     def set_vector(self, w):
         w = np.ascontiguousarray(w, dtype=np.float64)
@@ -472,6 +481,12 @@ class KfspContext:
         ms = C.c_float(0.0)
         self._chk(self._lib.kfsp_spmv_bench(self._h, int(reps), int(variant), C.byref(ms)), "kfsp_spmv_bench")
         return ms.value
+
+    def exchange_bench(self, reps):
+        """-> (ms for reps exchanges of the source vector alone, bytes this rank receives per exchange)"""
+        ms, b = C.c_float(0.0), C.c_int64(0)
+        self._chk(self._lib.kfsp_exchange_bench(self._h, int(reps), C.byref(ms), C.byref(b)), "kfsp_exchange_bench")
+        return ms.value, b.value
 
     def selftest_stream(self, nbytes, elem_bytes, reps=1):
         ms = C.c_float(0.0)

@@ -398,6 +398,75 @@ class GoutsiasConserved:
         return nnz
 
 
+class GoutsiasEllipsoid:
+    """A NON-BOX FSP of the Goutsias model for bandwidth measurements at sizes the reference's own solver never
+    reaches: the states (M, D, RNA, DNA, DNA.D, DNA.2D) with DNA + DNA.D + DNA.2D = 2 (the six configurations a run
+    from (2, 6, 0, 2, 0, 0) lives on, examples/transcr6d.f90:50) and (M, D, RNA) inside an ellipsoid clipped at 0 -
+    the shape a probability-mass truncation gives - listed NOT in lexicographic order but in the order of a
+    reachability search from a seed state: by graph distance |dM| + |dD| + |dRNA| from the seed, ties shuffled
+    (fixed seed) - which scatters the neighbours of a state over the vector as SSA_EXTENDER / ONESTEP_EXTENDER
+    (StateSpace.f90:347-396, :550-630) do.  `ell()` gives the reference's FSP_MATRIX arrays (1-based ADJ, 0 =
+    target not listed, -1 = negative population), `state` the species counts [n][6] (FSP%STATE)."""
+
+    def __init__(self, center=(60, 50, 20), axes=(110, 90, 80), seed_state=(2, 6, 0), params=None, order="search", rng_seed=7):
+        self.c = GOUTSIAS_PARAMS if params is None else params
+        cM, cD, cR = center
+        aM, aD, aR = axes
+        m = np.arange(0, int(cM + aM) + 1, dtype=np.int64)
+        d = np.arange(0, int(cD + aD) + 1, dtype=np.int64)
+        r = np.arange(0, int(cR + aR) + 1, dtype=np.int64)
+        inside = (((m - cM) / aM) ** 2)[:, None, None] + (((d - cD) / aD) ** 2)[None, :, None] + \
+                 (((r - cR) / aR) ** 2)[None, None, :] <= 1.0
+        M, D, R = np.nonzero(inside)                               # lexicographic with RNA fastest here; reordered below
+        nb = len(M)
+        cfg = np.repeat(np.arange(6, dtype=np.int64), nb)
+        M, D, R = np.tile(M, 6), np.tile(D, 6), np.tile(R, 6)
+        n = len(M)
+        if order == "search":
+            dist = np.abs(M - seed_state[0]) + np.abs(D - seed_state[1]) + np.abs(R - seed_state[2]) + 3 * cfg
+            tie = np.random.default_rng(rng_seed).permutation(n)
+            o = np.lexsort((tie, dist))
+        elif order == "lex":                                       # species 1 (M) fastest, the configuration slowest
+            o = np.lexsort((M, D, R, cfg))
+        else:
+            raise ValueError(order)
+        M, D, R, cfg = M[o], D[o], R[o], cfg[o]
+        C = GoutsiasConserved.CFG
+        self.state = np.stack([M, D, R, C[cfg, 0], C[cfg, 1], C[cfg, 2]], axis=1).astype(np.int32)
+        self.n, self.d, self.R = n, 6, 10
+        self._M, self._D, self._R, self._cfg = M, D, R, cfg
+        self._shape = (len(m), len(d), len(r), 6)
+
+    def ell(self):
+        M, D, R, cfg = self._M, self._D, self._R, self._cfg
+        nM, nD, nR, _ = self._shape
+        n = self.n
+        lut = np.zeros(nM * nD * nR * 6, dtype=np.int32)           # dense (M, D, RNA, cfg) -> 1-based index, 0 = not listed
+        key = ((cfg * nR + R) * nD + D) * nM + M
+        lut[key] = np.arange(1, n + 1, dtype=np.int32)
+        X = [M.astype(np.float64), D.astype(np.float64), R.astype(np.float64)] + \
+            [GoutsiasConserved.CFG[cfg, k].astype(np.float64) for k in range(3)]
+        m, d_, rna, dna, dnad, dna2d = X
+        c = self.c
+        props = (c[0] * rna, c[1] * m, c[2] * dnad, c[3] * rna, c[4] * dna * d_, c[5] * dnad,
+                 c[6] * dnad * d_, c[7] * dna2d, c[8] * m * (m - 1) / 2.0, c[9] * d_)
+        adj = np.empty((n, 10), dtype=np.int32)
+        off = np.empty((n, 10), dtype=np.float64)
+        diag = np.zeros(n, dtype=np.float64)
+        for k, (delta, succ) in enumerate(GoutsiasConserved.REACTIONS):
+            cmap = np.asarray(succ, dtype=np.int64)
+            c2 = cmap[cfg]
+            m2, d2, r2 = M + delta[0], D + delta[1], R + delta[2]
+            neg = (c2 < 0) | (m2 < 0) | (d2 < 0) | (r2 < 0)
+            out = (m2 >= nM) | (d2 >= nD) | (r2 >= nR)
+            ok = ~(neg | out)
+            k2 = ((np.where(ok, c2, 0) * nR + np.where(ok, r2, 0)) * nD + np.where(ok, d2, 0)) * nM + np.where(ok, m2, 0)
+            adj[:, k] = np.where(neg, -1, np.where(out, 0, lut[k2]))
+            off[:, k] = props[k]
+            diag += off[:, k]
+        return adj, off, diag
+
+
 def spmv_alg_bytes(nnz, n):
     """Algorithmic bytes of one generator SpMV: CSR with f64
     values + int32 columns (12 B per nonzero incl. the diagonal) and per row a

@@ -29,7 +29,15 @@ def _models():
 
 
 MODES = {"halo": {}, "halo+split": {"overlap": 2}, "strips between neighbours": {"halo_p2p": 1},
-         "strips between neighbours+split": {"halo_p2p": 1, "overlap": 2}, "allgather": {"halo": 0}, "sell": {"format": 1}}
+         "strips between neighbours+split": {"halo_p2p": 1, "overlap": 2}, "allgather": {"halo": 0},
+         # SELL-64 rows of the same boxes: their reach max |col - row| is one species stride, so they exchange
+         # halo strips like the banded form (round 3); the whole-vector all-gather stays for unbounded reach
+         "sell": {"format": 1}, "sell+split": {"format": 1, "overlap": 2}, "sell+allgather": {"format": 1, "halo_sell": 0},
+         "sell coded": {"format": 1, "sell_code": 1}, "sell coded+split": {"format": 1, "sell_code": 1, "overlap": 2}}
+# (kernel format, exchange) kfsp_layout_info must report: format 0 SELL / 5 coded SELL / 1, 2 banded; exchange 1 strips / 2 all-gather
+EXPECT = {"halo": ((1, 2), 1), "halo+split": ((1, 2), 1), "strips between neighbours": ((1, 2), 1),
+          "strips between neighbours+split": ((1, 2), 1), "allgather": ((1, 2), 2), "sell": ((0,), 1), "sell+split": ((0,), 1),
+          "sell+allgather": ((0,), 2), "sell coded": ((5,), 1), "sell coded+split": ((5,), 1)}
 
 
 @pytest.mark.parametrize("P", [2, 3, 4])
@@ -52,6 +60,7 @@ def test_partitioned_product_arnoldi_expv_match_the_oracle(oracle, P, model, mod
         r0, nr = ctx.row_block(n)
         rp, cc, vv = mdl.csr_rows(r0, nr)
         ctx.set_matrix_csr(n, rp, cc, vv)
+        info = ctx.layout_info()
         ctx.set_vector(p0[r0:r0 + nr])
         y = ctx.spmv_w()
         beta = ctx.begin_step()
@@ -59,9 +68,19 @@ def test_partitioned_product_arnoldi_expv_match_the_oracle(oracle, P, model, mod
         v5 = ctx.get_basis(5)
         ctx.set_vector(p0[r0:r0 + nr])
         ws = ctx.expv_fixed(m, tau, nsteps)
-        return dict(r0=r0, nr=nr, y=y, beta=beta, H=H.copy(), mb=mb, k1=k1, av=av, v5=v5, ws=ws.copy(), w=ctx.get_vector())
+        return dict(r0=r0, nr=nr, y=y, beta=beta, H=H.copy(), mb=mb, k1=k1, av=av, v5=v5, ws=ws.copy(), w=ctx.get_vector(),
+                    info=info)
 
     res = host.run_loopback_ranks(P, body)
+    # which kernel format and which exchange actually ran (agreed by all ranks)
+    for r in res:
+        if r["nr"] > 0:
+            assert r["info"]["format"] in EXPECT[mode][0], r["info"]
+        assert r["info"]["exchange"] == EXPECT[mode][1], r["info"]
+        if mode.startswith("sell") and EXPECT[mode][1] == 1 and r["nr"] > 0:
+            assert 0 < r["info"]["sell_reach"] <= r["info"]["halo_rows"] <= host.partition(n, P, 0)[2]
+        if mode.startswith("sell coded") and r["nr"] > 0:
+            assert r["info"]["coded_chunks"] == r["info"]["chunks"] and r["info"]["code_words"] > 0
     # the blocks tile [0, n): equal padded length, short (possibly empty) last block
     L = host.partition(n, P, 0)[2]
     assert [r["r0"] for r in res] == [min(k * L, n) for k in range(P)]
