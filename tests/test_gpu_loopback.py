@@ -61,6 +61,8 @@ def test_partitioned_product_arnoldi_expv_match_the_oracle(oracle, P, model, mod
         rp, cc, vv = mdl.csr_rows(r0, nr)
         ctx.set_matrix_csr(n, rp, cc, vv)
         info = ctx.layout_info()
+        rows = np.repeat(np.arange(r0, r0 + nr), np.diff(rp))
+        info["reach_of_my_rows"] = int(np.abs(cc.astype(np.int64) - rows).max()) if nr else 0
         ctx.set_vector(p0[r0:r0 + nr])
         y = ctx.spmv_w()
         beta = ctx.begin_step()
@@ -73,11 +75,15 @@ def test_partitioned_product_arnoldi_expv_match_the_oracle(oracle, P, model, mod
 
     res = host.run_loopback_ranks(P, body)
     # which kernel format and which exchange actually ran (agreed by all ranks)
+    # (strips need the reach max |col - row| to stay within one block; a wider generator - the six DNA
+    # configurations of the Goutsias set over 4 ranks - takes the whole-vector all-gather whatever was asked)
+    reach = max(r["info"]["reach_of_my_rows"] for r in res)
+    want_exchange = EXPECT[mode][1] if reach <= host.partition(n, P, 0)[2] else 2
     for r in res:
         if r["nr"] > 0:
             assert r["info"]["format"] in EXPECT[mode][0], r["info"]
-        assert r["info"]["exchange"] == EXPECT[mode][1], r["info"]
-        if mode.startswith("sell") and EXPECT[mode][1] == 1 and r["nr"] > 0:
+        assert r["info"]["exchange"] == want_exchange, r["info"]
+        if mode.startswith("sell") and want_exchange == 1 and r["nr"] > 0:
             assert 0 < r["info"]["sell_reach"] <= r["info"]["halo_rows"] <= host.partition(n, P, 0)[2]
         if mode.startswith("sell coded") and r["nr"] > 0:
             assert r["info"]["coded_chunks"] == r["info"]["chunks"] and r["info"]["code_words"] > 0
