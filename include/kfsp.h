@@ -247,6 +247,34 @@ int kfsp_onestep(kfsp_ctx *ctx, int32_t ns, int32_t nr, const int32_t *stoich, i
                  int32_t ld_state, const int32_t *adj, int32_t ld_adj, int32_t max_count, int32_t capacity, int32_t *n_new,
                  int32_t *state_new, int32_t *adj_out);
 
+/* ---- propensities on the device (ModelModule.f90:163-199 through the stack code of FortranParser.f90:187-302) ---- */
+/* The model's propensity program, once per model (and again after RESET_PARAMETERS): reaction k is the postfix code
+ * code[code_off[k] .. code_off[k+1]) with immediates imm[imm_off[k] ..) in order of use.  Opcodes (those of the host's
+ * expression type, krylovfspssa_amd/fortran/kfsp_expr.f90, which tests/golden/exprtable.npz pins against the
+ * reference's parser): 1 IMM, 2 NEG, 3 ADD, 4 SUB, 5 MUL, 6 DIV, 7 POW, 10 + f for the functions f = 1..14 abs exp
+ * log10 log sqrt sinh cosh tanh sin cos tan asin acos atan, 100 + i for variable i = 1..ns (species counts) and
+ * ns+1..ns+nparams (parameters); x / 0, log / log10 of x <= 0, sqrt of x < 0, asin / acos outside [-1, 1] make the
+ * whole expression 0, as in the reference.
+ * + - * / NEG are evaluated one IEEE operation at a time: the same bits as the host.  pow and the functions come
+ * from the device's math library (<= 2 ulp from the host's).  So that the columns stay BIT-IDENTICAL to the host's
+ * wherever that is possible, a propensity that depends on ONE species only may be handed over as a table made with
+ * the host's own evaluator: tab_species[k] = that species (0-based) or -1, tab[k * tab_len + x] = a_k at population x
+ * (tab_len may be 0: no tables; populations >= tab_len are interpreted).  Stack depth <= 32. */
+int kfsp_set_propensity_program(kfsp_ctx *ctx, int32_t ns, int32_t nr, int32_t nparams, const double *params,
+                                const int32_t *code_off, const int32_t *code, const int32_t *imm_off, const double *imm,
+                                const int32_t *tab_species, int32_t tab_len, const double *tab);
+/* OFFDIAG(1:nr, i) = a_k(x_i) and DIAG(i) = their sum in reaction order (ADD_STATE, StateSpace.f90:207-212) for the
+ * n states state[ld_state][n] (host arrays in and out) */
+int kfsp_propensities(kfsp_ctx *ctx, int32_t n, const int32_t *state, int32_t ld_state, double *offdiag, int32_t ld_off,
+                      double *diag);
+/* kfsp_onestep that also returns the COMPLETE columns of the appended states: offdiag_new[ld_off][*n_new - n] and
+ * diag_new[*n_new - n] from the propensity program - the host then only enters the new states into its look-up
+ * table.  -15 without a program for (ns, nr). */
+int kfsp_onestep_columns(kfsp_ctx *ctx, int32_t ns, int32_t nr, const int32_t *stoich, int32_t n, const int32_t *state,
+                         int32_t ld_state, const int32_t *adj, int32_t ld_adj, int32_t max_count, int32_t capacity,
+                         int32_t *n_new, int32_t *state_new, int32_t *adj_out, double *offdiag_new, int32_t ld_off,
+                         double *diag_new);
+
 /* single reductions over the resident w (tests; FIND_DROPTOL-style sums) */
 int kfsp_nrm2_w(kfsp_ctx *ctx, double *out);
 int kfsp_asum_w(kfsp_ctx *ctx, double *out);

@@ -13,7 +13,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libkfsp_hip.so")
-SOURCES = ["kfsp_api.cpp", "kfsp_group.cpp", "kfsp_padm.cpp", "kfsp_stepper.cpp", "kfsp_kernels.hip", "kfsp_build.hip", "kfsp_drop.hip", "kfsp_onestep.hip"]
+SOURCES = ["kfsp_api.cpp", "kfsp_group.cpp", "kfsp_padm.cpp", "kfsp_stepper.cpp", "kfsp_kernels.hip", "kfsp_build.hip", "kfsp_drop.hip", "kfsp_onestep.hip", "kfsp_prop.hip"]
 HEADERS = ["kfsp_internal.h", "kfsp_ctx.h", os.path.join("..", "..", "include", "kfsp.h")]
 
 

@@ -792,6 +792,7 @@ int kfsp_destroy(kfsp_ctx *ctx)
     ctx->d_ell_adj.release(); ctx->d_ell_off.release(); ctx->d_ell_diag.release(); ctx->d_cnt.release();
     ctx->d_ticket.release(); ctx->d_slot.release(); ctx->d_scan.release(); ctx->d_strip.release();
     ctx->d_dropflag.release(); ctx->d_dropcnt.release(); ctx->d_box.release(); ctx->d_os1.release(); ctx->d_os2.release();
+    ctx->d_os3.release(); ctx->d_prop_i.release(); ctx->d_prop_d.release();
     ctx->d_perm.release(); ctx->d_iperm.release(); ctx->d_coords.release(); ctx->d_ell_adj2.release();
     ctx->d_ell_off2.release(); ctx->d_ell_diag2.release(); ctx->d_pstage.release(); ctx->d_keys.release();
     ctx->d_sortidx.release(); ctx->d_sorttmp.release(); ctx->d_gmask.release(); ctx->d_zero.release();
@@ -1694,9 +1695,9 @@ int kfsp_spmv_w(kfsp_ctx *ctx, double *y)
     return 0;
 }
 
-int kfsp_onestep(kfsp_ctx *ctx, int32_t ns, int32_t nr, const int32_t *stoich, int32_t n, const int32_t *state, int32_t ld_state,
-                 const int32_t *adj, int32_t ld_adj, int32_t max_count, int32_t capacity, int32_t *n_new, int32_t *state_new,
-                 int32_t *adj_out)
+static int onestep_impl(kfsp_ctx *ctx, int32_t ns, int32_t nr, const int32_t *stoich, int32_t n, const int32_t *state, int32_t ld_state,
+                        const int32_t *adj, int32_t ld_adj, int32_t max_count, int32_t capacity, int32_t *n_new, int32_t *state_new,
+                        int32_t *adj_out, double *off_new, int32_t ld_off, double *diag_new)
 {
     return no_throw(ctx, [&]() -> int {
         if (!ctx) return -1;
@@ -1709,14 +1710,71 @@ int kfsp_onestep(kfsp_ctx *ctx, int32_t ns, int32_t nr, const int32_t *stoich, i
         if (max_count < 1) return fail(ctx, -10, "max_count < 1");
         if (capacity < n) return fail(ctx, -11, "capacity < n");
         if (!n_new || !state_new || !adj_out) return fail(ctx, -12, "null output");
-        if (ctx->group)
-            return kfsp::group_onestep(ctx, ns, nr, stoich, n, state, ld_state, adj, ld_adj, max_count, capacity, n_new, state_new, adj_out);
+        if (ctx->group) ctx = kfsp::group_rank0(ctx);      // integer work on the whole lists, no collective inside: one rank does it
+        if (off_new || diag_new) {
+            if (!off_new || !diag_new || ld_off < nr) return fail(ctx, -15, "bad offdiag_new / ld_off / diag_new");
+            if (!ctx->prop_ready || ctx->prop_ns != ns || ctx->prop_nr != nr)
+                return fail(ctx, -15, "no propensity program for this model (kfsp_set_propensity_program)");
+        }
         HIP_TRY(hipSetDevice(ctx->device));
         const auto t0 = std::chrono::steady_clock::now();
         const int rc = kfsp::onestep_device(ctx, ns, nr, stoich, n, state, ld_state, adj, ld_adj, max_count, capacity, n_new,
-                                            state_new, adj_out);
+                                            state_new, adj_out, off_new, ld_off, diag_new);
         ctx->t_ms[KFSP_T_ONESTEP] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         return rc;
+    });
+}
+
+int kfsp_onestep(kfsp_ctx *ctx, int32_t ns, int32_t nr, const int32_t *stoich, int32_t n, const int32_t *state, int32_t ld_state,
+                 const int32_t *adj, int32_t ld_adj, int32_t max_count, int32_t capacity, int32_t *n_new, int32_t *state_new,
+                 int32_t *adj_out)
+{
+    return onestep_impl(ctx, ns, nr, stoich, n, state, ld_state, adj, ld_adj, max_count, capacity, n_new, state_new, adj_out,
+                        nullptr, 0, nullptr);
+}
+
+int kfsp_onestep_columns(kfsp_ctx *ctx, int32_t ns, int32_t nr, const int32_t *stoich, int32_t n, const int32_t *state, int32_t ld_state,
+                         const int32_t *adj, int32_t ld_adj, int32_t max_count, int32_t capacity, int32_t *n_new, int32_t *state_new,
+                         int32_t *adj_out, double *offdiag_new, int32_t ld_off, double *diag_new)
+{
+    if (ctx && (!offdiag_new || !diag_new)) return fail(ctx, -15, "null offdiag_new / diag_new");
+    return onestep_impl(ctx, ns, nr, stoich, n, state, ld_state, adj, ld_adj, max_count, capacity, n_new, state_new, adj_out,
+                        offdiag_new, ld_off, diag_new);
+}
+
+int kfsp_set_propensity_program(kfsp_ctx *ctx, int32_t ns, int32_t nr, int32_t nparams, const double *params, const int32_t *code_off,
+                                const int32_t *code, const int32_t *imm_off, const double *imm, const int32_t *tab_species,
+                                int32_t tab_len, const double *tab)
+{
+    return no_throw(ctx, [&]() -> int {
+        if (!ctx) return -1;
+        if (ns < 1 || ns > 16) return fail(ctx, -2, "1 <= ns <= 16");
+        if (nr < 1 || nr > 64) return fail(ctx, -3, "1 <= nr <= 64");
+        if (nparams < 0 || (nparams > 0 && !params)) return fail(ctx, -4, "bad parameters");
+        if (!code_off || !code || !imm_off) return fail(ctx, -6, "null code");
+        if (imm_off[nr] > 0 && !imm) return fail(ctx, -9, "null immediates");
+        if (!tab_species) return fail(ctx, -10, "null tab_species");
+        if (tab_len < 0 || (tab_len > 0 && !tab)) return fail(ctx, -11, "bad tables");
+        if (ctx->group)
+            return kfsp::group_set_propensity_program(ctx, ns, nr, nparams, params, code_off, code, imm_off, imm, tab_species, tab_len, tab);
+        HIP_TRY(hipSetDevice(ctx->device));
+        return kfsp::prop_set_program(ctx, ns, nr, nparams, params, code_off, code, imm_off, imm, tab_species, tab_len, tab);
+    });
+}
+
+int kfsp_propensities(kfsp_ctx *ctx, int32_t n, const int32_t *state, int32_t ld_state, double *offdiag, int32_t ld_off, double *diag)
+{
+    return no_throw(ctx, [&]() -> int {
+        if (!ctx) return -1;
+        if (ctx->group) ctx = kfsp::group_rank0(ctx);
+        if (!ctx->prop_ready) return fail(ctx, -1, "no propensity program (kfsp_set_propensity_program)");
+        if (n < 0) return fail(ctx, -2, "n < 0");
+        if (n == 0) return 0;
+        if (!state || ld_state < ctx->prop_ns) return fail(ctx, -3, "bad state / ld_state");
+        if (!offdiag || ld_off < ctx->prop_nr) return fail(ctx, -5, "bad offdiag / ld_off");
+        if (!diag) return fail(ctx, -7, "null diag");
+        HIP_TRY(hipSetDevice(ctx->device));
+        return kfsp::prop_eval_host(ctx, n, state, ld_state, offdiag, ld_off, diag);
     });
 }
 

@@ -227,8 +227,13 @@ struct kfsp_ctx {
     bool w_pending = false;
     int64_t w_pending_n = 0;
 
-    // ONESTEP_EXTENDER on the device (kfsp_onestep.hip): two scratch arenas
-    DevBuf<char> d_os1, d_os2;
+    // ONESTEP_EXTENDER on the device (kfsp_onestep.hip): two scratch arenas (+ one for the columns of the new states)
+    DevBuf<char> d_os1, d_os2, d_os3;
+    // the model's propensity program (kfsp_prop.hip): [code_off | imm_off | tab_species | code] and [params | imm | tables]
+    DevBuf<int32_t> d_prop_i;
+    DevBuf<double> d_prop_d;
+    bool prop_ready = false;
+    int prop_ns = 0, prop_nr = 0, prop_np = 0, prop_np_pad = 1, prop_nimm_pad = 1, prop_tab_len = 0;
 
     // vectors
     DevBuf<double> d_V;    // (kMMax+2) columns, stride ldv, unnormalised basis
@@ -303,9 +308,6 @@ int group_combine(kfsp_ctx *h, int mx, double beta, const double *y, double *wsu
 int group_restore_w(kfsp_ctx *h, double beta);
 int group_spmv(kfsp_ctx *h, const double *x, double *y);
 int group_spmv_w(kfsp_ctx *h, double *y);
-int group_onestep(kfsp_ctx *h, int32_t ns, int32_t nr, const int32_t *stoich, int32_t n, const int32_t *state, int32_t ld_state,
-                  const int32_t *adj, int32_t ld_adj, int32_t max_count, int32_t capacity, int32_t *n_new, int32_t *state_new,
-                  int32_t *adj_out);
 int group_drop_plan(kfsp_ctx *h, double dsum, double *droptol, int64_t *drop_count, int64_t *n_flagged);
 int group_drop_flags(kfsp_ctx *h, int64_t n, uint8_t *dropped);
 int group_drop_compact(kfsp_ctx *h, int64_t *n_new);
@@ -314,6 +316,10 @@ int group_get_basis(kfsp_ctx *h, int j, int64_t n, double *v);
 int group_spmv_bench(kfsp_ctx *h, int reps, int variant, float *ms_total);
 int group_get_timers(kfsp_ctx *h, double *ms, int reset);
 int group_layout_info(const kfsp_ctx *h, int64_t *v);
+int group_set_propensity_program(kfsp_ctx *h, int32_t ns, int32_t nr, int32_t np, const double *params, const int32_t *code_off,
+                                 const int32_t *code, const int32_t *imm_off, const double *imm, const int32_t *tab_species,
+                                 int32_t tab_len, const double *tab);
+kfsp_ctx *group_rank0(const kfsp_ctx *h);
 // generator build on the device from the reference layout (kfsp_build.hip)
 // keep: leading columns whose OFFDIAG / DIAG are resident and unchanged (only the rest is uploaded)
 int build_from_ell_device(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, const int32_t *adj,
@@ -337,7 +343,14 @@ void launch_drop_flags(int64_t n, const double *w, const double *aw, double drop
 void launch_flags_to_caller(int64_t n, const uint8_t *all, const int32_t *perm, uint8_t *flag, hipStream_t st);
 int drop_compact_vector(kfsp_ctx *ctx, int64_t n, const double *src, double *dst, int *n_keep_dev);
 // ONESTEP_EXTENDER's integer work (kfsp_onestep.hip); all arrays are host memory
+// off_new / diag_new (may be null): the propensity columns of the appended states, made by the program of kfsp_prop.hip
 int onestep_device(kfsp_ctx *ctx, int32_t ns, int32_t nr, const int32_t *stoich, int32_t n, const int32_t *state, int32_t lds,
                    const int32_t *adj, int32_t lda, int32_t max_count, int32_t cap, int32_t *n_out, int32_t *state_new,
-                   int32_t *adj_out);
+                   int32_t *adj_out, double *off_new = nullptr, int32_t ldo = 0, double *diag_new = nullptr);
+// propensities on the device (kfsp_prop.hip)
+int prop_set_program(kfsp_ctx *ctx, int32_t ns, int32_t nr, int32_t np, const double *params, const int32_t *code_off,
+                     const int32_t *code, const int32_t *imm_off, const double *imm, const int32_t *tab_species, int32_t tab_len,
+                     const double *tab);
+int prop_eval_device(kfsp_ctx *ctx, int64_t n, const int32_t *d_state, int lds, double *d_off, int ldo, double *d_diag);
+int prop_eval_host(kfsp_ctx *ctx, int32_t n, const int32_t *state, int32_t lds, double *offdiag, int32_t ldo, double *diag);
 }  // namespace kfsp

@@ -338,16 +338,8 @@ int group_spmv_w(kfsp_ctx *h, double *y)
     return gall(h, [&](kfsp_ctx *c, int p) { return kfsp_spmv_w(c, y ? y + block_of(h, h->n, p).row0 : y); });
 }
 
-int group_onestep(kfsp_ctx *h, int32_t ns, int32_t nr, const int32_t *stoich, int32_t n, const int32_t *state, int32_t ld_state,
-                  const int32_t *adj, int32_t ld_adj, int32_t max_count, int32_t capacity, int32_t *n_new, int32_t *state_new,
-                  int32_t *adj_out)
-{
-    // integer work on the whole lists, no collective inside: one rank does it
-    kfsp_ctx *c = h->group->sub[0];
-    const int rc = kfsp_onestep(c, ns, nr, stoich, n, state, ld_state, adj, ld_adj, max_count, capacity, n_new, state_new, adj_out);
-    if (rc) h->err = kfsp_last_error(c);
-    return rc;
-}
+// (kfsp_onestep / kfsp_onestep_columns / kfsp_propensities: work on the whole lists, no collective inside - the entry
+// points hand a head's call to rank 0, group_rank0)
 
 int group_drop_plan(kfsp_ctx *h, double dsum, double *droptol, int64_t *drop_count, int64_t *n_flagged)
 {
@@ -416,6 +408,17 @@ int group_spmv_bench(kfsp_ctx *h, int reps, int variant, float *ms_total)
     *ms_total = t;
     return 0;
 }
+
+int group_set_propensity_program(kfsp_ctx *h, int32_t ns, int32_t nr, int32_t np, const double *params, const int32_t *code_off,
+                                 const int32_t *code, const int32_t *imm_off, const double *imm, const int32_t *tab_species,
+                                 int32_t tab_len, const double *tab)
+{
+    return gall(h, [&](kfsp_ctx *c, int) {
+        return kfsp_set_propensity_program(c, ns, nr, np, params, code_off, code, imm_off, imm, tab_species, tab_len, tab);
+    });
+}
+
+kfsp_ctx *group_rank0(const kfsp_ctx *h) { return h->group->sub[0]; }
 
 int group_layout_info(const kfsp_ctx *h, int64_t *v)
 {

@@ -223,7 +223,7 @@ inline int blocks(int64_t n) { return (int)std::max<int64_t>(1, (n + 255) / 256)
 
 int onestep_device(kfsp_ctx *ctx, int32_t ns, int32_t nr, const int32_t *stoich, int32_t n, const int32_t *state, int32_t lds,
                    const int32_t *adj, int32_t lda, int32_t max_count, int32_t cap, int32_t *n_out, int32_t *state_new,
-                   int32_t *adj_out)
+                   int32_t *adj_out, double *off_new, int32_t ldo, double *diag_new)
 {
     hipStream_t st = ctx->stream;
     OsModel M;
@@ -340,6 +340,15 @@ int onestep_device(kfsp_ctx *ctx, int32_t ns, int32_t nr, const int32_t *stoich,
         hipLaunchKernelGGL(k_os_new, dim3(blocks(nu)), dim3(256), 0, st, nu, n, lds, lda, M, d_ugid2, d_ukey, d_newidx, okey, oidx,
                            d_state_new, d_adj_out);
         OS_TRY(hipMemcpyAsync(state_new, d_state_new, (size_t)nu * lds * 4, hipMemcpyDeviceToHost, st));
+        if (off_new) {
+            // the propensity columns of the appended states, made where their coordinates already are (kfsp_prop.hip)
+            const size_t ob = (size_t)nu * (size_t)ldo * 8;
+            OS_TRY(ctx->d_os3.reserve(ob + (size_t)nu * 8 + 256, false));
+            double *d_off = reinterpret_cast<double *>(ctx->d_os3.p), *d_dg = reinterpret_cast<double *>(ctx->d_os3.p + ob);
+            if (int rc = prop_eval_device(ctx, nu, d_state_new, lds, d_off, ldo, d_dg)) return rc;
+            OS_TRY(hipMemcpyAsync(off_new, d_off, ob, hipMemcpyDeviceToHost, st));
+            OS_TRY(hipMemcpyAsync(diag_new, d_dg, (size_t)nu * 8, hipMemcpyDeviceToHost, st));
+        }
     }
     OS_TRY(hipMemcpyAsync(adj_out, d_adj_out, (size_t)(n + nu) * lda * 4, hipMemcpyDeviceToHost, st));
     OS_TRY(hipStreamSynchronize(st));

@@ -1,0 +1,244 @@
+// Propensities on the device (second half): a_k(x) of the model's .input expressions
+// for whole lists of states, so that the OFFDIAG / DIAG columns of appended states are made where the state
+// lists already are.
+//
+// Reference: MODEL%PROPENSITY (src/model/ModelModule.f90:163-199) evaluates the parsed expression of
+// reaction k through the stack machine of src/parser/FortranParser.f90:187-302 over (species counts,
+// parameter values).  The program handed over here is the postfix code of the host's own expression type
+// (krylovfspssa_amd/fortran/kfsp_expr.f90, pinned against the reference parser by tests/golden/exprtable.npz):
+//   1 IMM (next immediate)   2 NEG   3 ADD   4 SUB   5 MUL   6 DIV   7 POW   10+k function k (abs exp log10 log
+//   sqrt sinh cosh tanh sin cos tan asin acos atan)   100+i variable i (1..ns species, then the parameters)
+// with the reference's rules: x / 0, log / log10 of x <= 0, sqrt of x < 0, asin / acos outside [-1, 1] make the
+// WHOLE expression 0.
+//
+// Bit-exactness.  + - * / and NEG are IEEE operations, evaluated one by one as the host's interpreter does (no
+// contraction: the code is data) - same bits.  pow and the functions come from the device's math library, which
+// is not the host's: up to ~2 ulp apart.  To keep the columns bit-identical to the host's wherever possible, a
+// propensity that depends on ONE species only (every Hill function, every x (x - 1) / 2 of the shipped
+// models) is not interpreted at all: the host tabulates it with ITS evaluator at every population count
+// 0 .. tab_len - 1 and the device looks it up; populations beyond the table fall back to the interpreter.
+// Propensities of several species built from + - * / alone (mass action c X Y) are exact either way.
+#include "kfsp_ctx.h"
+
+#include <cstring>
+
+#pragma clang fp contract(off)
+
+namespace kfsp {
+
+namespace {
+
+constexpr int kPropStack = 32;
+
+struct PropDev {
+    int ns, nr, np, tab_len;
+    const int32_t *code_off, *code, *imm_off, *tab_species;
+    const double *imm, *params, *tab;
+};
+
+__device__ double prop_eval(const PropDev &P, int k, const int32_t *__restrict__ x)
+{
+    const int ts = P.tab_species[k];
+    if (ts >= 0) {
+        const int v = x[ts];
+        if (v >= 0 && v < P.tab_len) return P.tab[(int64_t)k * P.tab_len + v];
+    }
+    double st[kPropStack];
+    int sp = 0;
+    const double *imm = P.imm + P.imm_off[k];
+    for (int ip = P.code_off[k]; ip < P.code_off[k + 1]; ++ip) {
+        const int c = P.code[ip];
+        switch (c) {
+        case 1: st[sp++] = *imm++; break;
+        case 2: st[sp - 1] = -st[sp - 1]; break;
+        case 3: st[sp - 2] = st[sp - 2] + st[sp - 1]; --sp; break;
+        case 4: st[sp - 2] = st[sp - 2] - st[sp - 1]; --sp; break;
+        case 5: st[sp - 2] = st[sp - 2] * st[sp - 1]; --sp; break;
+        case 6:
+            if (st[sp - 1] == 0.0) return 0.0;
+            st[sp - 2] = st[sp - 2] / st[sp - 1];
+            --sp;
+            break;
+        case 7: st[sp - 2] = pow(st[sp - 2], st[sp - 1]); --sp; break;
+        case 11: st[sp - 1] = fabs(st[sp - 1]); break;
+        case 12: st[sp - 1] = exp(st[sp - 1]); break;
+        case 13:
+            if (st[sp - 1] <= 0.0) return 0.0;
+            st[sp - 1] = log10(st[sp - 1]);
+            break;
+        case 14:
+            if (st[sp - 1] <= 0.0) return 0.0;
+            st[sp - 1] = log(st[sp - 1]);
+            break;
+        case 15:
+            if (st[sp - 1] < 0.0) return 0.0;
+            st[sp - 1] = sqrt(st[sp - 1]);
+            break;
+        case 16: st[sp - 1] = sinh(st[sp - 1]); break;
+        case 17: st[sp - 1] = cosh(st[sp - 1]); break;
+        case 18: st[sp - 1] = tanh(st[sp - 1]); break;
+        case 19: st[sp - 1] = sin(st[sp - 1]); break;
+        case 20: st[sp - 1] = cos(st[sp - 1]); break;
+        case 21: st[sp - 1] = tan(st[sp - 1]); break;
+        case 22:
+            if (fabs(st[sp - 1]) > 1.0) return 0.0;
+            st[sp - 1] = asin(st[sp - 1]);
+            break;
+        case 23:
+            if (fabs(st[sp - 1]) > 1.0) return 0.0;
+            st[sp - 1] = acos(st[sp - 1]);
+            break;
+        case 24: st[sp - 1] = atan(st[sp - 1]); break;
+        default: {
+            const int v = c - 101;                                   // 0-based variable
+            st[sp++] = v < P.ns ? (double)x[v] : P.params[v - P.ns];
+        }
+        }
+    }
+    return sp >= 1 ? st[0] : 0.0;
+}
+
+// OFFDIAG(k, i) = a_k(x_i), DIAG(i) = their sum in reaction order (StateSpace.f90:207-212); one lane per state
+__global__ __launch_bounds__(kBlock) void k_propensities(PropDev P, int64_t n, const int32_t *__restrict__ state, int lds,
+                                                         double *__restrict__ offdiag, int ldo, double *__restrict__ diag)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int32_t *x = state + i * lds;
+    double d = 0.0;
+    for (int k = 0; k < P.nr; ++k) {
+        const double a = prop_eval(P, k, x);
+        offdiag[i * ldo + k] = a;
+        d += a;
+    }
+    diag[i] = d;
+}
+
+PropDev prop_dev(const kfsp_ctx *ctx)
+{
+    PropDev P;
+    P.ns = ctx->prop_ns;
+    P.nr = ctx->prop_nr;
+    P.np = ctx->prop_np;
+    P.tab_len = ctx->prop_tab_len;
+    const int32_t *ib = ctx->d_prop_i.p;
+    P.code_off = ib;
+    P.imm_off = ib + (P.nr + 1);
+    P.tab_species = ib + 2 * (P.nr + 1);
+    P.code = ib + 2 * (P.nr + 1) + P.nr;
+    const double *db = ctx->d_prop_d.p;
+    P.params = db;
+    P.imm = db + ctx->prop_np_pad;
+    P.tab = db + ctx->prop_np_pad + ctx->prop_nimm_pad;
+    return P;
+}
+
+}  // namespace
+
+#define HIP_TRY_P(expr)                                                                    \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            ctx->err = std::string(#expr) + ": " + hipGetErrorString(e_);                  \
+            return 1000 + (int)e_;                                                         \
+        }                                                                                  \
+    } while (0)
+
+int prop_set_program(kfsp_ctx *ctx, int32_t ns, int32_t nr, int32_t np, const double *params, const int32_t *code_off,
+                     const int32_t *code, const int32_t *imm_off, const double *imm, const int32_t *tab_species, int32_t tab_len,
+                     const double *tab)
+{
+    ctx->prop_ready = false;
+    // the code is checked once, here: every operand exists, the stack never exceeds the kernel's, variables are in range
+    const int ncode = code_off[nr], nimm = imm_off[nr];
+    for (int k = 0; k < nr; ++k) {
+        if (code_off[k + 1] < code_off[k] || imm_off[k + 1] < imm_off[k]) {
+            ctx->err = "propensity program: offsets not monotone";
+            return -6;
+        }
+        int sp = 0, ni = 0;
+        for (int ip = code_off[k]; ip < code_off[k + 1]; ++ip) {
+            const int c = code[ip];
+            if (c == 1) {
+                ++sp;
+                ++ni;
+            } else if (c == 2 || (c >= 11 && c <= 24)) {
+                if (sp < 1) sp = -1000;
+            } else if (c >= 3 && c <= 7) {
+                if (sp < 2) sp = -1000;
+                --sp;
+            } else if (c >= 101 && c <= 100 + ns + np) {
+                ++sp;
+            } else {
+                ctx->err = "propensity program: unknown opcode";
+                return -7;
+            }
+            if (sp < 0 || sp > kPropStack) {
+                ctx->err = "propensity program: malformed expression or stack deeper than 32";
+                return -7;
+            }
+        }
+        if (ni != imm_off[k + 1] - imm_off[k]) {
+            ctx->err = "propensity program: immediates do not match the code";
+            return -9;
+        }
+        if (tab_species[k] >= ns) {
+            ctx->err = "propensity program: table species out of range";
+            return -10;
+        }
+    }
+    hipStream_t st = ctx->stream;
+    std::vector<int32_t> ib((size_t)(2 * (nr + 1) + nr + std::max(ncode, 1)));
+    std::memcpy(ib.data(), code_off, sizeof(int32_t) * (size_t)(nr + 1));
+    std::memcpy(ib.data() + (nr + 1), imm_off, sizeof(int32_t) * (size_t)(nr + 1));
+    std::memcpy(ib.data() + 2 * (nr + 1), tab_species, sizeof(int32_t) * (size_t)nr);
+    if (ncode > 0) std::memcpy(ib.data() + 2 * (nr + 1) + nr, code, sizeof(int32_t) * (size_t)ncode);
+    const int np_pad = std::max(np, 1), nimm_pad = std::max(nimm, 1);
+    const size_t ntab = tab_len > 0 ? (size_t)nr * (size_t)tab_len : 0;
+    std::vector<double> db((size_t)np_pad + (size_t)nimm_pad + std::max<size_t>(ntab, 1), 0.0);
+    if (np > 0) std::memcpy(db.data(), params, sizeof(double) * (size_t)np);
+    if (nimm > 0) std::memcpy(db.data() + np_pad, imm, sizeof(double) * (size_t)nimm);
+    if (ntab > 0) std::memcpy(db.data() + np_pad + nimm_pad, tab, sizeof(double) * ntab);
+    HIP_TRY_P(ctx->d_prop_i.reserve(ib.size(), false));
+    HIP_TRY_P(ctx->d_prop_d.reserve(db.size(), false));
+    HIP_TRY_P(hipMemcpyAsync(ctx->d_prop_i.p, ib.data(), ib.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY_P(hipMemcpyAsync(ctx->d_prop_d.p, db.data(), db.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY_P(hipStreamSynchronize(st));
+    ctx->prop_ns = ns;
+    ctx->prop_nr = nr;
+    ctx->prop_np = np;
+    ctx->prop_np_pad = np_pad;
+    ctx->prop_nimm_pad = nimm_pad;
+    ctx->prop_tab_len = tab_len > 0 ? tab_len : 0;
+    ctx->prop_ready = true;
+    return 0;
+}
+
+// states already on the device (n x lds int32) -> columns on the device
+int prop_eval_device(kfsp_ctx *ctx, int64_t n, const int32_t *d_state, int lds, double *d_off, int ldo, double *d_diag)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_propensities, dim3((int)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, prop_dev(ctx), n, d_state,
+                       lds, d_off, ldo, d_diag);
+    return 0;
+}
+
+// host arrays in, host arrays out
+int prop_eval_host(kfsp_ctx *ctx, int32_t n, const int32_t *state, int32_t lds, double *offdiag, int32_t ldo, double *diag)
+{
+    hipStream_t st = ctx->stream;
+    const size_t ns_b = (size_t)n * (size_t)lds * 4, no_b = (size_t)n * (size_t)ldo * 8, nd_b = (size_t)n * 8;
+    HIP_TRY_P(ctx->d_os1.reserve(ns_b + no_b + nd_b + 1024, false));
+    char *base = ctx->d_os1.p;
+    double *d_off = reinterpret_cast<double *>(base);
+    double *d_diag = reinterpret_cast<double *>(base + no_b);
+    int32_t *d_state = reinterpret_cast<int32_t *>(base + no_b + nd_b);
+    HIP_TRY_P(hipMemcpyAsync(d_state, state, ns_b, hipMemcpyHostToDevice, st));
+    if (int rc = prop_eval_device(ctx, n, d_state, lds, d_off, ldo, d_diag)) return rc;
+    HIP_TRY_P(hipMemcpyAsync(offdiag, d_off, no_b, hipMemcpyDeviceToHost, st));
+    HIP_TRY_P(hipMemcpyAsync(diag, d_diag, nd_b, hipMemcpyDeviceToHost, st));
+    HIP_TRY_P(hipStreamSynchronize(st));
+    return 0;
+}
+
+}  // namespace kfsp

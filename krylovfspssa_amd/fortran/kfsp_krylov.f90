@@ -52,12 +52,16 @@ MODULE KRYLOVSOLVER
   TYPE(CME_MODEL), POINTER, SAVE, PRIVATE :: CUR_MODEL => NULL()
   INTEGER, SAVE, PRIVATE :: CUR_TRACE = 0
   LOGICAL, SAVE, PRIVATE :: HOST_DROP = .FALSE.      ! KFSP_HOST_DROP=1: DROP_STATES decided on the host
+  ! the model's propensity program is resident on the device (kfsp_set_propensity_program): one-step sweeps on the
+  ! device return the complete columns of the states they append.  KFSP_DEVICE_PROPENSITY=0 keeps them on the host.
+  LOGICAL, SAVE, PRIVATE :: PROGRAM_READY = .FALSE., PROGRAM_WANTED = .TRUE.
   ! wall seconds spent in the host state-space code of the current solve:
   ! (1) DROP_STATES decision + compaction, (2) SSA_EXTENDER, (3) ONESTEP_EXTENDER,
   ! (4) uploads of the changed FSP
   DOUBLE PRECISION, SAVE, PRIVATE :: HOST_SEC(4) = 0.0D0
 
   PRIVATE :: ENSURE_CONTEXT, UPLOAD_FSP, CHECK, CB_DROP, CB_EXPAND, CB_LOG, WALL, DEVICE_ONESTEP
+  PUBLIC :: KFSP_UPLOAD_PROGRAM, KFSP_DEVICE_PROPENSITIES
 
 CONTAINS
 
@@ -102,6 +106,7 @@ CONTAINS
     ! the device context comes first: the threads its runtime starts must not
     ! inherit the one-core affinity the host sweeps give the calling thread
     CALL ENSURE_CONTEXT()
+    CALL KFSP_UPLOAD_PROGRAM(MODEL)
     N0 = FSP%SIZE
     ALLOCATE(P0(N0))
     P0 = V(1:N0)                       ! DCOPY(FSP%SIZE, V, 1, W, 1)  :176
@@ -236,6 +241,8 @@ CONTAINS
     ENDIF
     CALL GET_ENVIRONMENT_VARIABLE('KFSP_HOST_DROP', ENV, L, STAT)
     HOST_DROP = (STAT == 0 .AND. L > 0 .AND. ENV(1:1) /= '0')
+    CALL GET_ENVIRONMENT_VARIABLE('KFSP_DEVICE_PROPENSITY', ENV, L, STAT)
+    IF (STAT == 0 .AND. L > 0) PROGRAM_WANTED = ENV(1:1) /= '0' 
     ! any other library option (kfsp_set_option, include/kfsp.h): KFSP_OPTIONS="name=value,name=value"
     CALL GET_ENVIRONMENT_VARIABLE('KFSP_OPTIONS', OPTS, L, STAT)
     IF (STAT == 0 .AND. L > 0) THEN
@@ -270,18 +277,90 @@ CONTAINS
 
   ! STATESPACE's hook: kfsp_onestep on this module's context; the appended states and the
   ! completed links are written behind / into the caller's own arrays
-  INTEGER FUNCTION DEVICE_ONESTEP(NS, NR, STOICH, N, STATE, ADJ, MAXCOUNT, CAP, NNEW)
+  INTEGER FUNCTION DEVICE_ONESTEP(NS, NR, STOICH, N, STATE, ADJ, MAXCOUNT, CAP, NNEW, OFFDIAG, DIAG, COLUMNS)
     INTEGER, INTENT(IN) :: NS, NR, N, MAXCOUNT, CAP
     INTEGER, INTENT(IN) :: STOICH(NS, NR)
     INTEGER, INTENT(INOUT) :: STATE(NS, *), ADJ(NR, *)
     INTEGER, INTENT(OUT) :: NNEW
+    DOUBLE PRECISION, INTENT(INOUT) :: OFFDIAG(NR, *), DIAG(*)
+    LOGICAL, INTENT(OUT) :: COLUMNS
     INTEGER(C_INT32_T) :: NN
     NN = N
-    DEVICE_ONESTEP = KFSP_ONESTEP(CTX, INT(NS, C_INT32_T), INT(NR, C_INT32_T), STOICH, INT(N, C_INT32_T), STATE, &
-         INT(NS, C_INT32_T), ADJ, INT(NR, C_INT32_T), INT(MAXCOUNT, C_INT32_T), INT(CAP, C_INT32_T), NN, &
-         STATE(1:NS, N + 1:CAP), ADJ)
+    COLUMNS = PROGRAM_READY
+    IF (COLUMNS) THEN
+       ! the propensity program of the model is on the device: complete columns come back
+       DEVICE_ONESTEP = KFSP_ONESTEP_COLUMNS(CTX, INT(NS, C_INT32_T), INT(NR, C_INT32_T), STOICH, INT(N, C_INT32_T), STATE, &
+            INT(NS, C_INT32_T), ADJ, INT(NR, C_INT32_T), INT(MAXCOUNT, C_INT32_T), INT(CAP, C_INT32_T), NN, &
+            STATE(1:NS, N + 1:CAP), ADJ, OFFDIAG(1:NR, N + 1:CAP), INT(NR, C_INT32_T), DIAG(N + 1:CAP))
+    ELSE
+       DEVICE_ONESTEP = KFSP_ONESTEP(CTX, INT(NS, C_INT32_T), INT(NR, C_INT32_T), STOICH, INT(N, C_INT32_T), STATE, &
+            INT(NS, C_INT32_T), ADJ, INT(NR, C_INT32_T), INT(MAXCOUNT, C_INT32_T), INT(CAP, C_INT32_T), NN, &
+            STATE(1:NS, N + 1:CAP), ADJ)
+    ENDIF
     NNEW = NN
   END FUNCTION DEVICE_ONESTEP
+
+  ! The model's parsed propensities -> the device (kfsp_set_propensity_program).  Expressions of ONE species (every
+  ! Hill function and x (x - 1) / 2 of the shipped models) travel as tables made HERE with MODEL%PROPENSITY at every
+  ! population count 0..MAXNUMBERMOLECULES, so the device returns the host's own bits for them; the others as postfix
+  ! code (exact for + - * /).  Nothing happens for a compiled-in CUSTOMPROP (no code to hand over).
+  SUBROUTINE KFSP_UPLOAD_PROGRAM(MODEL, NO_TABLES)
+    TYPE(CME_MODEL), INTENT(IN) :: MODEL
+    LOGICAL, INTENT(IN), OPTIONAL :: NO_TABLES         ! (tests: everything through the device's interpreter)
+    INTEGER, ALLOCATABLE :: CODE_OFF(:), CODE(:), IMM_OFF(:), DEP(:), X(:)
+    DOUBLE PRECISION, ALLOCATABLE :: IMM(:), TAB(:, :)
+    DOUBLE PRECISION :: PDUMMY(1)
+    LOGICAL :: OK, TABLES
+    INTEGER :: K, V, TL
+    INTEGER(C_INT) :: RC
+    PROGRAM_READY = .FALSE.
+    CALL ENSURE_CONTEXT()
+    IF (.NOT. PROGRAM_WANTED) RETURN
+    CALL MODEL%EXPORT_PROGRAM(OK, CODE_OFF, CODE, IMM_OFF, IMM, DEP)
+    IF (.NOT. OK) RETURN
+    IF (MODEL%NSPECIES > 16 .OR. MODEL%NREACTIONS > 64) RETURN
+    TABLES = .TRUE.
+    IF (PRESENT(NO_TABLES)) TABLES = .NOT. NO_TABLES
+    TL = 0
+    IF (TABLES .AND. ANY(DEP >= 0)) TL = MAXNUMBERMOLECULES + 1
+    ALLOCATE(TAB(MAX(TL, 1), MODEL%NREACTIONS), X(MODEL%NSPECIES))
+    TAB = 0.0D0
+    IF (TL > 0) THEN
+       DO K = 1, MODEL%NREACTIONS
+          IF (DEP(K) < 0) CYCLE
+          X = 0
+          DO V = 0, TL - 1
+             X(DEP(K) + 1) = V
+             TAB(V + 1, K) = MODEL%PROPENSITY(X, K)
+          ENDDO
+       ENDDO
+    ELSE
+       DEP = -1
+    ENDIF
+    PDUMMY = 0.0D0
+    IF (MODEL%NPARAMETERS > 0) THEN
+       RC = KFSP_SET_PROPENSITY_PROGRAM(CTX, INT(MODEL%NSPECIES, C_INT32_T), INT(MODEL%NREACTIONS, C_INT32_T), &
+            INT(MODEL%NPARAMETERS, C_INT32_T), MODEL%PARAMETER_VAL, CODE_OFF, CODE, IMM_OFF, IMM, DEP, INT(TL, C_INT32_T), TAB)
+    ELSE
+       RC = KFSP_SET_PROPENSITY_PROGRAM(CTX, INT(MODEL%NSPECIES, C_INT32_T), INT(MODEL%NREACTIONS, C_INT32_T), &
+            0_C_INT32_T, PDUMMY, CODE_OFF, CODE, IMM_OFF, IMM, DEP, INT(TL, C_INT32_T), TAB)
+    ENDIF
+    PROGRAM_READY = RC == 0               ! (a program the device cannot take - stack too deep - stays on the host)
+  END SUBROUTINE KFSP_UPLOAD_PROGRAM
+
+  ! OFFDIAG / DIAG columns of N states through the resident program (kfsp_propensities); .FALSE. without one
+  LOGICAL FUNCTION KFSP_DEVICE_PROPENSITIES(N, STATE, OFFDIAG, DIAG) RESULT(DONE)
+    INTEGER, INTENT(IN) :: N
+    INTEGER, INTENT(IN) :: STATE(:, :)
+    DOUBLE PRECISION, INTENT(OUT) :: OFFDIAG(:, :), DIAG(:)
+    INTEGER(C_INT) :: RC
+    DONE = .FALSE.
+    IF (.NOT. PROGRAM_READY) RETURN
+    RC = KFSP_PROPENSITIES(CTX, INT(N, C_INT32_T), STATE, INT(SIZE(STATE, 1), C_INT32_T), OFFDIAG, &
+         INT(SIZE(OFFDIAG, 1), C_INT32_T), DIAG)
+    CALL CHECK(RC, 'kfsp_propensities')
+    DONE = .TRUE.
+  END FUNCTION KFSP_DEVICE_PROPENSITIES
 
   ! generator columns + probability vector of the current FSP -> device
   SUBROUTINE UPLOAD_FSP(FSP, MODEL, WITH_VECTOR, N_UNCHANGED)

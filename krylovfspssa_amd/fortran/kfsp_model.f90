@@ -42,6 +42,7 @@ MODULE MODELMODULE
      PROCEDURE :: LOAD
      PROCEDURE :: RESET_PARAMETERS
      PROCEDURE :: PROPENSITY => PROPENSITY_BUILTIN
+     PROCEDURE :: EXPORT_PROGRAM
   END TYPE CME_MODEL
 
   PRIVATE :: UPPER, FIRST_TOKEN, NEXT_LINE, PARSE_REACTION
@@ -169,6 +170,56 @@ CONTAINS
        PROPENSITY_BUILTIN = EXPR_EVAL(THIS%PROPEXPR(REACTION), VAL)
     ENDIF
   END FUNCTION PROPENSITY_BUILTIN
+
+  ! The parsed propensities as the flat postfix program of kfsp_set_propensity_program (include/kfsp.h): reaction k
+  ! is CODE(CODE_OFF(k)+1 : CODE_OFF(k+1)) with immediates IMM(IMM_OFF(k)+1 : IMM_OFF(k+1)) (offsets 0-based, as the C
+  ! side wants them); DEP_SPECIES(k) = the one species (0-based) the expression refers to - 0 if it refers to none -
+  ! or -1 if it refers to several.  OK = .FALSE.: the model evaluates a compiled-in CUSTOMPROP, there is no code.
+  SUBROUTINE EXPORT_PROGRAM(THIS, OK, CODE_OFF, CODE, IMM_OFF, IMM, DEP_SPECIES)
+    CLASS(CME_MODEL), INTENT(IN) :: THIS
+    LOGICAL, INTENT(OUT) :: OK
+    INTEGER, ALLOCATABLE, INTENT(OUT) :: CODE_OFF(:), CODE(:), IMM_OFF(:), DEP_SPECIES(:)
+    DOUBLE PRECISION, ALLOCATABLE, INTENT(OUT) :: IMM(:)
+    INTEGER :: K, J, NC, NI, V, S
+    OK = .NOT. ASSOCIATED(THIS%CUSTOMPROP) .AND. ALLOCATED(THIS%PROPEXPR)
+    IF (.NOT. OK) RETURN
+    ALLOCATE(CODE_OFF(THIS%NREACTIONS + 1), IMM_OFF(THIS%NREACTIONS + 1), DEP_SPECIES(THIS%NREACTIONS))
+    NC = 0
+    NI = 0
+    DO K = 1, THIS%NREACTIONS
+       CODE_OFF(K) = NC
+       IMM_OFF(K) = NI
+       IF (THIS%PROPEXPR(K)%VALID) THEN            ! (an expression that did not parse evaluates to 0: no code)
+          NC = NC + THIS%PROPEXPR(K)%NCODE
+          NI = NI + COUNT(THIS%PROPEXPR(K)%CODE(1:THIS%PROPEXPR(K)%NCODE) == 1)
+       ENDIF
+    ENDDO
+    CODE_OFF(THIS%NREACTIONS + 1) = NC
+    IMM_OFF(THIS%NREACTIONS + 1) = NI
+    ALLOCATE(CODE(MAX(NC, 1)), IMM(MAX(NI, 1)))
+    CODE = 0
+    IMM = 0.0D0
+    DO K = 1, THIS%NREACTIONS
+       S = -2                                      ! -2: no species seen yet
+       IF (THIS%PROPEXPR(K)%VALID) THEN
+          DO J = 1, THIS%PROPEXPR(K)%NCODE
+             V = THIS%PROPEXPR(K)%CODE(J)
+             CODE(CODE_OFF(K) + J) = V
+             IF (V > 100 .AND. V <= 100 + THIS%NSPECIES) THEN
+                IF (S == -2) THEN
+                   S = V - 101
+                ELSEIF (S /= V - 101) THEN
+                   S = -1
+                ENDIF
+             ENDIF
+          ENDDO
+          J = IMM_OFF(K + 1) - IMM_OFF(K)
+          IF (J > 0) IMM(IMM_OFF(K) + 1:IMM_OFF(K) + J) = THIS%PROPEXPR(K)%IMM(1:J)
+       ENDIF
+       IF (S == -2) S = 0
+       DEP_SPECIES(K) = S
+    ENDDO
+  END SUBROUTINE EXPORT_PROGRAM
 
   SUBROUTINE RESET_PARAMETERS(THIS, PVAL)
     CLASS(CME_MODEL) :: THIS

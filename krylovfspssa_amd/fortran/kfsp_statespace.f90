@@ -93,11 +93,15 @@ MODULE STATESPACE
   ! (environment KFSP_DEVICE_ONESTEP_MIN, default 20000; KFSP_DEVICE_ONESTEP=0 switches it off).
   ! Returns 0, -9 (state keys need more than 63 bits: the host sweep runs instead) or -11 (capacity).
   ABSTRACT INTERFACE
-     INTEGER FUNCTION ONESTEP_DEVICE_FN(NS, NR, STOICH, N, STATE, ADJ, MAXCOUNT, CAP, NNEW)
+     INTEGER FUNCTION ONESTEP_DEVICE_FN(NS, NR, STOICH, N, STATE, ADJ, MAXCOUNT, CAP, NNEW, OFFDIAG, DIAG, COLUMNS)
        INTEGER, INTENT(IN) :: NS, NR, N, MAXCOUNT, CAP
        INTEGER, INTENT(IN) :: STOICH(NS, NR)
        INTEGER, INTENT(INOUT) :: STATE(NS, *), ADJ(NR, *)      ! new states / completed links are written in place
        INTEGER, INTENT(OUT) :: NNEW
+       ! .TRUE. on return: OFFDIAG(:, N+1:NNEW) and DIAG(N+1:NNEW) were filled in as well (the model's propensity
+       ! program runs on the device, kfsp_onestep_columns); .FALSE.: the caller evaluates the propensities
+       DOUBLE PRECISION, INTENT(INOUT) :: OFFDIAG(NR, *), DIAG(*)
+       LOGICAL, INTENT(OUT) :: COLUMNS
      END FUNCTION ONESTEP_DEVICE_FN
   END INTERFACE
   PROCEDURE(ONESTEP_DEVICE_FN), POINTER, SAVE :: ONESTEP_DEVICE => NULL()
@@ -643,7 +647,7 @@ CONTAINS
     INTEGER :: L, STAT, RC, N0, NNEW, SD, PD, I, K, NT
     INTEGER(8) :: TCLK
     DOUBLE PRECISION :: A
-    LOGICAL :: PARPROP
+    LOGICAL :: PARPROP, COLUMNS
     DONE = .FALSE.
     IF (.NOT. ASSOCIATED(ONESTEP_DEVICE)) RETURN
     IF (ONESTEP_DEVICE_MIN < 0) THEN
@@ -662,38 +666,49 @@ CONTAINS
     IF (SIZE(FSP%STATE, 1) /= SD .OR. SIZE(FSP%MATRIX%ADJ, 1) /= PD) RETURN
     CALL TICK(0, TCLK)
     RC = ONESTEP_DEVICE(SD, PD, MODEL%STOICHIOMETRY(1:SD, 1:PD), N0, FSP%STATE, FSP%MATRIX%ADJ, MAXNUMBERMOLECULES, &
-         FSP%MAX_SIZE - 1, NNEW)
+         FSP%MAX_SIZE - 1, NNEW, FSP%MATRIX%OFFDIAG, FSP%MATRIX%DIAG, COLUMNS)
     IF (RC == -11) STOP 'OVERFLOW ERROR: FSP SIZE EXCEEDS MEMORY LIMIT.'
     IF (RC /= 0) RETURN                      ! (-9: keys too wide) the host sweep takes over
     CALL TICK(1, TCLK)
     DONE = .TRUE.
     IF (NNEW == N0) RETURN
     CALL RESERVE_TABLE(FSP, NNEW)
-    PARPROP = .NOT. ASSOCIATED(MODEL%CUSTOMPROP) .OR. CUSTOMPROP_IS_PURE()
-    NT = HOST_THREADS(NNEW - N0, 1024)
-    !$OMP PARALLEL DO NUM_THREADS(NT) SCHEDULE(STATIC) IF(NT > 1) PRIVATE(K, A)
-    DO I = N0 + 1, NNEW
-       FSP%KEY(I) = STATE_HASH(FSP%STATE(1:SD, I))
-       FSP%VECTOR(I) = 0.0D0
-       IF (PARPROP) THEN
-          FSP%MATRIX%DIAG(I) = 0.0D0
-          DO K = 1, PD
-             A = MODEL%PROPENSITY(FSP%STATE(1:SD, I), K)
-             FSP%MATRIX%DIAG(I) = FSP%MATRIX%DIAG(I) + A
-             FSP%MATRIX%OFFDIAG(K, I) = A
+    IF (COLUMNS) THEN
+       ! the device made the propensity columns as well: what is left is the host's own look-up structure
+       NT = HOST_THREADS(NNEW - N0, 4096)
+       !$OMP PARALLEL DO NUM_THREADS(NT) SCHEDULE(STATIC) IF(NT > 1)
+       DO I = N0 + 1, NNEW
+          FSP%KEY(I) = STATE_HASH(FSP%STATE(1:SD, I))
+          FSP%VECTOR(I) = 0.0D0
+       ENDDO
+       !$OMP END PARALLEL DO
+    ELSE
+       PARPROP = .NOT. ASSOCIATED(MODEL%CUSTOMPROP) .OR. CUSTOMPROP_IS_PURE()
+       NT = HOST_THREADS(NNEW - N0, 1024)
+       !$OMP PARALLEL DO NUM_THREADS(NT) SCHEDULE(STATIC) IF(NT > 1) PRIVATE(K, A)
+       DO I = N0 + 1, NNEW
+          FSP%KEY(I) = STATE_HASH(FSP%STATE(1:SD, I))
+          FSP%VECTOR(I) = 0.0D0
+          IF (PARPROP) THEN
+             FSP%MATRIX%DIAG(I) = 0.0D0
+             DO K = 1, PD
+                A = MODEL%PROPENSITY(FSP%STATE(1:SD, I), K)
+                FSP%MATRIX%DIAG(I) = FSP%MATRIX%DIAG(I) + A
+                FSP%MATRIX%OFFDIAG(K, I) = A
+             ENDDO
+          ENDIF
+       ENDDO
+       !$OMP END PARALLEL DO
+       IF (.NOT. PARPROP) THEN
+          DO I = N0 + 1, NNEW
+             FSP%MATRIX%DIAG(I) = 0.0D0
+             DO K = 1, PD
+                A = MODEL%PROPENSITY(FSP%STATE(1:SD, I), K)
+                FSP%MATRIX%DIAG(I) = FSP%MATRIX%DIAG(I) + A
+                FSP%MATRIX%OFFDIAG(K, I) = A
+             ENDDO
           ENDDO
        ENDIF
-    ENDDO
-    !$OMP END PARALLEL DO
-    IF (.NOT. PARPROP) THEN
-       DO I = N0 + 1, NNEW
-          FSP%MATRIX%DIAG(I) = 0.0D0
-          DO K = 1, PD
-             A = MODEL%PROPENSITY(FSP%STATE(1:SD, I), K)
-             FSP%MATRIX%DIAG(I) = FSP%MATRIX%DIAG(I) + A
-             FSP%MATRIX%OFFDIAG(K, I) = A
-          ENDDO
-       ENDDO
     ENDIF
     FSP%SIZE = NNEW
     FSP%MATRIX%SIZE = NNEW

@@ -62,6 +62,9 @@ def load_library():
         "kfsp_num_states": [vp, C.POINTER(i64)],
         "kfsp_layout_info": [vp, vp],
         "kfsp_onestep": [vp, i32, i32, vp, i32, vp, i32, vp, i32, i32, i32, C.POINTER(i32), vp, vp],
+        "kfsp_onestep_columns": [vp, i32, i32, vp, i32, vp, i32, vp, i32, i32, i32, C.POINTER(i32), vp, vp, vp, i32, vp],
+        "kfsp_set_propensity_program": [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp],
+        "kfsp_propensities": [vp, i32, vp, i32, vp, i32, vp],
         "kfsp_drop_plan": [vp, dbl, C.POINTER(dbl), C.POINTER(i64), C.POINTER(i64)],
         "kfsp_drop_flags": [vp, i64, vp],
         "kfsp_drop_compact": [vp, C.POINTER(i64)],
@@ -346,6 +349,33 @@ class KfspContext:
                                          C.byref(n_new), _p(st_new), _p(adj_out)), "kfsp_onestep")
         m = n_new.value
         return np.concatenate([state, st_new[:m - n]]), adj_out[:m].copy()
+
+    def set_propensity_program(self, ns, params, programs, tables=None):
+        """programs: per reaction (code list, immediates list); tables: None or (tab_species [nr], tab [nr][tab_len])"""
+        nr = len(programs)
+        code_off = np.concatenate(([0], np.cumsum([len(c) for c, _ in programs]))).astype(np.int32)
+        imm_off = np.concatenate(([0], np.cumsum([len(i) for _, i in programs]))).astype(np.int32)
+        code = np.array([v for c, _ in programs for v in c] or [0], dtype=np.int32)
+        imm = np.array([v for _, i in programs for v in i] or [0.0], dtype=np.float64)
+        params = np.ascontiguousarray(params, dtype=np.float64)
+        if tables is None:
+            ts, tab, tl = np.full(nr, -1, dtype=np.int32), np.zeros(1), 0
+        else:
+            ts = np.ascontiguousarray(tables[0], dtype=np.int32)
+            tab = np.ascontiguousarray(tables[1], dtype=np.float64)
+            tl = tab.shape[1]
+        self._chk(self._lib.kfsp_set_propensity_program(self._h, int(ns), nr, len(params), _p(params) if len(params) else None,
+                                                        _p(code_off), _p(code), _p(imm_off), _p(imm), _p(ts), int(tl), _p(tab)),
+                  "kfsp_set_propensity_program")
+        self._prop_nr = nr
+
+    def propensities(self, state):
+        state = np.ascontiguousarray(state, dtype=np.int32)
+        n, ns = state.shape
+        off = np.zeros((n, self._prop_nr))
+        diag = np.zeros(n)
+        self._chk(self._lib.kfsp_propensities(self._h, n, _p(state), ns, _p(off), self._prop_nr, _p(diag)), "kfsp_propensities")
+        return off, diag
 
     def drop_plan(self, dsum):
         """DROP_STATES decision on the device -> (droptol, drop_count, n_flagged)."""

@@ -12,6 +12,10 @@
 ! usage:  kfsp_replay <case> <script.bin> <steps.bin> <out.bin> [T] [safe|safestop|-] [digest]
 !         kfsp_replay rkey <model> <out.txt>     COMPUTE_RKEY of our STATESPACE for one of the
 !                                                .input models: one line "sign key" per reaction
+!         kfsp_replay proptable <out.bin> [notab]   the grid of ref_dump exprtable (expr_test_model.input, 13 x 13 x 3
+!                                                states, 16 propensities) evaluated ON THE DEVICE through the model's
+!                                                propensity program (kfsp_propensities); notab: no host-made tables,
+!                                                every expression through the device's interpreter
 !   script.bin: int64 rows; f64 script(4, rows)
 !   forks go to <steps.bin>.forks: int32 rc, nforks, rows_used_lo, rows_used_hi ... see below
 MODULE REPLAY_OBSERVER
@@ -113,6 +117,10 @@ PROGRAM KFSP_REPLAY_MAIN
      CALL DO_RKEY(TRIM(SCRIPTFILE), TRIM(STEPFILE))
      STOP
   ENDIF
+  IF (TRIM(CASENAME) == 'proptable') THEN
+     CALL DO_DEVICE_PROPTABLE(TRIM(SCRIPTFILE), TRIM(STEPFILE))
+     STOP
+  ENDIF
   CALL RANDOM_SEED()
   CALL SETUP_SOLVE_CASE(TRIM(CASENAME), MODEL, FSP_IN, FSP, T, FSPTOL, KRYTOL)
   IF (LEN_TRIM(TARG) > 0 .AND. TRIM(TARG) /= '-') READ(TARG, *) T
@@ -157,6 +165,30 @@ PROGRAM KFSP_REPLAY_MAIN
   PRINT *, 'FINAL SIZE', FSP%SIZE
   PRINT *, 'FINAL SUM ', SUM(FSP%VECTOR(1:FSP%SIZE))
 CONTAINS
+  SUBROUTINE DO_DEVICE_PROPTABLE(FNAME, MODE)
+    CHARACTER(LEN=*), INTENT(IN) :: FNAME, MODE
+    TYPE(CME_MODEL) :: M
+    INTEGER :: ST(3, 3 * 13 * 13), I, J, K, N, UU
+    DOUBLE PRECISION :: OFF(16, 3 * 13 * 13), DG(3 * 13 * 13)
+    CALL M%LOAD('expr_test_model.input')
+    CALL M%RESET_PARAMETERS((/7.5D0, 2.0D0, 0.75D0, 0.3D0, 4.0D0/))
+    N = 0
+    DO I = 0, 12                                   ! the order of ref_dump's P(16, 3, 13, 13): DNA.2D fastest, then Y, X
+       DO J = 0, 12
+          DO K = 0, 2
+             N = N + 1
+             ST(:, N) = (/I, J, K/)
+          ENDDO
+       ENDDO
+    ENDDO
+    CALL KFSP_UPLOAD_PROGRAM(M, NO_TABLES=(MODE == 'notab'))
+    IF (.NOT. KFSP_DEVICE_PROPENSITIES(N, ST, OFF, DG)) STOP 'no propensity program on the device'
+    OPEN(NEWUNIT=UU, FILE=FNAME, ACCESS='STREAM', FORM='UNFORMATTED', STATUS='REPLACE')
+    WRITE(UU) OFF
+    WRITE(UU) DG
+    CLOSE(UU)
+  END SUBROUTINE DO_DEVICE_PROPTABLE
+
   SUBROUTINE DO_RKEY(NAME, FNAME)
     CHARACTER(LEN=*), INTENT(IN) :: NAME, FNAME
     TYPE(CME_MODEL) :: M
