@@ -275,6 +275,25 @@ int kfsp_onestep_columns(kfsp_ctx *ctx, int32_t ns, int32_t nr, const int32_t *s
                          int32_t *n_new, int32_t *state_new, int32_t *adj_out, double *offdiag_new, int32_t ld_off,
                          double *diag_new);
 
+/* ---- SSA paths on the device: the INDEPENDENT-STREAM expansion ---------------------------------------------- */
+/* The reference's SSA_EXTENDER (StateSpace.f90:550-630) draws all paths from ONE random stream and lets each see the
+ * states of the earlier ones: sequential by definition, it stays on the host.  What runs here is the host's opt-in
+ * variant (SSA_EXTENDER_STREAMS of krylovfspssa_amd/fortran/kfsp_statespace.f90, KFSP_SSA_STREAMS=1): one path of
+ * length `timestep` from EVERY listed state, each on a Lehmer stream of its own seeded from (seedmix, index of the
+ * seed state), walking the FSP as it stands (state / adj / offdiag / diag: the reference's arrays, host memory),
+ * passing through unlisted states on propensities of the model's program (kfsp_set_propensity_program), stopping at
+ * a negative or > max_count population, at an absorbing state, or when it falls back onto an earlier seed.  Out: the
+ * DISTINCT unlisted states the paths met, in (seed state, position on the path) order of their first occurrence -
+ * state_new[ld_state][*n_found] - with their propensity columns offdiag_new[ld_off][*n_found], diag_new[*n_found];
+ * the caller appends and links them.  The arithmetic (generator, reaction choice, the waiting time through a
+ * fixed-sequence logarithm) is defined so that the host variant and this one give the same states in the same
+ * order, bit for bit, whenever the program's propensities are bit-exact (tables / + - * /, i.e. all shipped models).
+ * Returns -11 when more than capacity_new states were found (nothing is returned then). */
+int kfsp_ssa_streams(kfsp_ctx *ctx, double timestep, int64_t seedmix, int32_t ns, int32_t nr, const int32_t *stoich, int32_t n,
+                     const int32_t *state, int32_t ld_state, const int32_t *adj, const double *offdiag, int32_t ld_adj,
+                     const double *diag, int32_t max_count, int32_t capacity_new, int32_t *n_found, int32_t *state_new,
+                     double *offdiag_new, int32_t ld_off, double *diag_new);
+
 /* single reductions over the resident w (tests; FIND_DROPTOL-style sums) */
 int kfsp_nrm2_w(kfsp_ctx *ctx, double *out);
 int kfsp_asum_w(kfsp_ctx *ctx, double *out);

@@ -1762,6 +1762,35 @@ int kfsp_set_propensity_program(kfsp_ctx *ctx, int32_t ns, int32_t nr, int32_t n
     });
 }
 
+int kfsp_ssa_streams(kfsp_ctx *ctx, double timestep, int64_t seedmix, int32_t ns, int32_t nr, const int32_t *stoich, int32_t n,
+                     const int32_t *state, int32_t ld_state, const int32_t *adj, const double *offdiag, int32_t ld_adj,
+                     const double *diag, int32_t max_count, int32_t capacity_new, int32_t *n_found, int32_t *state_new,
+                     double *offdiag_new, int32_t ld_off, double *diag_new)
+{
+    return no_throw(ctx, [&]() -> int {
+        if (!ctx) return -1;
+        if (ctx->group) ctx = kfsp::group_rank0(ctx);      // the whole lists, no collective inside: one rank does it
+        if (!(timestep > 0.0)) return fail(ctx, -2, "timestep must be positive");
+        if (ns < 1 || ns > 16) return fail(ctx, -4, "1 <= ns <= 16");
+        if (nr < 1 || nr > 64) return fail(ctx, -5, "1 <= nr <= 64");
+        if (!stoich) return fail(ctx, -6, "null stoich");
+        if (n < 1) return fail(ctx, -7, "n < 1");
+        if (!state || ld_state < ns) return fail(ctx, -8, "bad state / ld_state");
+        if (!adj || !offdiag || ld_adj < nr || !diag) return fail(ctx, -10, "bad adj / offdiag / ld_adj / diag");
+        if (max_count < 1) return fail(ctx, -14, "max_count < 1");
+        if (capacity_new < 0 || !n_found || !state_new) return fail(ctx, -15, "bad capacity_new / outputs");
+        if (!offdiag_new || ld_off < nr || !diag_new) return fail(ctx, -18, "bad offdiag_new / ld_off / diag_new");
+        if (!ctx->prop_ready || ctx->prop_ns != ns || ctx->prop_nr != nr)
+            return fail(ctx, -1, "no propensity program for this model (kfsp_set_propensity_program)");
+        HIP_TRY(hipSetDevice(ctx->device));
+        const auto t0 = std::chrono::steady_clock::now();
+        const int rc = kfsp::ssa_streams_device(ctx, timestep, seedmix, ns, nr, stoich, n, state, ld_state, adj, offdiag, ld_adj, diag,
+                                                max_count, capacity_new, n_found, state_new, offdiag_new, ld_off, diag_new);
+        ctx->t_ms[KFSP_T_ONESTEP] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return rc;
+    });
+}
+
 int kfsp_propensities(kfsp_ctx *ctx, int32_t n, const int32_t *state, int32_t ld_state, double *offdiag, int32_t ld_off, double *diag)
 {
     return no_throw(ctx, [&]() -> int {

@@ -352,5 +352,10 @@ int prop_set_program(kfsp_ctx *ctx, int32_t ns, int32_t nr, int32_t np, const do
                      const int32_t *code, const int32_t *imm_off, const double *imm, const int32_t *tab_species, int32_t tab_len,
                      const double *tab);
 int prop_eval_device(kfsp_ctx *ctx, int64_t n, const int32_t *d_state, int lds, double *d_off, int ldo, double *d_diag);
+// SSA paths on independent streams (kfsp_ssa.hip); all arrays are host memory
+int ssa_streams_device(kfsp_ctx *ctx, double tstep, int64_t seedmix, int32_t ns, int32_t nr, const int32_t *stoich, int32_t n,
+                       const int32_t *state, int32_t lds, const int32_t *adj, const double *offdiag, int32_t lda, const double *diag,
+                       int32_t max_count, int32_t cap_new, int32_t *n_found, int32_t *state_new, double *off_new, int32_t ldo,
+                       double *diag_new);
 int prop_eval_host(kfsp_ctx *ctx, int32_t n, const int32_t *state, int32_t lds, double *offdiag, int32_t ldo, double *diag);
 }  // namespace kfsp

@@ -1,0 +1,369 @@
+// SSA paths on the device - the INDEPENDENT-STREAM expansion ("parallel SSA paths with a
+// counter-based generator").
+//
+// The reference's SSA_EXTENDER (src/state_space/StateSpace.f90:550-630) walks one stochastic path of length
+// TIMESTEP from every listed state on ONE random stream, each path seeing the states the earlier ones added: the
+// walk is sequential by definition and stays on the host.  The host's opt-in variant SSA_EXTENDER_STREAMS
+// (krylovfspssa_amd/fortran/kfsp_statespace.f90, KFSP_SSA_STREAMS=1) gives every path a stream of its own - a
+// Lehmer generator seeded from (one number per call, index of the seed state) - walks the FSP as it stood at the
+// call, passes through unlisted states by evaluating their propensities on the fly, and appends the states met in
+// (seed state, position on the path) order, first occurrence first.  THAT variant is what runs here, one lane per
+// path, and it is defined so that host and device produce the same bits:
+//   * the generator, the mixing of the seed and the choice of the reaction are integer / single IEEE operations
+//   * the exponential waiting time uses plog() below instead of the math library's log: a fixed sequence of IEEE
+//     operations that the Fortran host (KFSP_PLOG) performs identically
+//   * propensities of unlisted states come from the model's program (kfsp_prop_dev.h): host-made tables or exact
+//     + - * / code for every shipped model (an expression with library functions of several species may differ
+//     from the host's in the last bits, and a path that hinges on it with them - documented in kfsp.h)
+// Two passes over the paths (count the records, then write them at their final offsets) make the record list
+// deterministic without a sort; duplicates are removed through a hash table with an atomic MIN on the record
+// index (the set of survivors does not depend on the order of the insertions).
+#include "kfsp_prop_dev.h"
+
+#include <hipcub/hipcub.hpp>
+
+#include <climits>
+#include <cstring>
+
+#pragma clang fp contract(off)
+
+namespace kfsp {
+
+namespace {
+
+constexpr int kSsaMaxS = 16, kSsaMaxR = 64;
+
+struct SsaDev {
+    int ns, nr, n0, max_count, lds, lda;
+    double tstep;
+    unsigned long long seedmix;
+    const int32_t *state;      // [n0][lds]
+    const int32_t *adj;        // [n0][lda], the reference's encoding
+    const double *off;         // [n0][lda]
+    const double *diag;        // [n0]
+    const int32_t *nu;         // [nr][ns]
+    const int32_t *tab;        // hash table of the listed states: index + 1, 0 = empty
+    unsigned tmask;
+    PropDev P;
+};
+
+__device__ __forceinline__ unsigned hash_state(const int32_t *x, int ns)
+{
+    unsigned long long h = 0x9E3779B97F4A7C15ull;
+    for (int s = 0; s < ns; ++s) {
+        h ^= (unsigned long long)(unsigned)x[s] + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+        h *= 0xBF58476D1CE4E5B9ull;
+        h ^= h >> 29;
+    }
+    return (unsigned)(h ^ (h >> 32));
+}
+
+// index (1-based) of state y among the listed ones, 0 = not listed
+__device__ __forceinline__ int lookup_state(const SsaDev &A, const int32_t *y)
+{
+    unsigned slot = hash_state(y, A.ns) & A.tmask;
+    for (;;) {
+        const int e = A.tab[slot];
+        if (e == 0) return 0;
+        const int32_t *z = A.state + (int64_t)(e - 1) * A.lds;
+        bool same = true;
+        for (int s = 0; s < A.ns; ++s) same = same && z[s] == y[s];
+        if (same) return e;
+        slot = (slot + 1) & A.tmask;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_ht_build(int n, int ns, int lds, const int32_t *__restrict__ state, int32_t *tab, unsigned mask)
+{
+    const int j = blockIdx.x * kBlock + threadIdx.x;
+    if (j >= n) return;
+    unsigned slot = hash_state(state + (int64_t)j * lds, ns) & mask;
+    for (;;) {
+        if (atomicCAS(&tab[slot], 0, j + 1) == 0) return;
+        slot = (slot + 1) & mask;
+    }
+}
+
+// log of 0 < x <= 1 by a fixed sequence of IEEE operations (no library call, no contraction): x = m 2^e with m in
+// [sqrt(1/2), sqrt(2)), s = (m - 1) / (m + 1), log m = 2 s (1 + s^2/3 + s^4/5 + ... + s^22/23), log x = e ln2 + log m.
+// KFSP_PLOG of the Fortran host is the same sequence; ~1e-16 relative.
+__device__ __forceinline__ double plog(double x)
+{
+    int e;
+    double m = frexp(x, &e);                      // x = m 2^e, m in [0.5, 1)
+    if (m < 0.70710678118654752440) {
+        m = m + m;
+        e = e - 1;
+    }
+    const double f = m - 1.0;
+    const double s = f / (2.0 + f);
+    const double z = s * s;
+    double p = 1.0 / 23.0;
+    for (int k = 21; k >= 3; k -= 2) {
+        p = p * z;
+        p = p + 1.0 / (double)k;
+    }
+    p = p * z;
+    const double two_s = s + s;
+    const double r = two_s + two_s * p;
+    const double de = (double)e;
+    const double hi = de * 6.93147180369123816490e-01;
+    const double lo = de * 1.90821492927058770002e-10;
+    return hi + (lo + r);
+}
+
+constexpr unsigned long long kLcgA = 48271ull, kLcgM = 2147483647ull, kLcgLow = 1073741823ull;
+
+__device__ __forceinline__ double lcg_uniform(unsigned long long &rs)
+{
+    const unsigned long long g1 = rs;
+    rs = (rs * kLcgA) % kLcgM;
+    const unsigned long long g2 = rs;
+    rs = (rs * kLcgA) % kLcgM;
+    return (double)(((g1 << 30) | ((g2 - 1ull) & kLcgLow)) >> 7) * 0x1p-54;
+}
+
+// One path (STREAM_PATH of the host).  WRITE = false: count its records; true: write them at rec[recoff[j0]..].
+template <bool WRITE>
+__global__ __launch_bounds__(kBlock) void k_ssa_walk(SsaDev A, int32_t *__restrict__ cnt, const long long *__restrict__ recoff,
+                                                     int32_t *__restrict__ rec)
+{
+    const int j0 = blockIdx.x * kBlock + threadIdx.x + 1;          // 1-based seed state, as on the host
+    if (j0 > A.n0) return;
+    // the path's own stream: a 64-bit mix of (call, seed state) folded into the generator's range
+    unsigned long long rs = (A.seedmix * 2654435761ull) ^ ((unsigned long long)j0 * 40503ull + 12345ull);
+    rs = ((rs ^ (rs >> 29)) & 4294967295ull) * 1181783497ull;
+    rs = 1ull + (((rs ^ (rs >> 32)) & 9223372036854775807ull) % (kLcgM - 1ull));
+    int j = j0;
+    bool virt = false;
+    int32_t x[kSsaMaxS], y[kSsaMaxS];
+    for (int s = 0; s < A.ns; ++s) x[s] = A.state[(int64_t)(j - 1) * A.lds + s];
+    double tt = 0.0;
+    int nrec = 0;
+    long long base = WRITE ? recoff[j0 - 1] : 0;
+    double pr[kSsaMaxR];
+    for (;;) {
+        double r1 = lcg_uniform(rs);
+        const double r2 = lcg_uniform(rs);
+        if (r1 <= 0.0) r1 = 0x1p-54;
+        double a0;
+        if (virt) {
+            a0 = 0.0;
+            for (int k = 0; k < A.nr; ++k) {
+                pr[k] = prop_eval(A.P, k, x);
+                a0 = a0 + pr[k];
+            }
+        } else {
+            a0 = A.diag[j - 1];
+            for (int k = 0; k < A.nr; ++k) pr[k] = A.off[(int64_t)(j - 1) * A.lda + k];
+        }
+        if (!(a0 > 0.0)) break;                                    // absorbing state
+        tt = fmin(A.tstep, tt + (-plog(r1) / a0));
+        double acc = pr[0];
+        int k = 0;
+        const double r2a = fmin(r2 * a0, a0);
+        while (acc < r2a && k < A.nr - 1) {
+            ++k;
+            acc = acc + pr[k];
+        }
+        bool neg = false;
+        for (int s = 0; s < A.ns; ++s) {
+            y[s] = x[s] + A.nu[k * A.ns + s];
+            neg = neg || y[s] < 0;
+        }
+        if (neg) break;
+        int idx = 0;
+        if (!virt) idx = max(A.adj[(int64_t)(j - 1) * A.lda + k], 0);
+        if (idx == 0) {
+            bool legal = true;
+            for (int s = 0; s < A.ns; ++s) legal = legal && y[s] <= A.max_count;
+            if (!legal) break;
+            idx = lookup_state(A, y);
+        }
+        for (int s = 0; s < A.ns; ++s) x[s] = y[s];
+        if (idx > 0) {
+            j = idx;
+            virt = false;
+            if (j < j0) break;                                     // fell back onto an earlier seed
+        } else {
+            virt = true;
+            if (WRITE)
+                for (int s = 0; s < A.ns; ++s) rec[(base + nrec) * A.ns + s] = y[s];
+            ++nrec;
+        }
+        if (!(tt < A.tstep)) break;
+    }
+    if (!WRITE) cnt[j0 - 1] = nrec;
+}
+
+// duplicates among the records: one table slot per distinct state, minidx[slot] = its first record
+__global__ __launch_bounds__(kBlock) void k_rec_insert(long long nrec, int ns, const int32_t *__restrict__ rec, int32_t *tab2,
+                                                       int32_t *minidx, unsigned mask)
+{
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nrec) return;
+    const int32_t *y = rec + i * ns;
+    unsigned slot = hash_state(y, ns) & mask;
+    for (;;) {
+        int cur = tab2[slot];
+        if (cur == 0) cur = atomicCAS(&tab2[slot], 0, (int)i + 1);
+        if (cur == 0) {                                            // claimed: this record names the slot
+            atomicMin(&minidx[slot], (int)i);
+            return;
+        }
+        const int32_t *z = rec + (long long)(cur - 1) * ns;
+        bool same = true;
+        for (int s = 0; s < ns; ++s) same = same && z[s] == y[s];
+        if (same) {
+            atomicMin(&minidx[slot], (int)i);
+            return;
+        }
+        slot = (slot + 1) & mask;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_rec_first(unsigned slots, const int32_t *__restrict__ tab2, const int32_t *__restrict__ minidx,
+                                                      uint8_t *__restrict__ first)
+{
+    const unsigned s = blockIdx.x * kBlock + threadIdx.x;
+    if (s < slots && tab2[s] != 0) first[minidx[s]] = 1;
+}
+
+__global__ __launch_bounds__(kBlock) void k_rec_gather(int nnew, int ns, int lds, const int32_t *__restrict__ sel, const int32_t *__restrict__ rec,
+                                                       int32_t *__restrict__ out)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nnew) return;
+    for (int s = 0; s < lds; ++s) out[(int64_t)i * lds + s] = s < ns ? rec[(int64_t)sel[i] * ns + s] : 0;
+}
+
+__global__ __launch_bounds__(kBlock) void k_iota(long long n, int32_t *v)
+{
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) v[i] = (int32_t)i;
+}
+
+struct Arena {
+    char *p;
+    template <class T>
+    T *take(size_t n)
+    {
+        T *r = reinterpret_cast<T *>(p);
+        p += (n * sizeof(T) + 255) / 256 * 256;
+        return r;
+    }
+};
+
+}  // namespace
+
+#define SSA_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            ctx->err = std::string(#expr) + ": " + hipGetErrorString(e_);                  \
+            return 1000 + (int)e_;                                                         \
+        }                                                                                  \
+    } while (0)
+
+int ssa_streams_device(kfsp_ctx *ctx, double tstep, int64_t seedmix, int32_t ns, int32_t nr, const int32_t *stoich, int32_t n,
+                       const int32_t *state, int32_t lds, const int32_t *adj, const double *offdiag, int32_t lda, const double *diag,
+                       int32_t max_count, int32_t cap_new, int32_t *n_found, int32_t *state_new, double *off_new, int32_t ldo,
+                       double *diag_new)
+{
+    hipStream_t st = ctx->stream;
+    const auto blocks = [](long long k) { return (int)std::max<long long>(1, (k + kBlock - 1) / kBlock); };
+    unsigned slots = 64;
+    while (slots < 2u * (unsigned)n) slots <<= 1;
+    // arena 1: the FSP as the host holds it, the table of its states, per-path counts and offsets
+    const size_t need1 = (size_t)n * lds * 4 + (size_t)n * lda * 12 + (size_t)n * 8 + (size_t)nr * ns * 4 + (size_t)slots * 4 +
+                         (size_t)(n + 1) * 12 + 16 * 256 + 4096;
+    SSA_TRY(ctx->d_os1.reserve(need1, false));
+    Arena a1{ctx->d_os1.p};
+    int32_t *d_state = a1.take<int32_t>((size_t)n * lds), *d_adj = a1.take<int32_t>((size_t)n * lda);
+    double *d_off = a1.take<double>((size_t)n * lda), *d_diag = a1.take<double>((size_t)n);
+    int32_t *d_nu = a1.take<int32_t>((size_t)nr * ns), *d_tab = a1.take<int32_t>(slots);
+    int32_t *d_cnt = a1.take<int32_t>((size_t)n + 1);
+    long long *d_recoff = a1.take<long long>((size_t)n + 1);
+    SSA_TRY(hipMemcpyAsync(d_state, state, (size_t)n * lds * 4, hipMemcpyHostToDevice, st));
+    SSA_TRY(hipMemcpyAsync(d_adj, adj, (size_t)n * lda * 4, hipMemcpyHostToDevice, st));
+    SSA_TRY(hipMemcpyAsync(d_off, offdiag, (size_t)n * lda * 8, hipMemcpyHostToDevice, st));
+    SSA_TRY(hipMemcpyAsync(d_diag, diag, (size_t)n * 8, hipMemcpyHostToDevice, st));
+    SSA_TRY(hipMemcpyAsync(d_nu, stoich, (size_t)nr * ns * 4, hipMemcpyHostToDevice, st));
+    SSA_TRY(hipMemsetAsync(d_tab, 0, (size_t)slots * 4, st));
+    SSA_TRY(hipMemsetAsync(d_cnt, 0, ((size_t)n + 1) * 4, st));
+    hipLaunchKernelGGL(k_ht_build, dim3(blocks(n)), dim3(kBlock), 0, st, n, ns, lds, d_state, d_tab, slots - 1);
+    SsaDev A;
+    A.ns = ns;
+    A.nr = nr;
+    A.n0 = n;
+    A.max_count = max_count;
+    A.lds = lds;
+    A.lda = lda;
+    A.tstep = tstep;
+    A.seedmix = (unsigned long long)seedmix;
+    A.state = d_state;
+    A.adj = d_adj;
+    A.off = d_off;
+    A.diag = d_diag;
+    A.nu = d_nu;
+    A.tab = d_tab;
+    A.tmask = slots - 1;
+    A.P = prop_dev(ctx);
+    hipLaunchKernelGGL((k_ssa_walk<false>), dim3(blocks(n)), dim3(kBlock), 0, st, A, d_cnt, (const long long *)nullptr, (int32_t *)nullptr);
+    size_t tmp_bytes = 0;
+    SSA_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_cnt, d_recoff, n + 1, st));
+    SSA_TRY(ctx->d_sorttmp.reserve(tmp_bytes + 256, false));
+    SSA_TRY(hipcub::DeviceScan::ExclusiveSum(ctx->d_sorttmp.p, tmp_bytes, d_cnt, d_recoff, n + 1, st));
+    long long nrec = 0;
+    SSA_TRY(hipMemcpyAsync(&nrec, d_recoff + n, sizeof(long long), hipMemcpyDeviceToHost, st));
+    SSA_TRY(hipStreamSynchronize(st));
+    *n_found = 0;
+    if (nrec == 0) return 0;
+    if (nrec > 2000000000LL) {
+        ctx->err = "SSA paths met more than 2e9 unlisted states";
+        return -11;
+    }
+    // arena 2: the records, the table of their distinct states, the survivors
+    unsigned slots2 = 64;
+    while (slots2 < 2u * (unsigned)nrec) slots2 <<= 1;
+    const size_t need2 = (size_t)nrec * ns * 4 + (size_t)slots2 * 8 + (size_t)nrec * 9 + 4096 + 8 * 256;
+    SSA_TRY(ctx->d_os2.reserve(need2, false));
+    Arena a2{ctx->d_os2.p};
+    int32_t *d_rec = a2.take<int32_t>((size_t)nrec * ns), *d_tab2 = a2.take<int32_t>(slots2), *d_min = a2.take<int32_t>(slots2);
+    int32_t *d_iota = a2.take<int32_t>((size_t)nrec), *d_sel = a2.take<int32_t>((size_t)nrec);
+    uint8_t *d_first = a2.take<uint8_t>((size_t)nrec);
+    int *d_nsel = a2.take<int>(4);
+    hipLaunchKernelGGL((k_ssa_walk<true>), dim3(blocks(n)), dim3(kBlock), 0, st, A, d_cnt, d_recoff, d_rec);
+    SSA_TRY(hipMemsetAsync(d_tab2, 0, (size_t)slots2 * 4, st));
+    SSA_TRY(hipMemsetAsync(d_min, 0x7f, (size_t)slots2 * 4, st));
+    SSA_TRY(hipMemsetAsync(d_first, 0, (size_t)nrec, st));
+    hipLaunchKernelGGL(k_rec_insert, dim3(blocks(nrec)), dim3(kBlock), 0, st, nrec, ns, d_rec, d_tab2, d_min, slots2 - 1);
+    hipLaunchKernelGGL(k_rec_first, dim3(blocks(slots2)), dim3(kBlock), 0, st, slots2, d_tab2, d_min, d_first);
+    hipLaunchKernelGGL(k_iota, dim3(blocks(nrec)), dim3(kBlock), 0, st, nrec, d_iota);
+    SSA_TRY(hipcub::DeviceSelect::Flagged(nullptr, tmp_bytes, d_iota, d_first, d_sel, d_nsel, (int)nrec, st));
+    SSA_TRY(ctx->d_sorttmp.reserve(tmp_bytes + 256, false));
+    SSA_TRY(hipcub::DeviceSelect::Flagged(ctx->d_sorttmp.p, tmp_bytes, d_iota, d_first, d_sel, d_nsel, (int)nrec, st));
+    int nnew = 0;
+    SSA_TRY(hipMemcpyAsync(&nnew, d_nsel, sizeof(int), hipMemcpyDeviceToHost, st));
+    SSA_TRY(hipStreamSynchronize(st));
+    if (nnew > cap_new) {
+        ctx->err = "FSP SIZE EXCEEDS MEMORY LIMIT";
+        return -11;
+    }
+    // the new states in (seed state, position on the path) order of their first occurrence, and their columns
+    const size_t sb = (size_t)nnew * lds * 4, ob = (size_t)nnew * ldo * 8;
+    SSA_TRY(ctx->d_os3.reserve(sb + ob + (size_t)nnew * 8 + 1024, false));
+    Arena a3{ctx->d_os3.p};
+    double *d_on = a3.take<double>((size_t)nnew * ldo), *d_dn = a3.take<double>((size_t)nnew);
+    int32_t *d_sn = a3.take<int32_t>((size_t)nnew * lds);
+    hipLaunchKernelGGL(k_rec_gather, dim3(blocks(nnew)), dim3(kBlock), 0, st, nnew, ns, lds, d_sel, d_rec, d_sn);
+    if (int rc = prop_eval_device(ctx, nnew, d_sn, lds, d_on, ldo, d_dn)) return rc;
+    SSA_TRY(hipMemcpyAsync(state_new, d_sn, sb, hipMemcpyDeviceToHost, st));
+    SSA_TRY(hipMemcpyAsync(off_new, d_on, ob, hipMemcpyDeviceToHost, st));
+    SSA_TRY(hipMemcpyAsync(diag_new, d_dn, (size_t)nnew * 8, hipMemcpyDeviceToHost, st));
+    SSA_TRY(hipStreamSynchronize(st));
+    *n_found = nnew;
+    return 0;
+}
+
+}  // namespace kfsp

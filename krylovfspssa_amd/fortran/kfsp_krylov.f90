@@ -60,7 +60,7 @@ MODULE KRYLOVSOLVER
   ! (4) uploads of the changed FSP
   DOUBLE PRECISION, SAVE, PRIVATE :: HOST_SEC(4) = 0.0D0
 
-  PRIVATE :: ENSURE_CONTEXT, UPLOAD_FSP, CHECK, CB_DROP, CB_EXPAND, CB_LOG, WALL, DEVICE_ONESTEP
+  PRIVATE :: ENSURE_CONTEXT, UPLOAD_FSP, CHECK, CB_DROP, CB_EXPAND, CB_LOG, WALL, DEVICE_ONESTEP, DEVICE_SSA
   PUBLIC :: KFSP_UPLOAD_PROGRAM, KFSP_DEVICE_PROPENSITIES
 
 CONTAINS
@@ -300,6 +300,28 @@ CONTAINS
     NNEW = NN
   END FUNCTION DEVICE_ONESTEP
 
+  ! STATESPACE's hook for the independent-stream SSA walk: kfsp_ssa_streams on this module's context
+  INTEGER FUNCTION DEVICE_SSA(TIMESTEP, SEEDMIX, NS, NR, STOICH, N, STATE, ADJ, OFFDIAG, DIAG, MAXCOUNT, CAPNEW, NFOUND)
+    DOUBLE PRECISION, INTENT(IN) :: TIMESTEP
+    INTEGER(8), INTENT(IN) :: SEEDMIX
+    INTEGER, INTENT(IN) :: NS, NR, N, MAXCOUNT, CAPNEW
+    INTEGER, INTENT(IN) :: STOICH(NS, NR)
+    INTEGER, INTENT(INOUT) :: STATE(NS, *)
+    INTEGER, INTENT(IN) :: ADJ(NR, *)
+    DOUBLE PRECISION, INTENT(INOUT) :: OFFDIAG(NR, *), DIAG(*)
+    INTEGER, INTENT(OUT) :: NFOUND
+    INTEGER(C_INT32_T) :: NF
+    NF = 0
+    NFOUND = 0
+    DEVICE_SSA = -1
+    IF (.NOT. PROGRAM_READY .OR. CAPNEW < 1) RETURN
+    DEVICE_SSA = KFSP_SSA_STREAMS(CTX, TIMESTEP, INT(SEEDMIX, C_INT64_T), INT(NS, C_INT32_T), INT(NR, C_INT32_T), STOICH, &
+         INT(N, C_INT32_T), STATE, INT(NS, C_INT32_T), ADJ, OFFDIAG, INT(NR, C_INT32_T), DIAG, INT(MAXCOUNT, C_INT32_T), &
+         INT(CAPNEW, C_INT32_T), NF, STATE(1:NS, N + 1:N + CAPNEW), OFFDIAG(1:NR, N + 1:N + CAPNEW), INT(NR, C_INT32_T), &
+         DIAG(N + 1:N + CAPNEW))
+    NFOUND = NF
+  END FUNCTION DEVICE_SSA
+
   ! The model's parsed propensities -> the device (kfsp_set_propensity_program).  Expressions of ONE species (every
   ! Hill function and x (x - 1) / 2 of the shipped models) travel as tables made HERE with MODEL%PROPENSITY at every
   ! population count 0..MAXNUMBERMOLECULES, so the device returns the host's own bits for them; the others as postfix
@@ -314,6 +336,7 @@ CONTAINS
     INTEGER :: K, V, TL
     INTEGER(C_INT) :: RC
     PROGRAM_READY = .FALSE.
+    NULLIFY(SSA_DEVICE)
     CALL ENSURE_CONTEXT()
     IF (.NOT. PROGRAM_WANTED) RETURN
     CALL MODEL%EXPORT_PROGRAM(OK, CODE_OFF, CODE, IMM_OFF, IMM, DEP)
@@ -346,6 +369,12 @@ CONTAINS
             0_C_INT32_T, PDUMMY, CODE_OFF, CODE, IMM_OFF, IMM, DEP, INT(TL, C_INT32_T), TAB)
     ENDIF
     PROGRAM_READY = RC == 0               ! (a program the device cannot take - stack too deep - stays on the host)
+    ! with the program on the device the independent-stream SSA paths (KFSP_SSA_STREAMS=1) can be walked there
+    IF (PROGRAM_READY) THEN
+       SSA_DEVICE => DEVICE_SSA
+    ELSE
+       NULLIFY(SSA_DEVICE)
+    ENDIF
   END SUBROUTINE KFSP_UPLOAD_PROGRAM
 
   ! OFFDIAG / DIAG columns of N states through the resident program (kfsp_propensities); .FALSE. without one

@@ -65,7 +65,7 @@ MODULE STATESPACE
      PROCEDURE :: INDEX => INDEX_STATE
   END TYPE FINITE_STATE_PROJECTION
 
-  PRIVATE :: ONESTEP_ON_DEVICE, SSA_STREAMS_REQUESTED, SSA_EXTENDER_STREAMS, STREAM_PATH, TICK, STATE_HASH, LOOKUP, PROBE, INSERT_RANGE, APPEND_CANDIDATES, CUSTOMPROP_IS_PURE, TABLE_INSERT, REBUILD_TABLE, LEGAL, RESERVE_TABLE, APPEND_STATE, &
+  PRIVATE :: ONESTEP_ON_DEVICE, SSA_STREAMS_ON_DEVICE, KFSP_PLOG, SSA_STREAMS_REQUESTED, SSA_EXTENDER_STREAMS, STREAM_PATH, TICK, STATE_HASH, LOOKUP, PROBE, INSERT_RANGE, APPEND_CANDIDATES, CUSTOMPROP_IS_PURE, TABLE_INSERT, REBUILD_TABLE, LEGAL, RESERVE_TABLE, APPEND_STATE, &
        LINK_ONE, LINK_NEW, HOST_THREADS
 
   INTEGER(8), PARAMETER, PRIVATE :: LOW32 = 4294967295_8
@@ -105,6 +105,25 @@ MODULE STATESPACE
      END FUNCTION ONESTEP_DEVICE_FN
   END INTERFACE
   PROCEDURE(ONESTEP_DEVICE_FN), POINTER, SAVE :: ONESTEP_DEVICE => NULL()
+  ! SSA_EXTENDER_STREAMS' walk on the device (kfsp_ssa_streams, include/kfsp.h): set by the solver module once the
+  ! model's propensity program is on the device; used for lists of at least SSA_DEVICE_MIN states (environment
+  ! KFSP_DEVICE_SSA_MIN, default 20000; KFSP_DEVICE_SSA=0 switches it off).  On return 0 the NFOUND distinct unlisted
+  ! states the paths met stand behind the list - STATE(:, N+1:N+NFOUND) in (seed state, position) order of first
+  ! occurrence - with their OFFDIAG / DIAG columns; any other value: the host walks.
+  ABSTRACT INTERFACE
+     INTEGER FUNCTION SSA_DEVICE_FN(TIMESTEP, SEEDMIX, NS, NR, STOICH, N, STATE, ADJ, OFFDIAG, DIAG, MAXCOUNT, CAPNEW, NFOUND)
+       DOUBLE PRECISION, INTENT(IN) :: TIMESTEP
+       INTEGER(8), INTENT(IN) :: SEEDMIX
+       INTEGER, INTENT(IN) :: NS, NR, N, MAXCOUNT, CAPNEW
+       INTEGER, INTENT(IN) :: STOICH(NS, NR)
+       INTEGER, INTENT(INOUT) :: STATE(NS, *)
+       INTEGER, INTENT(IN) :: ADJ(NR, *)
+       DOUBLE PRECISION, INTENT(INOUT) :: OFFDIAG(NR, *), DIAG(*)
+       INTEGER, INTENT(OUT) :: NFOUND
+     END FUNCTION SSA_DEVICE_FN
+  END INTERFACE
+  PROCEDURE(SSA_DEVICE_FN), POINTER, SAVE :: SSA_DEVICE => NULL()
+  INTEGER, SAVE, PRIVATE :: SSA_DEVICE_MIN = -1
   INTEGER, SAVE, PRIVATE :: ONESTEP_DEVICE_MIN = -1
   INTEGER, PRIVATE, SAVE :: NTHREADS_CACHED = 0, PARALLEL_MIN = -1, SSA_STREAMS_FLAG = -1
   INTEGER, PRIVATE, SAVE :: TOUCH_SINK = 0        ! keeps the early loads of SSA_EXTENDER alive
@@ -1244,7 +1263,7 @@ CONTAINS
           PR = FSP%MATRIX%OFFDIAG(1:PD, J)
        ENDIF
        IF (.NOT. (A0 > 0.0D0)) EXIT                 ! absorbing state
-       TT = MIN(TIMESTEP, TT + (-LOG(R1) / A0))
+       TT = MIN(TIMESTEP, TT + (-KFSP_PLOG(R1) / A0))
        ACC = PR(1)
        K = 1
        R2A = MIN(R2 * A0, A0)
@@ -1287,6 +1306,37 @@ CONTAINS
     ENDDO
   END SUBROUTINE STREAM_PATH
 
+  ! log of 0 < X <= 1 by a FIXED sequence of IEEE operations - the waiting times of the independent-stream paths are
+  ! defined through it rather than through the runtime's LOG, so that the device walk (plog of csrc/kfsp_ssa.hip, the
+  ! same sequence) and this one produce the same bits.  X = M 2^E with M in [sqrt(1/2), sqrt(2)), S = (M - 1) / (M + 1),
+  ! log M = 2 S (1 + S^2/3 + ... + S^22/23), log X = E ln2 + log M; about 1E-16 relative.
+  DOUBLE PRECISION FUNCTION KFSP_PLOG(X) RESULT(R)
+    DOUBLE PRECISION, INTENT(IN) :: X
+    DOUBLE PRECISION :: M, F, S, Z, P, TWO_S, DE, HI, LO
+    INTEGER :: E, K
+    E = EXPONENT(X)
+    M = FRACTION(X)                               ! X = M 2^E, M in [0.5, 1)
+    IF (M < 0.70710678118654752440D0) THEN
+       M = M + M
+       E = E - 1
+    ENDIF
+    F = M - 1.0D0
+    S = F / (2.0D0 + F)
+    Z = S * S
+    P = 1.0D0 / 23.0D0
+    DO K = 21, 3, -2
+       P = P * Z
+       P = P + 1.0D0 / DBLE(K)
+    ENDDO
+    P = P * Z
+    TWO_S = S + S
+    R = TWO_S + TWO_S * P
+    DE = DBLE(E)
+    HI = DE * 6.93147180369123816490D-01
+    LO = DE * 1.90821492927058770002D-10
+    R = HI + (LO + R)
+  END FUNCTION KFSP_PLOG
+
   ! KFSP_SSA_STREAMS=1: every path gets a random stream of its own (below)
   LOGICAL FUNCTION SSA_STREAMS_REQUESTED()
     CHARACTER(LEN=8) :: BUF
@@ -1300,6 +1350,51 @@ CONTAINS
     ENDIF
     SSA_STREAMS_REQUESTED = SSA_STREAMS_FLAG == 1
   END FUNCTION SSA_STREAMS_REQUESTED
+
+  ! The walk of SSA_EXTENDER_STREAMS on the device: .TRUE. = the distinct unlisted states the paths met were appended
+  ! (state, key, table entry, propensity columns; links are the caller's LINK_NEW), in the order the host's walk
+  ! and append would have produced.
+  LOGICAL FUNCTION SSA_STREAMS_ON_DEVICE(TIMESTEP, SEEDMIX, FSP, MODEL) RESULT(DONE)
+    DOUBLE PRECISION, INTENT(IN) :: TIMESTEP
+    INTEGER(8), INTENT(IN) :: SEEDMIX
+    TYPE(FINITE_STATE_PROJECTION) :: FSP
+    TYPE(CME_MODEL), INTENT(IN) :: MODEL
+    CHARACTER(LEN=16) :: ENV
+    INTEGER :: L, STAT, RC, N0, NF, SD, PD, I, NT
+    DONE = .FALSE.
+    IF (.NOT. ASSOCIATED(SSA_DEVICE)) RETURN
+    IF (SSA_DEVICE_MIN < 0) THEN
+       SSA_DEVICE_MIN = 20000
+       CALL GET_ENVIRONMENT_VARIABLE('KFSP_DEVICE_SSA_MIN', ENV, L, STAT)
+       IF (STAT == 0 .AND. L > 0) READ(ENV(1:L), *, IOSTAT=STAT) SSA_DEVICE_MIN
+       CALL GET_ENVIRONMENT_VARIABLE('KFSP_DEVICE_SSA', ENV, L, STAT)
+       IF (STAT == 0 .AND. L > 0) THEN
+          IF (ENV(1:1) == '0') SSA_DEVICE_MIN = HUGE(1)
+       ENDIF
+    ENDIF
+    N0 = FSP%SIZE
+    IF (N0 < SSA_DEVICE_MIN) RETURN
+    SD = MODEL%NSPECIES
+    PD = MODEL%NREACTIONS
+    IF (SIZE(FSP%STATE, 1) /= SD .OR. SIZE(FSP%MATRIX%ADJ, 1) /= PD) RETURN
+    RC = SSA_DEVICE(TIMESTEP, SEEDMIX, SD, PD, MODEL%STOICHIOMETRY(1:SD, 1:PD), N0, FSP%STATE, FSP%MATRIX%ADJ, &
+         FSP%MATRIX%OFFDIAG, FSP%MATRIX%DIAG, MAXNUMBERMOLECULES, FSP%MAX_SIZE - 1 - N0, NF)
+    IF (RC /= 0) RETURN                       ! (no program, too many states for the list, ...: the host walks)
+    DONE = .TRUE.
+    IF (NF == 0) RETURN
+    CALL RESERVE_TABLE(FSP, N0 + NF)
+    NT = HOST_THREADS(NF, 4096)
+    !$OMP PARALLEL DO NUM_THREADS(NT) SCHEDULE(STATIC) IF(NT > 1)
+    DO I = N0 + 1, N0 + NF
+       FSP%KEY(I) = STATE_HASH(FSP%STATE(1:SD, I))
+       FSP%VECTOR(I) = 0.0D0
+       FSP%MATRIX%ADJ(1:PD, I) = 0
+    ENDDO
+    !$OMP END PARALLEL DO
+    FSP%SIZE = N0 + NF
+    FSP%MATRIX%SIZE = N0 + NF
+    CALL INSERT_RANGE(FSP, N0 + 1, N0 + NF, .FALSE.)
+  END FUNCTION SSA_STREAMS_ON_DEVICE
 
   ! OPT-IN VARIANT, NOT the reference's sampling order (KFSP_SSA_STREAMS=1).
   ! The reference's paths share one random stream and each sees the states the
@@ -1333,6 +1428,12 @@ CONTAINS
     CALL TICK(0, TCLK)
     CALL RANDOM_NUMBER(BASE)
     SEEDMIX = INT(BASE * 2147483647.0D0, 8)
+    IF (SSA_STREAMS_ON_DEVICE(TIMESTEP, SEEDMIX, FSP, MODEL)) THEN
+       CALL TICK(4, TCLK)
+       IF (FSP%SIZE > N0) CALL LINK_NEW(FSP, MODEL, N0 + 1, FSP%SIZE, .TRUE.)
+       CALL TICK(5, TCLK)
+       RETURN
+    ENDIF
     NT = HOST_THREADS(N0, 1024)
     IF (ASSOCIATED(MODEL%CUSTOMPROP) .AND. .NOT. CUSTOMPROP_IS_PURE()) NT = 1
     ALLOCATE(CNT(0:NT), OFS(0:NT))

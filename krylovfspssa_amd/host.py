@@ -65,6 +65,7 @@ def load_library():
         "kfsp_onestep_columns": [vp, i32, i32, vp, i32, vp, i32, vp, i32, i32, i32, C.POINTER(i32), vp, vp, vp, i32, vp],
         "kfsp_set_propensity_program": [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp],
         "kfsp_propensities": [vp, i32, vp, i32, vp, i32, vp],
+        "kfsp_ssa_streams": [vp, dbl, i64, i32, i32, vp, i32, vp, i32, vp, vp, i32, vp, i32, i32, C.POINTER(i32), vp, vp, i32, vp],
         "kfsp_drop_plan": [vp, dbl, C.POINTER(dbl), C.POINTER(i64), C.POINTER(i64)],
         "kfsp_drop_flags": [vp, i64, vp],
         "kfsp_drop_compact": [vp, C.POINTER(i64)],

@@ -292,6 +292,29 @@ def test_cme_solve_with_independent_stream_ssa(dump, tmp_path, fixture, case):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fixture,case", [("toggle_input_T05", "toggle_input"), ("repressilator_input_T1", "repressilator_input"),
+                                          ("goutsias_input_T40", "goutsias_input"), ("toggle_input_T2", "toggle_input")])
+def test_device_ssa_walk_equals_the_host_walk(dump, tmp_path, fixture, case):
+    """Independent-stream SSA (KFSP_SSA_STREAMS=1) with the paths walked ON THE DEVICE (kfsp_ssa_streams; every
+    expansion, KFSP_DEVICE_SSA_MIN=1) against the same mode walked by the host's thread team: one Lehmer stream per
+    path, the waiting times through the fixed-sequence logarithm both sides share, propensities of unlisted states from
+    the model's program - the device must find the same states in the same order, so the two adaptive runs are
+    identical: step log, state list, links, propensity columns and the probabilities, bit for bit."""
+    base = {"KFSP_SSA_STREAMS": "1", "KFSP_HOST_THREADS": "4", "KFSP_HOST_PARALLEL_MIN": "1"}
+    g, dh, logh = _solve(dump, tmp_path, fixture, case, env=dict(base, KFSP_DEVICE_SSA="0"))
+    g, dd, logd = _solve(dump, tmp_path, fixture, case, env=dict(base, KFSP_DEVICE_SSA_MIN="1"))
+    assert int(logd["n_ssa"]) == int(logh["n_ssa"]) and int(logd["n_ssa"]) >= 1
+    assert np.array_equal(logd["step_n"], logh["step_n"]) and np.array_equal(logd["step_tau"], logh["step_tau"])
+    assert np.array_equal(logd["step_m"], logh["step_m"]) and np.array_equal(logd["wsum"], logh["wsum"])
+    for key in ("state", "adj", "offdiag", "diag", "vector"):
+        assert np.array_equal(dd[key], dh[key]), key
+    # and it is the consistent expansion the mode promises: the reference's solution within the FSP tolerance
+    ref = {tuple(s): v for s, v in zip(g["state"].tolist(), g["vector"].tolist())}
+    got = {tuple(s): v for s, v in zip(dd["state"].tolist(), dd["vector"].tolist())}
+    assert sum(abs(ref.get(k, 0.0) - got.get(k, 0.0)) for k in set(ref) | set(got)) < float(g["fsptol"])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("fixture,case", LONG)
 def test_cme_solve_adaptive_fsp(dump, tmp_path, fixture, case):
     """The reference's own end-to-end workloads (test/TestSolverFromFile.f90:35,
