@@ -308,10 +308,11 @@ def test_device_ssa_walk_equals_the_host_walk(dump, tmp_path, fixture, case):
     assert np.array_equal(logd["step_m"], logh["step_m"]) and np.array_equal(logd["wsum"], logh["wsum"])
     for key in ("state", "adj", "offdiag", "diag", "vector"):
         assert np.array_equal(dd[key], dh[key]), key
-    # and it is the consistent expansion the mode promises: the reference's solution within the FSP tolerance
+    # and it is the consistent expansion the mode promises: the reference's solution within the two runs' FSP budgets
     ref = {tuple(s): v for s, v in zip(g["state"].tolist(), g["vector"].tolist())}
     got = {tuple(s): v for s, v in zip(dd["state"].tolist(), dd["vector"].tolist())}
-    assert sum(abs(ref.get(k, 0.0) - got.get(k, 0.0)) for k in set(ref) | set(got)) < float(g["fsptol"])
+    assert sum(abs(ref.get(k, 0.0) - got.get(k, 0.0)) for k in set(ref) | set(got)) < 2.0 * float(g["fsptol"])
+    assert 1.0 - dd["vector"].sum() < float(g["fsptol"]) and np.all(dd["vector"] >= 0)
 
 
 @pytest.mark.gpu
