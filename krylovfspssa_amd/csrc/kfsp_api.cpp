@@ -1283,6 +1283,7 @@ int kfsp_set_state_coords(kfsp_ctx *ctx, int32_t n, int32_t ns, int32_t ld, cons
         if (!state) return fail(ctx, -5, "null state");
         if (ctx->group) return kfsp::group_set_state_coords(ctx, n, ns, ld, state);
         ctx->perm_pending_n = 0;
+        ctx->coords_n = 0;                                  // (set again below if the coordinates are uploaded)
         if (!ctx->opt_state_order || n < ctx->opt_state_order_min) return 0;
         // Sorting, relabelling and the extra upload cost about as much as 20 products (at 10^6 states)
         // save: worth it only while generators live that long.  The generator being
@@ -2117,6 +2118,7 @@ int kfsp_set_option(kfsp_ctx *ctx, const char *name, int64_t value)
     else if (k == "box_generic") ctx->opt_box_generic = value;
     else if (k == "box_store") ctx->opt_box_store = value;
     else if (k == "sell_code") ctx->opt_sell_code = value;
+    else if (k == "ssa_resident") ctx->opt_ssa_resident = value;
     else if (k == "small_lds") ctx->opt_small_lds = value;
     else if (k == "state_order") ctx->opt_state_order = value;
     else if (k == "state_order_min") ctx->opt_state_order_min = value;

@@ -799,6 +799,7 @@ void launch_gather_index(int64_t n, const int32_t *index, const double *src, dou
 int state_order_from_coords(kfsp_ctx *ctx, int32_t n, int32_t ns, int32_t ld, const int32_t *state, bool *ok)
 {
     *ok = false;
+    ctx->coords_n = 0;
     if (ns > 16) return 0;                                 // more species than the key layout holds
     hipStream_t st = ctx->stream;
     const size_t nent = (size_t)n * (size_t)ld;
@@ -816,6 +817,8 @@ int state_order_from_coords(kfsp_ctx *ctx, int32_t n, int32_t ns, int32_t ld, co
                        ctx->d_coords.p, dmm);
     HIP_TRY_B(hipMemcpyAsync(mm, dmm, sizeof(int) * 2 * (size_t)ns, hipMemcpyDeviceToHost, st));
     HIP_TRY_B(hipStreamSynchronize(st));
+    ctx->coords_n = n;                                     // (the coordinates stay resident: kfsp_ssa_streams may use them)
+    ctx->coords_ld = ld;
     KeyLayout L;
     L.ns = ns;
     int bits = 0;

@@ -276,6 +276,9 @@ struct kfsp_ctx {
     int64_t opt_dia_mask = 1;             // 0: never skip empty diagonal segments
     int64_t opt_box_generic = 0;          // 1: matrix-free boxes always take the run-time interpreted kernel
     int64_t opt_mmax = kfsp::kMMax;        // largest Krylov dimension the basis is allocated for (m_max + 3 columns)
+    int64_t opt_ssa_resident = 0;          // 1: the caller vouches that the arrays given to kfsp_ssa_streams are the ones last uploaded
+    int64_t coords_n = 0;                  // states whose coordinates sit in d_coords (kfsp_set_state_coords), 0: none
+    int32_t coords_ld = 0;
     int64_t opt_sell_code = -1;            // dictionary-coded SELL columns: -1 auto (under the internal state order), 0 never, 1 always try
     int64_t opt_box_store = 0;            // 1: kfsp_set_matrix_box writes the generator out as stored diagonals on the device (banded form)
     int64_t opt_state_order = 1;          // 1: use kfsp_set_state_coords for large, long-lived generators (0: never)

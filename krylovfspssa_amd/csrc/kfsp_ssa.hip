@@ -284,10 +284,21 @@ int ssa_streams_device(kfsp_ctx *ctx, double tstep, int64_t seedmix, int32_t ns,
     int32_t *d_nu = a1.take<int32_t>((size_t)nr * ns), *d_tab = a1.take<int32_t>(slots);
     int32_t *d_cnt = a1.take<int32_t>((size_t)n + 1);
     long long *d_recoff = a1.take<long long>((size_t)n + 1);
-    SSA_TRY(hipMemcpyAsync(d_state, state, (size_t)n * lds * 4, hipMemcpyHostToDevice, st));
-    SSA_TRY(hipMemcpyAsync(d_adj, adj, (size_t)n * lda * 4, hipMemcpyHostToDevice, st));
-    SSA_TRY(hipMemcpyAsync(d_off, offdiag, (size_t)n * lda * 8, hipMemcpyHostToDevice, st));
-    SSA_TRY(hipMemcpyAsync(d_diag, diag, (size_t)n * 8, hipMemcpyHostToDevice, st));
+    // Option ssa_resident: the caller vouches that these arrays are what it uploaded last (kfsp_update_matrix_ell keeps the
+    // reference arrays verbatim, kfsp_set_state_coords the coordinates) - 152 MB per call stay where they are at 1e6 states.
+    const bool res_gen = ctx->opt_ssa_resident != 0 && ctx->ell_cols == n && ctx->ell_ld == lda;
+    const bool res_st = ctx->opt_ssa_resident != 0 && ctx->coords_n == n && ctx->coords_ld == lds;
+    if (res_st) d_state = ctx->d_coords.p;
+    else SSA_TRY(hipMemcpyAsync(d_state, state, (size_t)n * lds * 4, hipMemcpyHostToDevice, st));
+    if (res_gen) {
+        d_adj = ctx->d_ell_adj.p;
+        d_off = ctx->d_ell_off.p;
+        d_diag = ctx->d_ell_diag.p;
+    } else {
+        SSA_TRY(hipMemcpyAsync(d_adj, adj, (size_t)n * lda * 4, hipMemcpyHostToDevice, st));
+        SSA_TRY(hipMemcpyAsync(d_off, offdiag, (size_t)n * lda * 8, hipMemcpyHostToDevice, st));
+        SSA_TRY(hipMemcpyAsync(d_diag, diag, (size_t)n * 8, hipMemcpyHostToDevice, st));
+    }
     SSA_TRY(hipMemcpyAsync(d_nu, stoich, (size_t)nr * ns * 4, hipMemcpyHostToDevice, st));
     SSA_TRY(hipMemsetAsync(d_tab, 0, (size_t)slots * 4, st));
     SSA_TRY(hipMemsetAsync(d_cnt, 0, ((size_t)n + 1) * 4, st));

@@ -494,7 +494,10 @@ CONTAINS
     N_BEFORE = CUR_FSP%SIZE
     TS = T_SSA
     T0 = WALL()
+    ! (the FSP on the device IS the one the walk starts from: its arrays need not travel again)
+    RC = KFSP_SET_OPTION(CTX, 'ssa_resident' // C_NULL_CHAR, 1_C_INT64_T)
     CALL SSA_EXTENDER(TS, CUR_FSP, CUR_MODEL)
+    RC = KFSP_SET_OPTION(CTX, 'ssa_resident' // C_NULL_CHAR, 0_C_INT64_T)
     T1 = WALL()
     CALL ONESTEP_EXTENDER(CUR_FSP, CUR_MODEL)
     T2 = WALL()
