@@ -123,77 +123,113 @@ __device__ __forceinline__ double lcg_uniform(unsigned long long &rs)
     return (double)(((g1 << 30) | ((g2 - 1ull) & kLcgLow)) >> 7) * 0x1p-54;
 }
 
-// One path (STREAM_PATH of the host).  WRITE = false: count its records; true: write them at rec[recoff[j0]..].
+// The paths (STREAM_PATH of the host), one lane per path.  WRITE = false: count each path's records; true: write
+// them at rec[recoff[j0]..].  Paths differ wildly in length (a handful of jumps on average, hundreds for a few), so a
+// wavefront does not take 64 fixed seeds: it owns `spw` consecutive seed states and a lane that finishes its path takes
+// the next one of them (a wave-uniform register counter handed out by ballot / prefix count: no atomics), so all
+// lanes stay busy until the wave's seeds run out.
+constexpr int kSsaSeedsPerWave = 1024;
+
 template <bool WRITE>
 __global__ __launch_bounds__(kBlock) void k_ssa_walk(SsaDev A, int32_t *__restrict__ cnt, const long long *__restrict__ recoff,
                                                      int32_t *__restrict__ rec)
 {
-    const int j0 = blockIdx.x * kBlock + threadIdx.x + 1;          // 1-based seed state, as on the host
-    if (j0 > A.n0) return;
-    // the path's own stream: a 64-bit mix of (call, seed state) folded into the generator's range
-    unsigned long long rs = (A.seedmix * 2654435761ull) ^ ((unsigned long long)j0 * 40503ull + 12345ull);
-    rs = ((rs ^ (rs >> 29)) & 4294967295ull) * 1181783497ull;
-    rs = 1ull + (((rs ^ (rs >> 32)) & 9223372036854775807ull) % (kLcgM - 1ull));
-    int j = j0;
+    const int lane = threadIdx.x & 63;
+    const long long wave = ((long long)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const long long lo = wave * kSsaSeedsPerWave + 1;              // 1-based seed states of this wave, inclusive
+    if (lo > A.n0) return;
+    const int hi = (int)min((long long)A.n0, lo + kSsaSeedsPerWave - 1);
+    int next = (int)lo;                                            // wave-uniform: the next seed to hand out
+    bool active = false;
+    int j0 = 0, j = 0, nrec = 0;
     bool virt = false;
-    int32_t x[kSsaMaxS], y[kSsaMaxS];
-    for (int s = 0; s < A.ns; ++s) x[s] = A.state[(int64_t)(j - 1) * A.lds + s];
+    unsigned long long rs = 0;
     double tt = 0.0;
-    int nrec = 0;
-    long long base = WRITE ? recoff[j0 - 1] : 0;
+    long long base = 0;
+    int32_t x[kSsaMaxS], y[kSsaMaxS];
     double pr[kSsaMaxR];
     for (;;) {
-        double r1 = lcg_uniform(rs);
-        const double r2 = lcg_uniform(rs);
-        if (r1 <= 0.0) r1 = 0x1p-54;
-        double a0;
-        if (virt) {
-            a0 = 0.0;
-            for (int k = 0; k < A.nr; ++k) {
-                pr[k] = prop_eval(A.P, k, x);
-                a0 = a0 + pr[k];
+        const unsigned long long idle = __ballot(!active);
+        if (idle) {
+            if (!active) {
+                j0 = next + __popcll(idle & ((1ull << lane) - 1ull));
+                if (j0 <= hi) {
+                    // the path's own stream: a 64-bit mix of (call, seed state) folded into the generator's range
+                    rs = (A.seedmix * 2654435761ull) ^ ((unsigned long long)j0 * 40503ull + 12345ull);
+                    rs = ((rs ^ (rs >> 29)) & 4294967295ull) * 1181783497ull;
+                    rs = 1ull + (((rs ^ (rs >> 32)) & 9223372036854775807ull) % (kLcgM - 1ull));
+                    j = j0;
+                    virt = false;
+                    for (int s = 0; s < A.ns; ++s) x[s] = A.state[(int64_t)(j - 1) * A.lds + s];
+                    tt = 0.0;
+                    nrec = 0;
+                    base = WRITE ? recoff[j0 - 1] : 0;
+                    active = true;
+                }
             }
-        } else {
-            a0 = A.diag[j - 1];
-            for (int k = 0; k < A.nr; ++k) pr[k] = A.off[(int64_t)(j - 1) * A.lda + k];
+            next += __popcll(idle);
         }
-        if (!(a0 > 0.0)) break;                                    // absorbing state
-        tt = fmin(A.tstep, tt + (-plog(r1) / a0));
-        double acc = pr[0];
-        int k = 0;
-        const double r2a = fmin(r2 * a0, a0);
-        while (acc < r2a && k < A.nr - 1) {
-            ++k;
-            acc = acc + pr[k];
+        if (!__ballot(active)) break;                              // no path left in this wave
+        // ---- one jump of this lane's path (lanes without one wait at the end of this block: the ballots above are
+        // always executed by the whole wavefront)
+        bool ended = active;
+        if (active) do {
+            double r1 = lcg_uniform(rs);
+            const double r2 = lcg_uniform(rs);
+            if (r1 <= 0.0) r1 = 0x1p-54;
+            double a0;
+            if (virt) {
+                a0 = 0.0;
+                for (int k = 0; k < A.nr; ++k) {
+                    pr[k] = prop_eval(A.P, k, x);
+                    a0 = a0 + pr[k];
+                }
+            } else {
+                a0 = A.diag[j - 1];
+                for (int k = 0; k < A.nr; ++k) pr[k] = A.off[(int64_t)(j - 1) * A.lda + k];
+            }
+            if (!(a0 > 0.0)) break;                                // absorbing state
+            tt = fmin(A.tstep, tt + (-plog(r1) / a0));
+            double acc = pr[0];
+            int k = 0;
+            const double r2a = fmin(r2 * a0, a0);
+            while (acc < r2a && k < A.nr - 1) {
+                ++k;
+                acc = acc + pr[k];
+            }
+            bool neg = false;
+            for (int s = 0; s < A.ns; ++s) {
+                y[s] = x[s] + A.nu[k * A.ns + s];
+                neg = neg || y[s] < 0;
+            }
+            if (neg) break;
+            int idx = 0;
+            if (!virt) idx = max(A.adj[(int64_t)(j - 1) * A.lda + k], 0);
+            if (idx == 0) {
+                bool legal = true;
+                for (int s = 0; s < A.ns; ++s) legal = legal && y[s] <= A.max_count;
+                if (!legal) break;
+                idx = lookup_state(A, y);
+            }
+            for (int s = 0; s < A.ns; ++s) x[s] = y[s];
+            if (idx > 0) {
+                j = idx;
+                virt = false;
+                if (j < j0) break;                                 // fell back onto an earlier seed
+            } else {
+                virt = true;
+                if (WRITE)
+                    for (int s = 0; s < A.ns; ++s) rec[(base + nrec) * A.ns + s] = y[s];
+                ++nrec;
+            }
+            if (!(tt < A.tstep)) break;
+            ended = false;
+        } while (false);
+        if (active && ended) {
+            if (!WRITE) cnt[j0 - 1] = nrec;
+            active = false;
         }
-        bool neg = false;
-        for (int s = 0; s < A.ns; ++s) {
-            y[s] = x[s] + A.nu[k * A.ns + s];
-            neg = neg || y[s] < 0;
-        }
-        if (neg) break;
-        int idx = 0;
-        if (!virt) idx = max(A.adj[(int64_t)(j - 1) * A.lda + k], 0);
-        if (idx == 0) {
-            bool legal = true;
-            for (int s = 0; s < A.ns; ++s) legal = legal && y[s] <= A.max_count;
-            if (!legal) break;
-            idx = lookup_state(A, y);
-        }
-        for (int s = 0; s < A.ns; ++s) x[s] = y[s];
-        if (idx > 0) {
-            j = idx;
-            virt = false;
-            if (j < j0) break;                                     // fell back onto an earlier seed
-        } else {
-            virt = true;
-            if (WRITE)
-                for (int s = 0; s < A.ns; ++s) rec[(base + nrec) * A.ns + s] = y[s];
-            ++nrec;
-        }
-        if (!(tt < A.tstep)) break;
     }
-    if (!WRITE) cnt[j0 - 1] = nrec;
 }
 
 // duplicates among the records: one table slot per distinct state, minidx[slot] = its first record
@@ -320,7 +356,9 @@ int ssa_streams_device(kfsp_ctx *ctx, double tstep, int64_t seedmix, int32_t ns,
     A.tab = d_tab;
     A.tmask = slots - 1;
     A.P = prop_dev(ctx);
-    hipLaunchKernelGGL((k_ssa_walk<false>), dim3(blocks(n)), dim3(kBlock), 0, st, A, d_cnt, (const long long *)nullptr, (int32_t *)nullptr);
+    // one wavefront per kSsaSeedsPerWave seed states (4 wavefronts per workgroup)
+    const int wgrid = (int)(((long long)n + 4 * kSsaSeedsPerWave - 1) / (4 * kSsaSeedsPerWave));
+    hipLaunchKernelGGL((k_ssa_walk<false>), dim3(wgrid), dim3(kBlock), 0, st, A, d_cnt, (const long long *)nullptr, (int32_t *)nullptr);
     size_t tmp_bytes = 0;
     SSA_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_cnt, d_recoff, n + 1, st));
     SSA_TRY(ctx->d_sorttmp.reserve(tmp_bytes + 256, false));
@@ -344,7 +382,7 @@ int ssa_streams_device(kfsp_ctx *ctx, double tstep, int64_t seedmix, int32_t ns,
     int32_t *d_iota = a2.take<int32_t>((size_t)nrec), *d_sel = a2.take<int32_t>((size_t)nrec);
     uint8_t *d_first = a2.take<uint8_t>((size_t)nrec);
     int *d_nsel = a2.take<int>(4);
-    hipLaunchKernelGGL((k_ssa_walk<true>), dim3(blocks(n)), dim3(kBlock), 0, st, A, d_cnt, d_recoff, d_rec);
+    hipLaunchKernelGGL((k_ssa_walk<true>), dim3(wgrid), dim3(kBlock), 0, st, A, d_cnt, d_recoff, d_rec);
     SSA_TRY(hipMemsetAsync(d_tab2, 0, (size_t)slots2 * 4, st));
     SSA_TRY(hipMemsetAsync(d_min, 0x7f, (size_t)slots2 * 4, st));
     SSA_TRY(hipMemsetAsync(d_first, 0, (size_t)nrec, st));
