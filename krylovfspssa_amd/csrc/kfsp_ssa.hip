@@ -123,16 +123,20 @@ __device__ __forceinline__ double lcg_uniform(unsigned long long &rs)
     return (double)(((g1 << 30) | ((g2 - 1ull) & kLcgLow)) >> 7) * 0x1p-54;
 }
 
-// The paths (STREAM_PATH of the host), one lane per path.  WRITE = false: count each path's records; true: write
-// them at rec[recoff[j0]..].  Paths differ wildly in length (a handful of jumps on average, hundreds for a few), so a
-// wavefront does not take 64 fixed seeds: it owns `spw` consecutive seed states and a lane that finishes its path takes
-// the next one of them (a wave-uniform register counter handed out by ballot / prefix count: no atomics), so all
-// lanes stay busy until the wave's seeds run out.
-constexpr int kSsaSeedsPerWave = 1024;
+// The paths (STREAM_PATH of the host), one lane per path, ONE pass.  Paths differ wildly in length (a handful of jumps
+// for most - they fall back onto an earlier seed -, thousands for a few), and a path is a chain of dependent memory
+// round trips, so the kernel lasts as long as its longest path: everything a jump needs from the current state (DIAG,
+// the OFFDIAG column, the ADJ column) is requested together, one round trip per jump.  A wavefront owns kSsaSeedsPerWave
+// consecutive seed states and a lane that finishes its path takes the next of them (a wave-uniform register counter
+// handed out by ballot / prefix count), so the whole wavefront reconverges once per jump - which is where the unlisted
+// states met are appended to the record list: one atomic add per wavefront and jump, key = (seed state, position on
+// the path).  Sorting the records by that key afterwards makes their order independent of how the hardware
+// scheduled the paths.
+constexpr int kSsaSeedsPerWave = 256;
+constexpr int kSsaPosBits = 22;
 
-template <bool WRITE>
-__global__ __launch_bounds__(kBlock) void k_ssa_walk(SsaDev A, int32_t *__restrict__ cnt, const long long *__restrict__ recoff,
-                                                     int32_t *__restrict__ rec)
+__global__ __launch_bounds__(kBlock) void k_ssa_walk(SsaDev A, unsigned long long *__restrict__ nrec_total, long long cap,
+                                                     unsigned long long *__restrict__ keys, int32_t *__restrict__ rec)
 {
     const int lane = threadIdx.x & 63;
     const long long wave = ((long long)blockIdx.x * kBlock + threadIdx.x) >> 6;
@@ -141,13 +145,13 @@ __global__ __launch_bounds__(kBlock) void k_ssa_walk(SsaDev A, int32_t *__restri
     const int hi = (int)min((long long)A.n0, lo + kSsaSeedsPerWave - 1);
     int next = (int)lo;                                            // wave-uniform: the next seed to hand out
     bool active = false;
-    int j0 = 0, j = 0, nrec = 0;
+    int j0 = 0, j = 0, npos = 0;
     bool virt = false;
     unsigned long long rs = 0;
     double tt = 0.0;
-    long long base = 0;
     int32_t x[kSsaMaxS], y[kSsaMaxS];
     double pr[kSsaMaxR];
+    int32_t aj[kSsaMaxR];
     for (;;) {
         const unsigned long long idle = __ballot(!active);
         if (idle) {
@@ -162,17 +166,16 @@ __global__ __launch_bounds__(kBlock) void k_ssa_walk(SsaDev A, int32_t *__restri
                     virt = false;
                     for (int s = 0; s < A.ns; ++s) x[s] = A.state[(int64_t)(j - 1) * A.lds + s];
                     tt = 0.0;
-                    nrec = 0;
-                    base = WRITE ? recoff[j0 - 1] : 0;
+                    npos = 0;
                     active = true;
                 }
             }
             next += __popcll(idle);
         }
         if (!__ballot(active)) break;                              // no path left in this wave
-        // ---- one jump of this lane's path (lanes without one wait at the end of this block: the ballots above are
-        // always executed by the whole wavefront)
-        bool ended = active;
+        // ---- one jump of this lane's path (lanes without one wait at the end of this block: the ballots are always
+        // executed by the whole wavefront)
+        bool ended = active, record = false;
         if (active) do {
             double r1 = lcg_uniform(rs);
             const double r2 = lcg_uniform(rs);
@@ -183,10 +186,15 @@ __global__ __launch_bounds__(kBlock) void k_ssa_walk(SsaDev A, int32_t *__restri
                 for (int k = 0; k < A.nr; ++k) {
                     pr[k] = prop_eval(A.P, k, x);
                     a0 = a0 + pr[k];
+                    aj[k] = 0;
                 }
             } else {
+                const int64_t row = (int64_t)(j - 1) * A.lda;
                 a0 = A.diag[j - 1];
-                for (int k = 0; k < A.nr; ++k) pr[k] = A.off[(int64_t)(j - 1) * A.lda + k];
+                for (int k = 0; k < A.nr; ++k) {
+                    pr[k] = A.off[row + k];
+                    aj[k] = A.adj[row + k];
+                }
             }
             if (!(a0 > 0.0)) break;                                // absorbing state
             tt = fmin(A.tstep, tt + (-plog(r1) / a0));
@@ -203,8 +211,7 @@ __global__ __launch_bounds__(kBlock) void k_ssa_walk(SsaDev A, int32_t *__restri
                 neg = neg || y[s] < 0;
             }
             if (neg) break;
-            int idx = 0;
-            if (!virt) idx = max(A.adj[(int64_t)(j - 1) * A.lda + k], 0);
+            int idx = max(aj[k], 0);
             if (idx == 0) {
                 bool legal = true;
                 for (int s = 0; s < A.ns; ++s) legal = legal && y[s] <= A.max_count;
@@ -218,59 +225,73 @@ __global__ __launch_bounds__(kBlock) void k_ssa_walk(SsaDev A, int32_t *__restri
                 if (j < j0) break;                                 // fell back onto an earlier seed
             } else {
                 virt = true;
-                if (WRITE)
-                    for (int s = 0; s < A.ns; ++s) rec[(base + nrec) * A.ns + s] = y[s];
-                ++nrec;
+                record = true;                                     // x is an unlisted state: recorded below
             }
             if (!(tt < A.tstep)) break;
             ended = false;
         } while (false);
-        if (active && ended) {
-            if (!WRITE) cnt[j0 - 1] = nrec;
-            active = false;
+        const unsigned long long rmask = __ballot(record);
+        if (rmask) {
+            unsigned long long first = 0;
+            const int leader = __ffsll((long long)rmask) - 1;
+            if (lane == leader) first = atomicAdd(nrec_total, (unsigned long long)__popcll(rmask));
+            first = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(first >> 32), leader) << 32) |
+                    (unsigned)__builtin_amdgcn_readlane((int)first, leader);
+            if (record) {
+                const unsigned long long slot = first + (unsigned long long)__popcll(rmask & ((1ull << lane) - 1ull));
+                if ((long long)slot < cap) {
+                    keys[slot] = ((unsigned long long)(unsigned)j0 << kSsaPosBits) | (unsigned long long)min(npos, (1 << kSsaPosBits) - 1);
+                    for (int s = 0; s < A.ns; ++s) rec[slot * A.ns + s] = x[s];
+                }
+                ++npos;
+            }
         }
+        if (active && ended) active = false;
     }
 }
 
-// duplicates among the records: one table slot per distinct state, minidx[slot] = its first record
-__global__ __launch_bounds__(kBlock) void k_rec_insert(long long nrec, int ns, const int32_t *__restrict__ rec, int32_t *tab2,
-                                                       int32_t *minidx, unsigned mask)
+// duplicates among the records, visited in the order of their keys (perm[r] = the record of rank r): one table slot
+// per distinct state, minrank[slot] = the rank of its first record
+__global__ __launch_bounds__(kBlock) void k_rec_insert(long long nrec, int ns, const int32_t *__restrict__ rec, const int32_t *__restrict__ perm,
+                                                       int32_t *tab2, int32_t *minrank, unsigned mask)
 {
-    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= nrec) return;
-    const int32_t *y = rec + i * ns;
+    const long long r = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= nrec) return;
+    const int32_t *y = rec + (long long)perm[r] * ns;
     unsigned slot = hash_state(y, ns) & mask;
     for (;;) {
         int cur = tab2[slot];
-        if (cur == 0) cur = atomicCAS(&tab2[slot], 0, (int)i + 1);
+        if (cur == 0) cur = atomicCAS(&tab2[slot], 0, (int)r + 1);
         if (cur == 0) {                                            // claimed: this record names the slot
-            atomicMin(&minidx[slot], (int)i);
+            atomicMin(&minrank[slot], (int)r);
             return;
         }
-        const int32_t *z = rec + (long long)(cur - 1) * ns;
+        const int32_t *z = rec + (long long)perm[cur - 1] * ns;
         bool same = true;
         for (int s = 0; s < ns; ++s) same = same && z[s] == y[s];
         if (same) {
-            atomicMin(&minidx[slot], (int)i);
+            atomicMin(&minrank[slot], (int)r);
             return;
         }
         slot = (slot + 1) & mask;
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_rec_first(unsigned slots, const int32_t *__restrict__ tab2, const int32_t *__restrict__ minidx,
+__global__ __launch_bounds__(kBlock) void k_rec_first(unsigned slots, const int32_t *__restrict__ tab2, const int32_t *__restrict__ minrank,
                                                       uint8_t *__restrict__ first)
 {
     const unsigned s = blockIdx.x * kBlock + threadIdx.x;
-    if (s < slots && tab2[s] != 0) first[minidx[s]] = 1;
+    if (s < slots && tab2[s] != 0) first[minrank[s]] = 1;
 }
 
-__global__ __launch_bounds__(kBlock) void k_rec_gather(int nnew, int ns, int lds, const int32_t *__restrict__ sel, const int32_t *__restrict__ rec,
-                                                       int32_t *__restrict__ out)
+// out[i] = coordinates of the record whose rank is sel[i]
+__global__ __launch_bounds__(kBlock) void k_rec_gather(int nnew, int ns, int lds, const int32_t *__restrict__ sel, const int32_t *__restrict__ perm,
+                                                       const int32_t *__restrict__ rec, int32_t *__restrict__ out)
 {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= nnew) return;
-    for (int s = 0; s < lds; ++s) out[(int64_t)i * lds + s] = s < ns ? rec[(int64_t)sel[i] * ns + s] : 0;
+    const int32_t *y = rec + (int64_t)perm[sel[i]] * ns;
+    for (int s = 0; s < lds; ++s) out[(int64_t)i * lds + s] = s < ns ? y[s] : 0;
 }
 
 __global__ __launch_bounds__(kBlock) void k_iota(long long n, int32_t *v)
@@ -356,39 +377,54 @@ int ssa_streams_device(kfsp_ctx *ctx, double tstep, int64_t seedmix, int32_t ns,
     A.tab = d_tab;
     A.tmask = slots - 1;
     A.P = prop_dev(ctx);
-    // one wavefront per kSsaSeedsPerWave seed states (4 wavefronts per workgroup)
+    // one wavefront per kSsaSeedsPerWave seed states (4 wavefronts per workgroup); the record list is sized by a guess
+    // and, should the paths meet more unlisted states than that, by the count the first attempt returns
     const int wgrid = (int)(((long long)n + 4 * kSsaSeedsPerWave - 1) / (4 * kSsaSeedsPerWave));
-    hipLaunchKernelGGL((k_ssa_walk<false>), dim3(wgrid), dim3(kBlock), 0, st, A, d_cnt, (const long long *)nullptr, (int32_t *)nullptr);
-    size_t tmp_bytes = 0;
-    SSA_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_cnt, d_recoff, n + 1, st));
-    SSA_TRY(ctx->d_sorttmp.reserve(tmp_bytes + 256, false));
-    SSA_TRY(hipcub::DeviceScan::ExclusiveSum(ctx->d_sorttmp.p, tmp_bytes, d_cnt, d_recoff, n + 1, st));
-    long long nrec = 0;
-    SSA_TRY(hipMemcpyAsync(&nrec, d_recoff + n, sizeof(long long), hipMemcpyDeviceToHost, st));
-    SSA_TRY(hipStreamSynchronize(st));
+    unsigned long long *d_total = reinterpret_cast<unsigned long long *>(d_recoff);
+    long long cap = std::max<long long>((long long)1 << 18, (long long)n / 2), nrec = 0;
+    unsigned long long *d_keys = nullptr;
+    int32_t *d_rec = nullptr;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        SSA_TRY(ctx->d_os2.reserve((size_t)cap * 8 + (size_t)cap * ns * 4 + 1024, false));
+        Arena a2{ctx->d_os2.p};
+        d_keys = a2.take<unsigned long long>((size_t)cap);
+        d_rec = a2.take<int32_t>((size_t)cap * ns);
+        SSA_TRY(hipMemsetAsync(d_total, 0, sizeof(unsigned long long), st));
+        hipLaunchKernelGGL(k_ssa_walk, dim3(wgrid), dim3(kBlock), 0, st, A, d_total, cap, d_keys, d_rec);
+        unsigned long long got = 0;
+        SSA_TRY(hipMemcpyAsync(&got, d_total, sizeof(got), hipMemcpyDeviceToHost, st));
+        SSA_TRY(hipStreamSynchronize(st));
+        nrec = (long long)got;
+        if (nrec <= cap) break;
+        if (attempt == 1 || nrec > 2000000000LL) {
+            ctx->err = "SSA paths met more unlisted states than the record list holds";
+            return -11;
+        }
+        cap = nrec + 1024;
+    }
     *n_found = 0;
     if (nrec == 0) return 0;
-    if (nrec > 2000000000LL) {
-        ctx->err = "SSA paths met more than 2e9 unlisted states";
-        return -11;
-    }
-    // arena 2: the records, the table of their distinct states, the survivors
+    // the records in (seed state, position) order, duplicates removed (first occurrence stays)
     unsigned slots2 = 64;
     while (slots2 < 2u * (unsigned)nrec) slots2 <<= 1;
-    const size_t need2 = (size_t)nrec * ns * 4 + (size_t)slots2 * 8 + (size_t)nrec * 9 + 4096 + 8 * 256;
-    SSA_TRY(ctx->d_os2.reserve(need2, false));
-    Arena a2{ctx->d_os2.p};
-    int32_t *d_rec = a2.take<int32_t>((size_t)nrec * ns), *d_tab2 = a2.take<int32_t>(slots2), *d_min = a2.take<int32_t>(slots2);
-    int32_t *d_iota = a2.take<int32_t>((size_t)nrec), *d_sel = a2.take<int32_t>((size_t)nrec);
-    uint8_t *d_first = a2.take<uint8_t>((size_t)nrec);
-    int *d_nsel = a2.take<int>(4);
-    hipLaunchKernelGGL((k_ssa_walk<true>), dim3(wgrid), dim3(kBlock), 0, st, A, d_cnt, d_recoff, d_rec);
+    const size_t need3 = (size_t)nrec * (8 + 4 + 4 + 4 + 1) + (size_t)slots2 * 8 + 4096 + 10 * 256;
+    SSA_TRY(ctx->d_os3.reserve(need3, false));
+    Arena a3x{ctx->d_os3.p};
+    unsigned long long *d_keys2 = a3x.take<unsigned long long>((size_t)nrec);
+    int32_t *d_iota = a3x.take<int32_t>((size_t)nrec), *d_perm = a3x.take<int32_t>((size_t)nrec), *d_sel = a3x.take<int32_t>((size_t)nrec);
+    int32_t *d_tab2 = a3x.take<int32_t>(slots2), *d_min = a3x.take<int32_t>(slots2);
+    uint8_t *d_first = a3x.take<uint8_t>((size_t)nrec);
+    int *d_nsel = a3x.take<int>(4);
+    hipLaunchKernelGGL(k_iota, dim3(blocks(nrec)), dim3(kBlock), 0, st, nrec, d_iota);
+    size_t tmp_bytes = 0;
+    SSA_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_keys, d_keys2, d_iota, d_perm, (int)nrec, 0, 31 + kSsaPosBits, st));
+    SSA_TRY(ctx->d_sorttmp.reserve(tmp_bytes + 256, false));
+    SSA_TRY(hipcub::DeviceRadixSort::SortPairs(ctx->d_sorttmp.p, tmp_bytes, d_keys, d_keys2, d_iota, d_perm, (int)nrec, 0, 31 + kSsaPosBits, st));
     SSA_TRY(hipMemsetAsync(d_tab2, 0, (size_t)slots2 * 4, st));
     SSA_TRY(hipMemsetAsync(d_min, 0x7f, (size_t)slots2 * 4, st));
     SSA_TRY(hipMemsetAsync(d_first, 0, (size_t)nrec, st));
-    hipLaunchKernelGGL(k_rec_insert, dim3(blocks(nrec)), dim3(kBlock), 0, st, nrec, ns, d_rec, d_tab2, d_min, slots2 - 1);
+    hipLaunchKernelGGL(k_rec_insert, dim3(blocks(nrec)), dim3(kBlock), 0, st, nrec, ns, d_rec, d_perm, d_tab2, d_min, slots2 - 1);
     hipLaunchKernelGGL(k_rec_first, dim3(blocks(slots2)), dim3(kBlock), 0, st, slots2, d_tab2, d_min, d_first);
-    hipLaunchKernelGGL(k_iota, dim3(blocks(nrec)), dim3(kBlock), 0, st, nrec, d_iota);
     SSA_TRY(hipcub::DeviceSelect::Flagged(nullptr, tmp_bytes, d_iota, d_first, d_sel, d_nsel, (int)nrec, st));
     SSA_TRY(ctx->d_sorttmp.reserve(tmp_bytes + 256, false));
     SSA_TRY(hipcub::DeviceSelect::Flagged(ctx->d_sorttmp.p, tmp_bytes, d_iota, d_first, d_sel, d_nsel, (int)nrec, st));
@@ -401,11 +437,10 @@ int ssa_streams_device(kfsp_ctx *ctx, double tstep, int64_t seedmix, int32_t ns,
     }
     // the new states in (seed state, position on the path) order of their first occurrence, and their columns
     const size_t sb = (size_t)nnew * lds * 4, ob = (size_t)nnew * ldo * 8;
-    SSA_TRY(ctx->d_os3.reserve(sb + ob + (size_t)nnew * 8 + 1024, false));
-    Arena a3{ctx->d_os3.p};
-    double *d_on = a3.take<double>((size_t)nnew * ldo), *d_dn = a3.take<double>((size_t)nnew);
-    int32_t *d_sn = a3.take<int32_t>((size_t)nnew * lds);
-    hipLaunchKernelGGL(k_rec_gather, dim3(blocks(nnew)), dim3(kBlock), 0, st, nnew, ns, lds, d_sel, d_rec, d_sn);
+    SSA_TRY(ctx->d_pstage.reserve(((size_t)nnew * ldo + (size_t)nnew + (sb + 7) / 8) + 256, false));
+    double *d_on = ctx->d_pstage.p, *d_dn = d_on + (size_t)nnew * ldo;
+    int32_t *d_sn = reinterpret_cast<int32_t *>(d_dn + nnew);
+    hipLaunchKernelGGL(k_rec_gather, dim3(blocks(nnew)), dim3(kBlock), 0, st, nnew, ns, lds, d_sel, d_perm, d_rec, d_sn);
     if (int rc = prop_eval_device(ctx, nnew, d_sn, lds, d_on, ldo, d_dn)) return rc;
     SSA_TRY(hipMemcpyAsync(state_new, d_sn, sb, hipMemcpyDeviceToHost, st));
     SSA_TRY(hipMemcpyAsync(off_new, d_on, ob, hipMemcpyDeviceToHost, st));
