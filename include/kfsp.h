@@ -166,6 +166,14 @@ int kfsp_matrix_bytes(const kfsp_ctx *ctx, int force_sell, int64_t *bytes);
  *   v[3] reach max |col - row| of the local SELL rows (-1: not a SELL generator)
  *   v[4] chunks with coded columns, v[5] chunks, v[6] 64-bit code words, v[7] internal state order active */
 int kfsp_layout_info(const kfsp_ctx *ctx, int64_t *v);
+/* The ORDER in which a product takes its wavefront trips (one trip = 128 consecutive rows of a banded or matrix-free
+ * generator, 64 of a SELL one; ntrips = ceil(local rows / that)): position t of the sweep computes trip order[t].  Rows
+ * are independent (FMATVEC as a row gather), so y does not depend on the order - bits included; what changes is which rows
+ * of x are in an XCD's L2 when their far neighbours are computed.  kfsp_set_matrix_box chooses a tiled order itself for
+ * boxes with strides beyond the L2 (option "box_tile"); this entry point is for experiments.  Belongs to the current
+ * generator (the next kfsp_set_matrix_* drops it); ntrips = 0 restores the ascending order.  Single rank, whole-product
+ * launches. */
+int kfsp_set_trip_order(kfsp_ctx *ctx, int64_t ntrips, const int32_t *order);
 /* global number of states of the generator last set (FSP%SIZE) */
 int kfsp_num_states(const kfsp_ctx *ctx, int64_t *n);
 

@@ -146,6 +146,7 @@ void set_matrix_args(const kfsp_ctx *c, SpmvArgs &a)
     a.box_fast = reinterpret_cast<const BoxFast *>(c->d_box.p + (c->box_lds_bytes / sizeof(double)));
     a.udot2 = nullptr;
     a.partial2 = nullptr;
+    a.trip_order = nullptr;
 }
 
 // ---- the two collectives of the data path, over RCCL or the loop-back transport ----
@@ -295,6 +296,7 @@ int run_product(kfsp_ctx *ctx, int mode, SpmvArgs a, const double *src, bool src
         a.trip_end = trips;
         a.trip_split = INT64_MAX;
         a.trip_jump = 0;
+        a.trip_order = (ctx->trip_order_n == trips && !force_sell) ? ctx->d_trip_order.p : nullptr;
         const int g = trips_grid(trips, cap);
         launch_spmv(mode, g, a, nt, fmt, st, ctx->box_lds_bytes);
         if (p1) *p1 = Pending{P1, g};
@@ -468,6 +470,7 @@ inline double *vcol(const kfsp_ctx *c, int j) { return c->d_V.p + (size_t)j * (s
 int resize(kfsp_ctx *ctx, int64_t n)
 {
     ctx->n = n;
+    ctx->trip_order_n = 0;             // a trip order belongs to one generator
     ctx->L = round_up((n + ctx->nranks - 1) / ctx->nranks, kChunk);
     if (ctx->L == 0) ctx->L = kChunk;
     ctx->row0 = (int64_t)ctx->rank * ctx->L;
@@ -786,7 +789,7 @@ int kfsp_destroy(kfsp_ctx *ctx)
     ctx->d_off.release(); ctx->d_col.release(); ctx->d_val.release(); ctx->d_diag.release();
     ctx->d_V.release(); ctx->d_w.release(); ctx->d_xg.release(); ctx->d_tmp.release();
     ctx->d_full.release(); ctx->d_wfull.release(); ctx->d_flagloc.release();
-    ctx->d_dtab.release(); ctx->d_dtlen.release(); ctx->d_code.release(); ctx->d_codeoff.release();
+    ctx->d_dtab.release(); ctx->d_dtlen.release(); ctx->d_code.release(); ctx->d_codeoff.release(); ctx->d_trip_order.release();
     ctx->d_part.release(); ctx->d_stage.release(); ctx->d_H.release(); ctx->d_sq.release();
     ctx->d_y.release(); ctx->d_flag.release(); ctx->d_g.release(); ctx->d_dia.release();
     ctx->d_ell_adj.release(); ctx->d_ell_off.release(); ctx->d_ell_diag.release(); ctx->d_cnt.release();
@@ -1356,6 +1359,32 @@ int kfsp_layout_info(const kfsp_ctx *ctx, int64_t *v)
     v[6] = ctx->sell_coded ? ctx->code_words : 0;
     v[7] = ctx->perm_on ? 1 : 0;
     return 0;
+}
+
+int kfsp_set_trip_order(kfsp_ctx *ctx, int64_t ntrips, const int32_t *order)
+{
+    return no_throw(ctx, [&]() -> int {
+        if (!ctx) return -1;
+        if (ctx->group) return fail(ctx, -9, "not available on a group context");
+        if (ctx->ldv == 0) return fail(ctx, -1, "no matrix set");
+        if (ntrips == 0) {
+            ctx->trip_order_n = 0;
+            return 0;
+        }
+        const int64_t trips = ctx->use_dia ? (ctx->nchunks + 1) / 2 : ctx->nchunks;
+        if (ntrips != trips) return fail(ctx, -2, "ntrips is not the number of wavefront trips of the current generator");
+        if (!order) return fail(ctx, -3, "null order");
+        std::vector<uint8_t> seen((size_t)trips, 0);
+        for (int64_t t = 0; t < trips; ++t) {
+            if (order[t] < 0 || order[t] >= trips || seen[(size_t)order[t]]) return fail(ctx, -3, "order is not a permutation of the trips");
+            seen[(size_t)order[t]] = 1;
+        }
+        HIP_TRY(hipSetDevice(ctx->device));
+        HIP_TRY(ctx->d_trip_order.reserve((size_t)trips, false));
+        HIP_TRY(hipMemcpy(ctx->d_trip_order.p, order, (size_t)trips * sizeof(int32_t), hipMemcpyHostToDevice));
+        ctx->trip_order_n = trips;
+        return 0;
+    });
 }
 
 int kfsp_num_states(const kfsp_ctx *ctx, int64_t *n)

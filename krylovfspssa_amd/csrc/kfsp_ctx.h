@@ -189,6 +189,9 @@ struct kfsp_ctx {
     DevBuf<uint32_t> d_gmask;
     DevBuf<double> d_zero;   // 128 zeros, the stand-in for an empty segment
     bool dia_masked = false;
+    // optional order of the product's wavefront trips (kfsp_set_trip_order / the box tiling): trips of the CURRENT generator
+    DevBuf<int32_t> d_trip_order;
+    int64_t trip_order_n = 0;          // 0: ascending order
     // matrix-free box generator (kfsp_set_matrix_box): descriptor (host copy, passed as a kernel
     // argument) and the factor tables in device memory
     kfsp::BoxDev box;

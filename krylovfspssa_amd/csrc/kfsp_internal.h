@@ -157,6 +157,10 @@ struct SpmvArgs {
     // linear trip t stands for trip (t < trip_split ? t : t + trip_jump): one launch
     // can cover the two boundary ranges [0, lo) and [hi, trips)
     int64_t trip_split, trip_jump;
+    // optional: the ORDER in which the wavefront trips are taken - linear position t stands for trip trip_order[t].
+    // Rows are independent, so any order gives the same y; a tiled order keeps the far neighbours of a box's rows in
+    // the XCD's L2 (kfsp_set_trip_order / box tiling).  Null: ascending.  Whole-product launches only.
+    const int32_t *trip_order;
 };
 
 // Both Gram-Schmidt updates of an IOP(2) column in one pass.  With

@@ -633,6 +633,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv(SpmvArgs a)
     // finished: the partial-sum round trip overlaps the first generator loads.
     d2 sum = {0.0, 0.0};
     int64_t ct = c < a.trip_split ? c : c + a.trip_jump;   // actual trip of linear index c
+    if (a.trip_order && c < cend) ct = __builtin_amdgcn_readfirstlane(a.trip_order[c]);
     unsigned gm = 0xFFFFFFFFu;                              // group mask of the trip about to be computed
     if (FMT == 2 && c < cend) gm = __builtin_amdgcn_readfirstlane(a.D.gmask[ct]);
     if (c < cend) {
@@ -661,7 +662,8 @@ __global__ __launch_bounds__(kBlock) void k_spmv(SpmvArgs a)
     double acc = 0.0, acc2 = 0.0;
     while (c < cend) {
         const int64_t cn = c + cstep;
-        const int64_t ctn = cn < a.trip_split ? cn : cn + a.trip_jump;
+        int64_t ctn = cn < a.trip_split ? cn : cn + a.trip_jump;
+        if (a.trip_order && cn < cend) ctn = __builtin_amdgcn_readfirstlane(a.trip_order[cn]);
         if (FMT == 2 && cn < cend) gm = __builtin_amdgcn_readfirstlane(a.D.gmask[ctn]);
         if (DIA) {
             const int64_t r = (ct << 7) + 2 * lane;

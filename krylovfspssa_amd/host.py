@@ -61,6 +61,7 @@ def load_library():
         "kfsp_matrix_bytes": [vp, C.c_int, C.POINTER(i64)],
         "kfsp_num_states": [vp, C.POINTER(i64)],
         "kfsp_layout_info": [vp, vp],
+        "kfsp_set_trip_order": [vp, i64, vp],
         "kfsp_onestep": [vp, i32, i32, vp, i32, vp, i32, vp, i32, i32, i32, C.POINTER(i32), vp, vp],
         "kfsp_onestep_columns": [vp, i32, i32, vp, i32, vp, i32, vp, i32, i32, i32, C.POINTER(i32), vp, vp, vp, i32, vp],
         "kfsp_set_propensity_program": [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp],
@@ -399,6 +400,14 @@ class KfspContext:
         b = C.c_int64(0)
         self._chk(self._lib.kfsp_matrix_bytes(self._h, int(force_sell), C.byref(b)), "kfsp_matrix_bytes")
         return b.value
+
+    def set_trip_order(self, order):
+        """order of the product's wavefront trips (None: ascending)"""
+        if order is None:
+            self._chk(self._lib.kfsp_set_trip_order(self._h, 0, None), "kfsp_set_trip_order")
+            return
+        order = np.ascontiguousarray(order, dtype=np.int32)
+        self._chk(self._lib.kfsp_set_trip_order(self._h, len(order), _p(order)), "kfsp_set_trip_order")
 
     def layout_info(self):
         v = np.zeros(8, dtype=np.int64)
