@@ -161,7 +161,7 @@ int kfsp_matrix_info(const kfsp_ctx *ctx, int64_t *nrows, int64_t *slots, int64_
 int kfsp_matrix_bytes(const kfsp_ctx *ctx, int force_sell, int64_t *bytes);
 /* what the device holds and how a partitioned product exchanges its source vector, v[8]:
  *   v[0] kernel format: 0 SELL-64, 1 banded, 2 banded with group masks, 3 / 4 matrix-free box (interpreted / fast path),
- *        5 SELL-64 with dictionary-coded columns (option "sell_code")
+ *        5 SELL-64 with dictionary-coded columns (option "sell_code"), 6 matrix-free fast path with the near part of x in LDS
  *   v[1] exchange: 0 none (no communicator), 1 halo strips, 2 all-gather of the whole vector;  v[2] halo rows
  *   v[3] reach max |col - row| of the local SELL rows (-1: not a SELL generator)
  *   v[4] chunks with coded columns, v[5] chunks, v[6] 64-bit code words, v[7] internal state order active */
@@ -471,7 +471,9 @@ int kfsp_add_timer(kfsp_ctx *ctx, int phase, double ms);
  * "host_build", "halo", "halo_p2p" (1: halo strips travel between neighbouring ranks only, ncclSend/ncclRecv straight into the
  * column margins; 0, default: one all-gather of every rank's strips), "halo_sell" (0: SELL generators always all-gather the whole source
  * vector; 1, default: a SELL generator whose reach max |col - row| is at most one block - bounded under the internal state order -
- * exchanges halo strips like a banded one), "overlap", "small_kernel", "small_lds", "dia_mask", "ssa_resident" (1: the caller vouches that the FSP arrays handed to kfsp_ssa_streams are the ones of its last
+ * exchanges halo strips like a banded one), "overlap", "small_kernel", "small_lds", "dia_mask", "box_lds" (1, default: the single-factor matrix-free product stages the part of x within "box_reach" rows - default
+ * 512 - of a workgroup's rows in LDS and serves the near entries from there, kernel format 6; 0: every entry gathers from global
+ * memory, format 4; bit-identical results), "ssa_resident" (1: the caller vouches that the FSP arrays handed to kfsp_ssa_streams are the ones of its last
  * kfsp_update_matrix_ell / kfsp_set_state_coords: they are taken from the device's copies instead of being uploaded again; default 0),
  * "sell_code" (dictionary-coded SELL columns, DESIGN.md 4.1c: -1 auto = under the internal state order,
  * 0 never, 1 always try), "m_max" (largest Krylov dimension the basis is allocated for, default and maximum 100 = M_MAX of

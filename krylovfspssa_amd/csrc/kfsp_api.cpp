@@ -298,7 +298,13 @@ int run_product(kfsp_ctx *ctx, int mode, SpmvArgs a, const double *src, bool src
         a.trip_jump = 0;
         a.trip_order = (ctx->trip_order_n == trips && !force_sell) ? ctx->d_trip_order.p : nullptr;
         const int g = trips_grid(trips, cap);
-        launch_spmv(mode, g, a, nt, fmt, st, ctx->box_lds_bytes);
+        if (fmt == 4 && ctx->box_reach > 0 && ctx->opt_box_lds != 0 && !ctx->use_comm && a.trip_order == nullptr) {
+            // format 6: near entries from an LDS window of x (single rank: x is readable exactly on [0, n))
+            const size_t img = (ctx->box_lds_bytes + 15) & ~(size_t)15;
+            launch_spmv_boxlds(mode, g, a, st, img + 2 * (size_t)(512 + 2 * ctx->box_reach) * sizeof(double), ctx->box_reach);
+        } else {
+            launch_spmv(mode, g, a, nt, fmt, st, ctx->box_lds_bytes);
+        }
         if (p1) *p1 = Pending{P1, g};
         if (p2) *p2 = Pending{P2, g};
         return 0;
@@ -1239,6 +1245,19 @@ int kfsp_set_matrix_box(kfsp_ctx *ctx, int32_t ns, const int32_t *dims, int32_t 
         HIP_TRY(hipMemcpy(ctx->d_box.p, image.data(), image.size() * sizeof(double), hipMemcpyHostToDevice));
         ctx->box = B;
         ctx->box_fast = fast;
+        // format 6: the largest shift within opt_box_reach rows decides how much of x a workgroup stages in LDS;
+        // the windows must fit beside the table image in the 64 KB a workgroup gets without asking for more
+        ctx->box_reach = 0;
+        if (fast) {
+            int64_t reach = 0;
+            for (int p = 0; p < nr; ++p) {
+                const int64_t d = std::llabs((long long)order[(size_t)p].delta);
+                if (d <= ctx->opt_box_reach) reach = std::max(reach, d);
+            }
+            reach = (reach + 1) & ~(int64_t)1;
+            const size_t need = (((size_t)nimage * 8 + 15) & ~(size_t)15) + 2 * (size_t)(512 + 2 * reach) * 8 + 256;
+            if (reach > 0 && need <= 64 * 1024) ctx->box_reach = (int)reach;
+        }
         ctx->box_lds_bytes = (size_t)nimage * sizeof(double);
         // the same bookkeeping as a banded generator with one diagonal per reaction
         ctx->nchunks = (ctx->nloc + kChunk - 1) / kChunk;
@@ -1350,7 +1369,7 @@ int kfsp_layout_info(const kfsp_ctx *ctx, int64_t *v)
     if (!ctx) return -1;
     if (!v) return -2;
     if (ctx->group) return kfsp::group_layout_info(ctx, v);
-    v[0] = ctx->use_box ? (ctx->box_fast && !ctx->opt_box_generic ? 4 : 3) : ctx->use_dia ? (ctx->dia_masked ? 2 : 1) : (ctx->sell_coded ? 5 : 0);
+    v[0] = ctx->use_box ? (ctx->box_fast && !ctx->opt_box_generic ? (ctx->box_reach > 0 && ctx->opt_box_lds && !ctx->use_comm ? 6 : 4) : 3) : ctx->use_dia ? (ctx->dia_masked ? 2 : 1) : (ctx->sell_coded ? 5 : 0);
     v[1] = !ctx->use_comm ? 0 : (ctx->use_halo ? 1 : 2);
     v[2] = ctx->halo;
     v[3] = ctx->use_dia ? -1 : ctx->sell_reach;
@@ -2145,6 +2164,8 @@ int kfsp_set_option(kfsp_ctx *ctx, const char *name, int64_t value)
     else if (k == "host_build") ctx->opt_host_build = value;
     else if (k == "dia_mask") ctx->opt_dia_mask = value;
     else if (k == "box_generic") ctx->opt_box_generic = value;
+    else if (k == "box_lds") ctx->opt_box_lds = value;
+    else if (k == "box_reach") ctx->opt_box_reach = value;
     else if (k == "box_store") ctx->opt_box_store = value;
     else if (k == "sell_code") ctx->opt_sell_code = value;
     else if (k == "ssa_resident") ctx->opt_ssa_resident = value;

@@ -199,6 +199,7 @@ struct kfsp_ctx {
     bool use_box = false;
     bool box_fast = false;        // the single-factor form (BoxFast) sits behind the tables
     size_t box_lds_bytes = 0;
+    int box_reach = 0;                // rows of x staged in LDS on either side of a workgroup's 512 (format 6), 0: format 4
     int64_t dia_empty_segments = 0;   // (diagonal, 128-row group) pairs without entries
     // device-side build from the reference layout (kfsp_build.hip)
     DevBuf<int32_t> d_ell_adj, d_cnt, d_ticket;
@@ -277,6 +278,8 @@ struct kfsp_ctx {
     int64_t opt_small_lds = 1;            // 0: the one-launch Arnoldi kernel reads the generator from global memory
     int64_t lds_per_block = 65536;        // device limit (hipDeviceAttributeMaxSharedMemoryPerBlock)
     int64_t opt_dia_mask = 1;             // 0: never skip empty diagonal segments
+    int64_t opt_box_lds = 1;              // 1: the single-factor matrix-free product stages the near part of x in LDS (format 6)
+    int64_t opt_box_reach = 512;          // largest shift (rows) served from that window
     int64_t opt_box_generic = 0;          // 1: matrix-free boxes always take the run-time interpreted kernel
     int64_t opt_mmax = kfsp::kMMax;        // largest Krylov dimension the basis is allocated for (m_max + 3 columns)
     int64_t opt_ssa_resident = 0;          // 1: the caller vouches that the arrays given to kfsp_ssa_streams are the ones last uploaded

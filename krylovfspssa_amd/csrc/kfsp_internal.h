@@ -231,6 +231,9 @@ int launch_arnoldi_small(const SmallArnoldiArgs &a, bool dia, int64_t lds_limit,
 // fmt: 0 SELL-64, 1 banded, 2 banded with group masks, 3 matrix-free box (lds_bytes = size of the factor tables),
 // 4 matrix-free box, single-factor fast path, 5 SELL-64 with dictionary-coded columns
 void launch_spmv(int mode, int grid, const SpmvArgs &a, bool nontemporal, int fmt, hipStream_t s, size_t lds_bytes = 0);
+// format 6: the single-factor matrix-free product with the near part of x staged in LDS (reach rows on either side of a
+// workgroup's 512; lds_bytes = table image + two windows)
+void launch_spmv_boxlds(int mode, int grid, const SpmvArgs &a, hipStream_t s, size_t lds_bytes, int reach);
 void launch_ortho2(int grid, const Ortho2Args &a, hipStream_t s);
 void launch_ortho(int grid, const OrthoArgs &a, hipStream_t s);
 void launch_combine(int grid, const CombineArgs &a, hipStream_t s);

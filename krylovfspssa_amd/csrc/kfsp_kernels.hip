@@ -718,6 +718,242 @@ __global__ __launch_bounds__(kBlock) void k_spmv(SpmvArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Format 6: the single-factor matrix-free product (format 4) with the NEAR part of x staged in LDS.
+// Format 4 fetches every entry's x pair with its own 16-byte global gather: a row's x goes through the CU's vector L1 once
+// per entry (7 x for the repressilator, 13 x for the 6-species network), and at ~18 wave-instructions per ns chip-wide -
+// half the 64 B/clk/CU of the L1 - that, not HBM, is what the kernel waits for (profiles/r03_pmc_summary_boxes_and_fsp.txt:
+// the same rate on c3x and on c5s).  The four wavefronts of a workgroup take four consecutive 128-row trips, i.e. 512
+// consecutive rows: their x and the `reach` rows on either side are loaded ONCE per workgroup pass (16 B per lane,
+// coalesced, two buffers so that the next pass's window is in flight while this one is computed; one barrier per
+// pass), and every entry whose shift is within the reach - the diagonal, +-1, +-d1, +-d1 d2 when they fit - reads its
+// pair from LDS (ds_read2_b64, conflict-free: consecutive lanes read consecutive pairs).  Far entries keep their
+// gathers.  Same table look-ups, same products, same order of additions as format 4: bit-identical results.
+template <int S, int NS, int PER>
+__device__ __forceinline__ void box_species_lds(const BoxRegs<NS, PER> &R, int xa, int xb, unsigned va, unsigned vb,
+                                                global_bytes_t xw, unsigned voff, const double *win, int wrow, int reach8,
+                                                double &acca, double &accb)
+{
+    const unsigned lds0 = (unsigned)(size_t)(lds_bytes_t)box_lds;                  // LDS address of the image = of its 0.0
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int ma = __builtin_amdgcn_sbfe(va, S * PER + j, 1);                  // -1: source state of row A inside the box
+        const int mb = __builtin_amdgcn_sbfe(vb, S * PER + j, 1);
+        const unsigned ata = lds0 + (unsigned)(8 * xa + R.koff8[S][j]);           // a_k(x - nu_k) ...
+        const unsigned atb = lds0 + (unsigned)(8 * xb + R.koff8[S][j]);
+        const double a1a = *(const __attribute__((address_space(3))) double *)(size_t)((ma & ata) | (~ma & lds0));   // ... or 0
+        const double a1b = *(const __attribute__((address_space(3))) double *)(size_t)((mb & atb) | (~mb & lds0));
+        const int d8 = R.delta8[S][j];
+        box_pair_t xv;
+        if ((d8 < 0 ? -d8 : d8) <= reach8) {                                      // uniform: the descriptor sits in SGPRs
+            const int sh = (ma | mb) ? (d8 >> 3) : 0;                              // neither row has the entry: their own x
+            xv.x = win[wrow + sh];
+            xv.y = win[wrow + sh + 1];
+        } else {
+            const unsigned vsrc = voff + (unsigned)d8;
+            const unsigned at = (unsigned)__builtin_amdgcn_bitop3_b32(ma | mb, (int)vsrc, (int)voff, 0xCA);   // either ? vsrc : voff
+            xv = *(const __attribute__((address_space(1), aligned(8))) box_pair_t *)(xw + at);
+        }
+        acca += a1a * xv.x;
+        accb += a1b * xv.y;
+    }
+}
+
+template <int NS, int PER>
+__device__ __forceinline__ d2 rows_box_lds(const BoxRegs<NS, PER> &R, const double *__restrict__ xg, int64_t row0, int64_t nloc,
+                                           int64_t c, int lane, const double *win, int wrow, int reach8)
+{
+    d2 sum = {0.0, 0.0};
+    const int64_t r0 = (c << 7) + 2 * lane;
+    if (r0 >= nloc) return sum;
+    const int64_t g = row0 + r0;
+    const uint64_t xb = reinterpret_cast<uint64_t>(xg + (row0 + (c << 7))) - (uint64_t)(int64_t)R.bias8;
+    const global_bytes_t xw = (global_bytes_t)((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)xb) |
+                                               (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(xb >> 32)) << 32);
+    const unsigned voff = (unsigned)(16 * lane + R.bias8);
+    int c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
+    uint32_t q = (uint32_t)g;
+#define KFSP_BOX_DEC(S, VAR)                                             \
+    if (NS > S + 1) {                                                    \
+        const int d = R.dims[NS > S ? S : 0];                            \
+        uint32_t t = (uint32_t)((double)q * R.inv_dim[NS > S ? S : 0]);  \
+        int r = (int)(q - t * (uint32_t)d);                              \
+        const int lo = r < 0, hi = r >= d;                               \
+        t = t - lo + hi;                                                 \
+        r = r + (lo ? d : 0) - (hi ? d : 0);                             \
+        VAR = r;                                                         \
+        q = t;                                                           \
+    } else if (NS == S + 1) {                                            \
+        VAR = (int)q;                                                    \
+    }
+    KFSP_BOX_DEC(0, c0)
+    KFSP_BOX_DEC(1, c1)
+    KFSP_BOX_DEC(2, c2)
+    KFSP_BOX_DEC(3, c3)
+    KFSP_BOX_DEC(4, c4)
+    KFSP_BOX_DEC(5, c5)
+#undef KFSP_BOX_DEC
+    int b0 = c0, b1 = c1, b2 = c2, b3 = c3, b4 = c4, b5 = c5, carry = 1;
+#define KFSP_BOX_INC(S, VAR)                                             \
+    if (NS > S) {                                                        \
+        const int v = VAR + carry;                                       \
+        const int wrap = (NS > S + 1) && v >= R.dims[NS > S ? S : 0];    \
+        VAR = wrap ? 0 : v;                                              \
+        carry = wrap;                                                    \
+    }
+    KFSP_BOX_INC(0, b0)
+    KFSP_BOX_INC(1, b1)
+    KFSP_BOX_INC(2, b2)
+    KFSP_BOX_INC(3, b3)
+    KFSP_BOX_INC(4, b4)
+    KFSP_BOX_INC(5, b5)
+#undef KFSP_BOX_INC
+    const bool two = r0 + 1 < nloc;
+    if (!two) b0 = b1 = b2 = b3 = b4 = b5 = 0;
+    double dsa, dsb;
+    unsigned va, vb;
+    box_df<NS, PER>(R, c0, c1, c2, c3, c4, c5, dsa, va);
+    box_df<NS, PER>(R, b0, b1, b2, b3, b4, b5, dsb, vb);
+    if (!two) vb = 0u;
+    const double xda = win[wrow], xdb = win[wrow + 1];
+    double acca = 0.0, accb = 0.0;
+    box_species_lds<0, NS, PER>(R, c0, b0, va, vb, xw, voff, win, wrow, reach8, acca, accb);
+    if (NS > 1) box_species_lds<(NS > 1 ? 1 : 0), NS, PER>(R, c1, b1, va, vb, xw, voff, win, wrow, reach8, acca, accb);
+    if (NS > 2) box_species_lds<(NS > 2 ? 2 : 0), NS, PER>(R, c2, b2, va, vb, xw, voff, win, wrow, reach8, acca, accb);
+    if (NS > 3) box_species_lds<(NS > 3 ? 3 : 0), NS, PER>(R, c3, b3, va, vb, xw, voff, win, wrow, reach8, acca, accb);
+    if (NS > 4) box_species_lds<(NS > 4 ? 4 : 0), NS, PER>(R, c4, b4, va, vb, xw, voff, win, wrow, reach8, acca, accb);
+    if (NS > 5) box_species_lds<(NS > 5 ? 5 : 0), NS, PER>(R, c5, b5, va, vb, xw, voff, win, wrow, reach8, acca, accb);
+    sum.x = acca - dsa * xda;
+    sum.y = two ? accb - dsb * xdb : 0.0;
+    return sum;
+}
+
+// reach: rows staged on either side of the workgroup's 512 (even); x is readable for global rows [0, a.D.n)
+template <int MODE, int NS, int PER>
+__global__ __launch_bounds__(kBlock) void k_spmv_boxlds(SpmvArgs a, int reach)
+{
+    __shared__ double red[12];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (MODE != 0) {
+        if (*a.brk_flag) return;
+    }
+    BoxRegs<NS, PER> boxr;
+    for (int i = threadIdx.x; i < a.B.ntab; i += kBlock) box_lds[i] = a.box_tab[i];
+    box_load(a.box_fast, boxr);
+    const int W = 4 * 128 + 2 * reach;                     // doubles per window
+    double *win0 = box_lds + ((a.B.ntab + 1) & ~1);        // two windows behind the table image (16-byte aligned)
+    const int xcd = blockIdx.x & 7;
+    const int slot = blockIdx.x >> 3;
+    const int bx = gridDim.x >> 3;                        // workgroups per XCD
+    const int64_t trips = a.trip_end - a.trip_begin;
+    const int64_t cpx = (((trips + 7) >> 3) + 3) & ~(int64_t)3;    // trips per XCD, a multiple of the 4 a workgroup takes per pass
+    const int64_t cbeg = a.trip_begin + (int64_t)xcd * cpx;
+    const int64_t cend = (cbeg + cpx < a.trip_end) ? cbeg + cpx : a.trip_end;
+    const int64_t cstep = (int64_t)bx * 4;
+    int64_t c0 = cbeg + (int64_t)slot * 4;                // the workgroup's first trip of this pass (uniform)
+    const int64_t xn = a.D.n;
+    // window of the pass that starts at trip cw: global rows [row0 + 128 cw - reach, row0 + 128 (cw + 4) + reach), zero outside x
+    auto stage = [&](double *win, int64_t cw) {
+        const int64_t gb = a.row0 + (cw << 7) - reach;
+        for (int i = 2 * (int)threadIdx.x; i < W; i += 2 * kBlock) {
+            const int64_t g = gb + i;
+            d2 v;
+            if (g >= 0 && g + 1 < xn) {
+                v = *reinterpret_cast<const d2 *>(a.xg + g);
+            } else {
+                v.x = (g >= 0 && g < xn) ? a.xg[g] : 0.0;
+                v.y = (g + 1 >= 0 && g + 1 < xn) ? a.xg[g + 1] : 0.0;
+            }
+            *reinterpret_cast<d2 *>(win + i) = v;
+        }
+    };
+    if (c0 < cend) stage(win0, c0);
+    __syncthreads();                                       // table image + first window
+    double s = 1.0;
+    if (MODE != 0) {
+        const double S = finish_sum(a.sq, red);
+        const double nrm = sqrt(S);
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            if (a.sq_final) *a.sq_final = S;
+            if (a.h_sub) *a.h_sub = nrm;
+        }
+        if (a.break_tol >= 0.0 && !(nrm > a.break_tol)) {   // happy breakdown :249
+            if (blockIdx.x == 0 && threadIdx.x == 0) *a.brk_flag = 1;
+            return;
+        }
+        s = 1.0 / nrm;
+    }
+    const int reach8 = 8 * reach;
+    const int wrow = wave * 128 + 2 * lane + reach;        // this lane's first row inside a window
+    double acc = 0.0, acc2 = 0.0;
+    int buf = 0;
+    while (c0 < cend) {
+        const int64_t c0n = c0 + cstep;
+        double *win = win0 + buf * W;
+        if (c0n < cend) stage(win0 + (buf ^ 1) * W, c0n);  // the next window travels while this one is computed
+        const int64_t c = c0 + wave;
+        if (c < cend) {
+            d2 sum = rows_box_lds<NS, PER>(boxr, a.xg, a.row0, a.A.nrows, c, lane, win, wrow, reach8);
+            const int64_t r = (c << 7) + 2 * lane;
+            if (MODE != 0) {
+                sum.x *= s;
+                sum.y *= s;
+            }
+            *reinterpret_cast<d2 *>(a.y + r) = sum;
+            if (MODE == 1 || MODE == 3) {
+                const d2 u = *reinterpret_cast<const d2 *>(a.udot + r);
+                acc += u.x * sum.x;
+                acc += u.y * sum.y;
+            }
+            if (MODE == 2) {
+                acc += sum.x * sum.x;
+                acc += sum.y * sum.y;
+            }
+            if (MODE == 3) {
+                const d2 u = *reinterpret_cast<const d2 *>(a.udot2 + r);
+                acc2 += u.x * sum.x;
+                acc2 += u.y * sum.y;
+            }
+        }
+        __syncthreads();                                   // next window complete, this one free
+        c0 = c0n;
+        buf ^= 1;
+    }
+    if (MODE == 3) {
+        double dummy = 0.0;
+        block_allreduce_sum3(acc, acc2, dummy, red);
+        if (threadIdx.x == 0) {
+            a.partial[blockIdx.x] = acc;
+            a.partial2[blockIdx.x] = acc2;
+        }
+    } else if (MODE != 0) {
+        const double t = block_allreduce_sum(acc, red);
+        if (threadIdx.x == 0) a.partial[blockIdx.x] = t;
+    }
+}
+
+template <int NS, int NE>
+static void launch_boxlds_mode(int mode, dim3 g, dim3 b, const SpmvArgs &a, hipStream_t st, size_t lds, int reach)
+{
+    if (mode == 0) hipLaunchKernelGGL((k_spmv_boxlds<0, NS, NE>), g, b, lds, st, a, reach);
+    else if (mode == 1) hipLaunchKernelGGL((k_spmv_boxlds<1, NS, NE>), g, b, lds, st, a, reach);
+    else if (mode == 2) hipLaunchKernelGGL((k_spmv_boxlds<2, NS, NE>), g, b, lds, st, a, reach);
+    else hipLaunchKernelGGL((k_spmv_boxlds<3, NS, NE>), g, b, lds, st, a, reach);
+}
+
+// format 6: lds_bytes = table image (rounded to 16 B) + two windows of (512 + 2 reach) doubles
+void launch_spmv_boxlds(int mode, int grid, const SpmvArgs &a, hipStream_t st, size_t lds_bytes, int reach)
+{
+    dim3 g(grid), b(kBlock);
+    switch (a.B.pad) {
+    case 2 * 16 + 2: launch_boxlds_mode<2, 2>(mode, g, b, a, st, lds_bytes, reach); break;
+    case 3 * 16 + 2: launch_boxlds_mode<3, 2>(mode, g, b, a, st, lds_bytes, reach); break;
+    case 6 * 16 + 2: launch_boxlds_mode<6, 2>(mode, g, b, a, st, lds_bytes, reach); break;
+    default: launch_boxlds_mode<6, 4>(mode, g, b, a, st, lds_bytes, reach); break;
+    }
+}
+
 template <bool NT, int FMT>
 static void launch_spmv_mode(int mode, dim3 g, dim3 b, const SpmvArgs &a, hipStream_t st, size_t lds = 0)
 {

@@ -141,6 +141,38 @@ def test_box_written_out_on_the_device_equals_the_uploaded_rows(oracle, name):
     assert np.array_equal(y2, y)
 
 
+@pytest.mark.parametrize("name", ["toggle", "repressilator", "birth_death6", "line"])
+def test_lds_window_gives_the_bits_of_the_gather_kernel(name):
+    """format 6 (the near part of x staged in LDS per workgroup) against format 4 (every entry its own global gather):
+    same table look-ups, same products, same order of additions - bit-identical products, Arnoldi passes and steps;
+    also with a reach smaller than the box's strides (only +-1 from LDS) and on boxes whose last trips are partial."""
+    from krylovfspssa_amd import KfspContext
+    mdl = _models()[name]
+    rng = np.random.default_rng(12)
+    x = rng.random(mdl.n)
+    p0 = rng.random(mdl.n)
+    p0 /= p0.sum()
+    out = {}
+    for key, opts in {"gather": {"box_lds": 0}, "lds": {"box_lds": 1}, "lds, reach 2": {"box_lds": 1, "box_reach": 2}}.items():
+        with KfspContext(0) as c:
+            c.set_option("small_kernel", 0)
+            for k, v in opts.items():
+                c.set_option(k, v)
+            c.set_matrix_box(mdl)
+            fmt = c.layout_info()["format"]
+            assert fmt == (4 if key == "gather" else 6), (key, fmt)
+            y = c.spmv(x)
+            c.set_vector(p0)
+            c.begin_step()
+            H, mb, k1, av = c.arnoldi(9)
+            c.set_vector(p0)
+            ws = c.expv_fixed(9, 0.004, 2)
+            out[key] = (y, H.copy(), av, ws, c.get_vector())
+    for key in ("lds", "lds, reach 2"):
+        for a, b in zip(out["gather"], out[key]):
+            assert np.array_equal(a, b), key
+
+
 def test_bad_boxes_are_rejected():
     from krylovfspssa_amd import KfspContext, KfspError, synth
     with KfspContext(0) as c:
