@@ -471,9 +471,9 @@ int kfsp_add_timer(kfsp_ctx *ctx, int phase, double ms);
  * "host_build", "halo", "halo_p2p" (1: halo strips travel between neighbouring ranks only, ncclSend/ncclRecv straight into the
  * column margins; 0, default: one all-gather of every rank's strips), "halo_sell" (0: SELL generators always all-gather the whole source
  * vector; 1, default: a SELL generator whose reach max |col - row| is at most one block - bounded under the internal state order -
- * exchanges halo strips like a banded one), "overlap", "small_kernel", "small_lds", "dia_mask", "box_lds" (1, default: the single-factor matrix-free product stages the part of x within "box_reach" rows - default
- * 512 - of a workgroup's rows in LDS and serves the near entries from there, kernel format 6; 0: every entry gathers from global
- * memory, format 4; bit-identical results), "ssa_resident" (1: the caller vouches that the FSP arrays handed to kfsp_ssa_streams are the ones of its last
+ * exchanges halo strips like a banded one), "overlap", "small_kernel", "small_lds", "dia_mask", "box_lds" (1: the single-factor matrix-free product stages the part of x within "box_reach" rows - default
+ * 512 - of a workgroup's rows in LDS and serves the near entries from there, kernel format 6; 0, default: every entry gathers from
+ * global memory, format 4, which measured faster on every box; bit-identical products), "ssa_resident" (1: the caller vouches that the FSP arrays handed to kfsp_ssa_streams are the ones of its last
  * kfsp_update_matrix_ell / kfsp_set_state_coords: they are taken from the device's copies instead of being uploaded again; default 0),
  * "sell_code" (dictionary-coded SELL columns, DESIGN.md 4.1c: -1 auto = under the internal state order,
  * 0 never, 1 always try), "m_max" (largest Krylov dimension the basis is allocated for, default and maximum 100 = M_MAX of
