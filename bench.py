@@ -469,6 +469,8 @@ def main():
             mf_ms = max_over_ranks(ctx.spmv_bench(args.steps, 0)) / args.steps
             barrier()
             mf_bytes = ctx.matrix_bytes()
+            mf_traffic, _ = pmc_traffic(args.workload + "_matrix_free")
+            mf_moved = max(mf_bytes, mf_traffic or 0)
             out["matrix_free"] = {
                 "what": "y = A x of the same workload with NO stored generator: propensity factor tables in LDS, rows rebuilt "
                         "from the row index (kfsp_set_matrix_box)",
@@ -478,8 +480,11 @@ def main():
                 "real_GBps": round(mf_bytes / (mf_ms * 1e-3) / 1e9, 2),
                 "speedup_vs_stored": round(kern_ms / mf_ms, 3),
                 "self_check": {"ok": bool(mf_err < 1e-12), "max_rel_err": mf_err},
-                "frac": round(mf_bytes / (mf_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                "bound": "memory latency / vector-memory issue (16 B/state of HBM traffic; DESIGN 4.1b)",
+                "traffic": mf_traffic,
+                "frac": round(mf_moved / (mf_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "frac_16B_per_state": round(mf_bytes / (mf_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "bound": "3-species boxes: within 10 % of the fabric rate for its traffic; 6-species boxes: re-fetching x through L2s "
+                         "that cannot hold its far strides (DESIGN 4.1b, 10.5; profiles/r03_box_lds_and_tiling.txt)",
             }
 
     # ------------------------------------------- the 10^7-state product (the size of the 60 % target)
@@ -507,7 +512,7 @@ def main():
             ms7 = max_over_ranks(ctx.spmv_bench(args.steps, 0)) / args.steps
             barrier()
             nnz7 = big.nnz() if world == 1 else big.nnz_rows(br0, bnr)
-            t7, t7src = pmc_traffic("c3x") if store else (None, None)
+            t7, t7src = pmc_traffic("c3x" if store else "c3x_matrix_free")
             blk[label] = roofline(ms7, synth.spmv_alg_bytes(nnz7, bnr), ctx.matrix_bytes(), t7, t7src)
             blk[label]["self_check"] = {"ok": bool(e7 < 1e-12), "max_rel_err": e7}
         out["spmv_1e7"] = blk
