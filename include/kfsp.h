@@ -237,6 +237,14 @@ int kfsp_drop_flags(kfsp_ctx *ctx, int64_t n, uint8_t *dropped);
  * all-gather), compacts it with the flags it holds, and takes its new block when the generator arrives. */
 int kfsp_drop_compact(kfsp_ctx *ctx, int64_t *n_new);
 
+/* After kfsp_drop_compact: the generator of the compacted FSP from the device's OWN copy of the reference arrays - the
+ * columns of the kept states move up in list order, ADJ is renumbered through the keep-prefix-sum, dropped targets become 0
+ * (StateSpace.f90:500-546 for STATE / ADJ / OFFDIAG / DIAG), the gather form is rebuilt and the compacted w adopted: no
+ * array travels.  Stands in for the kfsp_set_state_coords + kfsp_set_matrix_ell the host would otherwise send for the
+ * compacted FSP (the host still compacts ITS copy of the lists with the flags).  -9 when the arrays of this FSP are not
+ * resident (a CSR / box generator, option host_build): upload the compacted generator as before. */
+int kfsp_drop_rebuild(kfsp_ctx *ctx);
+
 /* ---- ONESTEP_EXTENDER on the device (StateSpace.f90:347-396 with ADD_STATE :136-246) ---- */
 /* The integer work of one reachability sweep over the listed states state[0..n) (ns counts each,
  * leading dimension ld_state) with link array adj (nr links each, leading dimension ld_adj; the

@@ -802,7 +802,7 @@ int kfsp_destroy(kfsp_ctx *ctx)
     ctx->d_ticket.release(); ctx->d_slot.release(); ctx->d_scan.release(); ctx->d_strip.release();
     ctx->d_dropflag.release(); ctx->d_dropcnt.release(); ctx->d_box.release(); ctx->d_os1.release(); ctx->d_os2.release();
     ctx->d_os3.release(); ctx->d_prop_i.release(); ctx->d_prop_d.release();
-    ctx->d_perm.release(); ctx->d_iperm.release(); ctx->d_coords.release(); ctx->d_ell_adj2.release();
+    ctx->d_perm.release(); ctx->d_iperm.release(); ctx->d_coords.release(); ctx->d_coords2.release(); ctx->d_ell_adj2.release();
     ctx->d_ell_off2.release(); ctx->d_ell_diag2.release(); ctx->d_pstage.release(); ctx->d_keys.release();
     ctx->d_sortidx.release(); ctx->d_sorttmp.release(); ctx->d_gmask.release(); ctx->d_zero.release();
     if (ctx->h_loop) (void)hipHostFree(ctx->h_loop);
@@ -1985,11 +1985,59 @@ int kfsp_drop_compact(kfsp_ctx *ctx, int64_t *n_new)
     HIP_TRY(hipStreamSynchronize(st));
     if ((int64_t)nk != n - ctx->drop_flagged) return fail(ctx, 4000, "compaction count does not match the plan");
     ctx->drop_planned = false;
+    ctx->drop_ell_cols = ctx->ell_cols;   // (kfsp_drop_rebuild can renumber the device's own copy)
+    ctx->drop_bw = ctx->ell_bw;
     ctx->ell_cols = 0;                 // the columns are about to be renumbered
     ctx->w_pending = true;
     ctx->w_pending_n = nk;
     *n_new = nk;
     return 0;
+}
+
+int kfsp_drop_rebuild(kfsp_ctx *ctx)
+{
+    return no_throw(ctx, [&]() -> int {
+        if (!ctx) return -1;
+        if (ctx->group) return kfsp::group_drop_rebuild(ctx);
+        if (!ctx->w_pending) return fail(ctx, -1, "no compaction pending (kfsp_drop_compact)");
+        const int64_t n_old = ctx->drop_n, n_new = ctx->w_pending_n;
+        if (ctx->drop_ell_cols != n_old || ctx->opt_host_build || n_new < 1)
+            return fail(ctx, -9, "the reference arrays of this FSP are not resident on the device: upload the compacted generator");
+        HIP_TRY(hipSetDevice(ctx->device));
+        auto t0 = std::chrono::steady_clock::now();
+        const int bw = ctx->drop_bw, ld = ctx->ell_ld;
+        const uint8_t *keep = ctx->d_dropflag.p + ctx->d_dropflag.cap / 2;      // (made by kfsp_drop_compact, caller's order)
+        const bool coords = ctx->coords_n == n_old;
+        const int cld = ctx->coords_ld, cns = ctx->coords_ns;
+        const bool want_order = ctx->opt_state_order && n_new >= ctx->opt_state_order_min && ctx->prod_count >= ctx->opt_state_order_products;
+        if (want_order && !coords)     // the upload path would order this FSP, and the coordinates are not here: let it
+            return fail(ctx, -9, "the state coordinates of this FSP are not resident on the device: upload the compacted generator");
+        ctx->drop_ell_cols = 0;
+        if (int rc = kfsp::compact_resident_ell(ctx, n_old, bw, ld, keep, n_new, coords, cld)) return rc;
+        ctx->ell_cols = n_new;
+        // the state order of the compacted FSP: the rule of kfsp_set_state_coords, on the coordinates that stayed here
+        ctx->perm_pending_n = 0;
+        ctx->coords_n = 0;
+        bool ordered = false;
+        if (coords && want_order)
+            if (int rc = kfsp::state_order_from_resident(ctx, (int32_t)n_new, cns, cld, &ordered)) return rc;
+        if (coords && !ordered) {                              // (the coordinates are resident either way)
+            ctx->coords_n = n_new;
+            ctx->coords_ld = cld;
+            ctx->coords_ns = cns;
+        }
+        ctx->use_box = false;
+        ctx->box_lds_bytes = 0;
+        if (int rc = resize(ctx, n_new)) return rc;
+        ctx->perm_on = ordered;
+        ctx->prod_last = ctx->prod_count;
+        ctx->prod_count = 0;
+        int rc = kfsp::build_from_resident_ell(ctx, (int32_t)n_new, bw, ld);
+        if (!rc) rc = setup_exchange(ctx);
+        if (!rc) rc = adopt_pending_vector(ctx);
+        ctx->t_ms[KFSP_T_UPLOAD] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return rc;
+    });
 }
 
 static int reduce_w(kfsp_ctx *ctx, int squared, double *out)

@@ -408,6 +408,19 @@ int build_from_ell_device(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, cons
         HIP_TRY_B(hipMemcpyAsync(ctx->d_ell_diag.p + keep, diag + keep, (size_t)(n - keep) * sizeof(double), hipMemcpyHostToDevice, st));
     ctx->ell_cols = n;
     ctx->ell_ld = ld;
+    ctx->ell_bw = bw;
+    return build_from_resident_ell(ctx, n, bw, ld);
+}
+
+// the gather form from the reference arrays that are ALREADY on the device (d_ell_adj / d_ell_off / d_ell_diag, n columns
+// of leading dimension ld): what build_from_ell_device does after its upload, and all kfsp_drop_rebuild needs
+int build_from_resident_ell(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld)
+{
+    hipStream_t st = ctx->stream;
+    const int64_t row0 = ctx->row0, nloc = ctx->nloc;
+    const int64_t nchunks = (nloc + kChunk - 1) / kChunk;
+    const int64_t nact = nchunks * kChunk;
+    const size_t nent = (size_t)n * (size_t)ld;
     const int32_t *ell_adj = ctx->d_ell_adj.p;
     const double *ell_off = ctx->d_ell_off.p, *ell_diag = ctx->d_ell_diag.p;
     if (ctx->perm_on) {
@@ -728,6 +741,63 @@ int build_sell_code(kfsp_ctx *ctx)
     return 0;
 }
 
+// DROP_STATES on the device's own copy of the reference arrays (StateSpace.f90:500-546): the kept states move up in list order
+// (scan[i] = kept states before i), links are renumbered through the same scan, a dropped target becomes 0 (:540-545), -1 stays.
+__global__ __launch_bounds__(kBlock) void k_ell_compact(int64_t n, int bw, int ld, int ns, int lds, const uint8_t *__restrict__ keep,
+                                                        const int32_t *__restrict__ scan, const int32_t *__restrict__ adj,
+                                                        const double *__restrict__ off, const double *__restrict__ diag,
+                                                        const int32_t *__restrict__ coords, int32_t *__restrict__ adj2,
+                                                        double *__restrict__ off2, double *__restrict__ diag2, int32_t *__restrict__ coords2)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n || !keep[i]) return;
+    const int64_t q = scan[i];
+    for (int k = 0; k < ld; ++k) {
+        int32_t a = adj[i * ld + k];
+        if (k < bw && a > 0) a = keep[a - 1] ? scan[a - 1] + 1 : 0;
+        adj2[q * ld + k] = a;
+        off2[q * ld + k] = off[i * ld + k];
+    }
+    diag2[q] = diag[i];
+    if (coords)
+        for (int s = 0; s < lds; ++s) coords2[q * lds + s] = coords[i * lds + s];
+}
+
+__global__ __launch_bounds__(kBlock) void k_u8_to_i32(int64_t n, const uint8_t *__restrict__ a, int32_t *__restrict__ b)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) b[i] = a[i] ? 1 : 0;
+}
+
+// keep: one byte per state of the resident arrays (caller's order); with_coords: d_coords holds their coordinates (ns used,
+// leading dimension lds).  Afterwards d_ell_* (and d_coords) hold the n_keep kept columns, renumbered.
+int compact_resident_ell(kfsp_ctx *ctx, int64_t n, int bw, int ld, const uint8_t *keep, int64_t n_keep, bool with_coords, int lds)
+{
+    hipStream_t st = ctx->stream;
+    const size_t nent2 = (size_t)n_keep * (size_t)ld;
+    HIP_TRY_B(ctx->d_ell_adj2.reserve(std::max<size_t>(nent2, 64), false));
+    HIP_TRY_B(ctx->d_ell_off2.reserve(std::max<size_t>(nent2, 64), false));
+    HIP_TRY_B(ctx->d_ell_diag2.reserve(std::max<size_t>((size_t)n_keep, 64), false));
+    if (with_coords) HIP_TRY_B(ctx->d_coords2.reserve((size_t)n_keep * (size_t)lds + 128, false));
+    HIP_TRY_B(ctx->d_sortidx.reserve(2 * (size_t)n + 64, false));
+    int32_t *flag32 = ctx->d_sortidx.p, *scan = ctx->d_sortidx.p + n;
+    const int grid = (int)((n + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_u8_to_i32, dim3(grid), dim3(kBlock), 0, st, n, keep, flag32);
+    size_t tmp_bytes = 0;
+    HIP_TRY_B(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, flag32, scan, (int)n, st));
+    HIP_TRY_B(ctx->d_sorttmp.reserve(tmp_bytes + 256, false));
+    HIP_TRY_B(hipcub::DeviceScan::ExclusiveSum(ctx->d_sorttmp.p, tmp_bytes, flag32, scan, (int)n, st));
+    hipLaunchKernelGGL(k_ell_compact, dim3(grid), dim3(kBlock), 0, st, n, bw, ld, lds, lds, keep, scan, ctx->d_ell_adj.p,
+                       ctx->d_ell_off.p, ctx->d_ell_diag.p, with_coords ? ctx->d_coords.p : (const int32_t *)nullptr, ctx->d_ell_adj2.p,
+                       ctx->d_ell_off2.p, ctx->d_ell_diag2.p, with_coords ? ctx->d_coords2.p : (int32_t *)nullptr);
+    HIP_TRY_B(hipStreamSynchronize(st));
+    std::swap(ctx->d_ell_adj, ctx->d_ell_adj2);
+    std::swap(ctx->d_ell_off, ctx->d_ell_off2);
+    std::swap(ctx->d_ell_diag, ctx->d_ell_diag2);
+    if (with_coords) std::swap(ctx->d_coords, ctx->d_coords2);
+    return 0;
+}
+
 // A box generator (kfsp_set_matrix_box) written out as stored diagonals, on the device: row r of the block
 // (global state g = row0 + r) gets, for the reaction at sorted position p, val[p * ld + r] = a_p(x - nu_p) when the
 // source state x - nu_p lies in the box (else 0) - the product of the factor tables in the order the kernel of
@@ -813,6 +883,17 @@ int state_order_from_coords(kfsp_ctx *ctx, int32_t n, int32_t ns, int32_t ld, co
     const size_t nent = (size_t)n * (size_t)ld;
     HIP_TRY_B(ctx->d_coords.reserve(nent + 64, false));
     HIP_TRY_B(hipMemcpyAsync(ctx->d_coords.p, state, nent * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    return state_order_from_resident(ctx, n, ns, ld, ok);
+}
+
+// the same from coordinates that are already in d_coords (n x ld, room for 64 more entries behind them)
+int state_order_from_resident(kfsp_ctx *ctx, int32_t n, int32_t ns, int32_t ld, bool *ok)
+{
+    *ok = false;
+    ctx->coords_n = 0;
+    if (ns > 16) return 0;
+    hipStream_t st = ctx->stream;
+    const size_t nent = (size_t)n * (size_t)ld;
     int mm[32];
     for (int k = 0; k < ns; ++k) {
         mm[2 * k] = INT_MAX;
@@ -827,6 +908,7 @@ int state_order_from_coords(kfsp_ctx *ctx, int32_t n, int32_t ns, int32_t ld, co
     HIP_TRY_B(hipStreamSynchronize(st));
     ctx->coords_n = n;                                     // (the coordinates stay resident: kfsp_ssa_streams may use them)
     ctx->coords_ld = ld;
+    ctx->coords_ns = ns;
     KeyLayout L;
     L.ns = ns;
     int bits = 0;

@@ -205,14 +205,14 @@ struct kfsp_ctx {
     DevBuf<int32_t> d_ell_adj, d_cnt, d_ticket;
     // columns of OFFDIAG / DIAG resident from the last reference-layout upload (0: none that may be reused)
     int64_t ell_cols = 0;
-    int32_t ell_ld = 0;
+    int32_t ell_ld = 0, ell_bw = 0;
     DevBuf<double> d_ell_off, d_ell_diag;
     DevBuf<int> d_slot;
     DevBuf<char> d_scan;
     // Internal state order (kfsp_set_state_coords): the device keeps generator and
     // vectors in lexicographic order of the state coordinates, the host sees its
     // own order.  perm[new] = old, iperm[old] = new (0-based).
-    DevBuf<int32_t> d_perm, d_iperm, d_coords, d_ell_adj2;
+    DevBuf<int32_t> d_perm, d_iperm, d_coords, d_coords2, d_ell_adj2;
     DevBuf<double> d_ell_off2, d_ell_diag2, d_pstage;
     DevBuf<unsigned long long> d_keys;     // 2 n sort keys (in, out)
     DevBuf<int32_t> d_sortidx;             // n identity indices (sort values in)
@@ -226,6 +226,8 @@ struct kfsp_ctx {
     DevBuf<uint8_t> d_dropflag;
     DevBuf<unsigned long long> d_dropcnt;
     bool drop_planned = false;
+    int64_t drop_ell_cols = 0;         // columns of the reference arrays resident when kfsp_drop_compact ran (kfsp_drop_rebuild)
+    int32_t drop_bw = 0;               // reaction slots of that generator
     int64_t drop_n = 0, drop_flagged = 0;
     // the compacted w (caller's order) waits in d_tmp for the generator of the compacted FSP
     bool w_pending = false;
@@ -285,7 +287,7 @@ struct kfsp_ctx {
     int64_t opt_mmax = kfsp::kMMax;        // largest Krylov dimension the basis is allocated for (m_max + 3 columns)
     int64_t opt_ssa_resident = 0;          // 1: the caller vouches that the arrays given to kfsp_ssa_streams are the ones last uploaded
     int64_t coords_n = 0;                  // states whose coordinates sit in d_coords (kfsp_set_state_coords), 0: none
-    int32_t coords_ld = 0;
+    int32_t coords_ld = 0, coords_ns = 0;
     int64_t opt_sell_code = -1;            // dictionary-coded SELL columns: -1 auto (under the internal state order), 0 never, 1 always try
     int64_t opt_box_store = 0;            // 1: kfsp_set_matrix_box writes the generator out as stored diagonals on the device (banded form)
     int64_t opt_state_order = 1;          // 1: use kfsp_set_state_coords for large, long-lived generators (0: never)
@@ -326,6 +328,7 @@ int group_get_basis(kfsp_ctx *h, int j, int64_t n, double *v);
 int group_spmv_bench(kfsp_ctx *h, int reps, int variant, float *ms_total);
 int group_get_timers(kfsp_ctx *h, double *ms, int reset);
 int group_layout_info(const kfsp_ctx *h, int64_t *v);
+int group_drop_rebuild(kfsp_ctx *h);
 int group_set_propensity_program(kfsp_ctx *h, int32_t ns, int32_t nr, int32_t np, const double *params, const int32_t *code_off,
                                  const int32_t *code, const int32_t *imm_off, const double *imm, const int32_t *tab_species,
                                  int32_t tab_len, const double *tab);
@@ -336,6 +339,9 @@ int build_from_ell_device(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, cons
                           const double *offdiag, const double *diag, int64_t keep = 0);
 // after a banded generator was stored: find the empty (diagonal, 128-row group) segments and
 // switch the masked kernel variant on if they are worth skipping
+int build_from_resident_ell(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld);
+int state_order_from_resident(kfsp_ctx *ctx, int32_t n, int32_t ns, int32_t ld, bool *ok);
+int compact_resident_ell(kfsp_ctx *ctx, int64_t n, int bw, int ld, const uint8_t *keep, int64_t n_keep, bool with_coords, int lds);
 int build_dia_mask(kfsp_ctx *ctx);
 // after a SELL image was stored (d_off, d_col, d_val): try the dictionary-coded column form
 int build_sell_code(kfsp_ctx *ctx);

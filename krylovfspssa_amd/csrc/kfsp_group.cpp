@@ -377,6 +377,14 @@ int group_drop_compact(kfsp_ctx *h, int64_t *n_new)
     return 0;
 }
 
+int group_drop_rebuild(kfsp_ctx *h)
+{
+    int rc = gall(h, [&](kfsp_ctx *c, int) { return kfsp_drop_rebuild(c); });
+    int64_t n = 0;
+    if (!rc) rc = kfsp_num_states(h->group->sub[0], &n);
+    return after_matrix(h, rc, n);
+}
+
 int group_reduce_w(kfsp_ctx *h, int squared, double *out)
 {
     Group *g = h->group;

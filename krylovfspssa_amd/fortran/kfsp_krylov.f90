@@ -55,6 +55,7 @@ MODULE KRYLOVSOLVER
   ! the model's propensity program is resident on the device (kfsp_set_propensity_program): one-step sweeps on the
   ! device return the complete columns of the states they append.  KFSP_DEVICE_PROPENSITY=0 keeps them on the host.
   LOGICAL, SAVE, PRIVATE :: PROGRAM_READY = .FALSE., PROGRAM_WANTED = .TRUE.
+  LOGICAL, SAVE, PRIVATE :: DEVICE_REBUILD = .TRUE.   ! KFSP_DEVICE_REBUILD=0: the compacted generator is uploaded after every drop
   ! wall seconds spent in the host state-space code of the current solve:
   ! (1) DROP_STATES decision + compaction, (2) SSA_EXTENDER, (3) ONESTEP_EXTENDER,
   ! (4) uploads of the changed FSP
@@ -241,6 +242,8 @@ CONTAINS
     ENDIF
     CALL GET_ENVIRONMENT_VARIABLE('KFSP_HOST_DROP', ENV, L, STAT)
     HOST_DROP = (STAT == 0 .AND. L > 0 .AND. ENV(1:1) /= '0')
+    CALL GET_ENVIRONMENT_VARIABLE('KFSP_DEVICE_REBUILD', ENV, L, STAT)
+    IF (STAT == 0 .AND. L > 0) DEVICE_REBUILD = ENV(1:1) /= '0'
     CALL GET_ENVIRONMENT_VARIABLE('KFSP_DEVICE_PROPENSITY', ENV, L, STAT)
     IF (STAT == 0 .AND. L > 0) PROGRAM_WANTED = ENV(1:1) /= '0' 
     ! any other library option (kfsp_set_option, include/kfsp.h): KFSP_OPTIONS="name=value,name=value"
@@ -455,7 +458,15 @@ CONTAINS
           RETURN
        ENDIF
        T0 = WALL()
-       CALL UPLOAD_FSP(CUR_FSP, CUR_MODEL, .FALSE.)
+       ! the device renumbers its own copy of the generator (kfsp_drop_rebuild): nothing travels; only when that
+       ! copy is not there (-9) does the compacted FSP go up again
+       RC = -9
+       IF (DEVICE_REBUILD) RC = KFSP_DROP_REBUILD(CTX)
+       IF (RC == -9) THEN
+          CALL UPLOAD_FSP(CUR_FSP, CUR_MODEL, .FALSE.)
+       ELSE
+          CALL CHECK(RC, 'kfsp_drop_rebuild')
+       ENDIF
        HOST_SEC(4) = HOST_SEC(4) + (WALL() - T0)
        N_NEW = CUR_FSP%SIZE
        RC = 0

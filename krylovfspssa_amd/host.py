@@ -70,6 +70,7 @@ def load_library():
         "kfsp_drop_plan": [vp, dbl, C.POINTER(dbl), C.POINTER(i64), C.POINTER(i64)],
         "kfsp_drop_flags": [vp, i64, vp],
         "kfsp_drop_compact": [vp, C.POINTER(i64)],
+        "kfsp_drop_rebuild": [vp],
         "kfsp_dgexpv": [vp, dbl, dbl, dbl, C.c_int, vp, vp],
         "kfsp_set_vector": [vp, i64, vp],
         "kfsp_get_vector": [vp, i64, vp],
@@ -394,6 +395,14 @@ class KfspContext:
         n = C.c_int64(0)
         self._chk(self._lib.kfsp_drop_compact(self._h, C.byref(n)), "kfsp_drop_compact")
         return n.value
+
+    def drop_rebuild(self):
+        """the generator of the compacted FSP from the device's own arrays (after drop_compact)"""
+        self._chk(self._lib.kfsp_drop_rebuild(self._h), "kfsp_drop_rebuild")
+        n = C.c_int64(0)
+        self._lib.kfsp_num_states(self._h, C.byref(n))
+        self.n = n.value
+        self.row0, self.nloc = self.row_block(self.n)
 
     def matrix_bytes(self, force_sell=False):
         """force_sell: False / True (the SELL image) / 3 (the SELL image read with plain columns)"""

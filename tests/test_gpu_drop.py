@@ -50,10 +50,11 @@ def test_find_droptol_thresholds(golden_dir):
 DROP_CASES = [("toggle", 20, 1e-6), ("goutsias", 16, 1e-12), ("repressilator", 10, 1e-4)]
 
 
+@pytest.mark.parametrize("rebuild", [False, True])
 @pytest.mark.parametrize("ranks", [1, 2, 3])
 @pytest.mark.parametrize("state_order", [0, 1])
 @pytest.mark.parametrize("name,k,dsum", DROP_CASES)
-def test_drop_decision_and_compaction_match_the_reference(golden_dir, name, k, dsum, state_order, ranks):
+def test_drop_decision_and_compaction_match_the_reference(golden_dir, name, k, dsum, state_order, ranks, rebuild):
     """The FSP of `k` one-step sweeps as the reference assembles it (fixture assembly_*), the
     decaying vector of oracle/ref_dump.f90 DO_DROP, DROP_STATES on the device: the states kept and
     the compacted vector are what the reference leaves behind (fixture drop_*: its list starts
@@ -61,7 +62,10 @@ def test_drop_decision_and_compaction_match_the_reference(golden_dir, name, k, d
     reference's counting rule, and after kfsp_set_matrix_ell of the compacted FSP the resident
     vector IS the compacted one - also with the device keeping its own state order, and also with the FSP
     row-partitioned over 2 and 3 ranks (a group context over a loop-back group: per-rank threshold sums + one
-    all-reduce, flags per block all-gathered, the compacted vector re-partitioned)."""
+    all-reduce, flags per block all-gathered, the compacted vector re-partitioned).  rebuild: the generator of the compacted
+    FSP comes from the device's OWN copy of the reference arrays (kfsp_drop_rebuild: columns moved up, links renumbered
+    through the keep-prefix-sum, dropped targets -> 0, StateSpace.f90:540-545) instead of being uploaded again - its products
+    must be the bits of the uploaded one."""
     from krylovfspssa_amd import KfspContext
     from oracle import make_golden as MG
     a = np.load(os.path.join(golden_dir, f"assembly_{name}_k{k}.npz"))
@@ -109,11 +113,22 @@ def test_drop_decision_and_compaction_match_the_reference(golden_dir, name, k, d
         adj2 = adj[keep].copy()
         pos = adj2 > 0
         adj2[pos] = newidx[adj2[pos]]
-        if state_order:
-            c.set_state_coords(state[keep])
-        c.set_matrix_ell(adj2, off[keep], diag[keep])
+        if rebuild:
+            c.drop_rebuild()
+            assert c.state_order_active() == bool(state_order)
+        else:
+            if state_order:
+                c.set_state_coords(state[keep])
+            c.set_matrix_ell(adj2, off[keep], diag[keep])
         assert c.n == nk
         assert np.array_equal(c.get_vector(), w[keep])
+        if rebuild:
+            # the rebuilt generator IS the generator of the compacted arrays: same products as a fresh upload of them
+            xk = np.random.default_rng(5).random(nk)
+            y = c.spmv(xk)
+            with KfspContext(0) as fresh:
+                fresh.set_matrix_ell(adj2, off[keep], diag[keep])
+                assert np.array_equal(y, fresh.spmv(xk))
         # and the solver goes on from it
         beta = c.begin_step()
         assert beta == pytest.approx(np.sqrt((w[keep] ** 2).sum()), rel=1e-14)
