@@ -480,12 +480,9 @@ typedef double __attribute__((ext_vector_type(2))) box_pair_t;
 // propensities that depend on this species; unsigned valid - bit e: entry e's source coordinate of this
 // species is inside the box; unsigned pad }.
 
-// xp1 / xm1 (species 0 only): the pairs (x[g+1], x[g+2]) and (x[g-1], x[g]) of the lane's rows g, g+1, assembled from
-// the diagonal pairs of the neighbouring lanes (rows_box1) - an entry one row away needs no gather of its own
 template <int S, int NS, int PER>
 __device__ __forceinline__ void box_species(const BoxRegs<NS, PER> &R, int xa, int xb, unsigned va, unsigned vb,
-                                            global_bytes_t xw, unsigned voff, double &acca, double &accb,
-                                            box_pair_t xp1 = box_pair_t{0.0, 0.0}, box_pair_t xm1 = box_pair_t{0.0, 0.0})
+                                            global_bytes_t xw, unsigned voff, double &acca, double &accb)
 {
     const unsigned lds0 = (unsigned)(size_t)(lds_bytes_t)box_lds;                  // LDS address of the image = of its 0.0
 #pragma unroll
@@ -496,16 +493,9 @@ __device__ __forceinline__ void box_species(const BoxRegs<NS, PER> &R, int xa, i
         const unsigned atb = lds0 + (unsigned)(8 * xb + R.koff8[S][j]);
         const double a1a = *(const __attribute__((address_space(3))) double *)(size_t)((ma & ata) | (~ma & lds0));   // ... or 0
         const double a1b = *(const __attribute__((address_space(3))) double *)(size_t)((mb & atb) | (~mb & lds0));
-        box_pair_t xv;
-        if (S == 0 && R.delta8[S][j] == 8) {                                       // (uniform: the descriptor sits in SGPRs)
-            xv = xp1;
-        } else if (S == 0 && R.delta8[S][j] == -8) {
-            xv = xm1;
-        } else {
-            const unsigned vsrc = voff + (unsigned)R.delta8[S][j];                 // (the same in every trip of the lane)
-            const unsigned at = (unsigned)__builtin_amdgcn_bitop3_b32(ma | mb, (int)vsrc, (int)voff, 0xCA);   // either ? vsrc : voff
-            xv = *(const __attribute__((address_space(1), aligned(8))) box_pair_t *)(xw + at);
-        }
+        const unsigned vsrc = voff + (unsigned)R.delta8[S][j];                     // (the same in every trip of the lane)
+        const unsigned at = (unsigned)__builtin_amdgcn_bitop3_b32(ma | mb, (int)vsrc, (int)voff, 0xCA);   // either ? vsrc : voff
+        const box_pair_t xv = *(const __attribute__((address_space(1), aligned(8))) box_pair_t *)(xw + at);
         acca += a1a * xv.x;
         accb += a1b * xv.y;
     }
@@ -595,31 +585,8 @@ __device__ __forceinline__ d2 rows_box1(const BoxRegs<NS, PER> &R, const double 
     box_df<NS, PER>(R, b0, b1, b2, b3, b4, b5, dsb, vb);
     if (!two) vb = 0u;
     const box_pair_t xd = *(const __attribute__((address_space(1), aligned(8))) box_pair_t *)(xw + voff);
-    // Entries one row away (species 1 changes by +-1: every model has them) need no gather: a lane's rows are g, g+1,
-    // so (x[g+1], x[g+2]) = (its own x[g+1], the next lane's x[g]) and (x[g-1], x[g]) = (the previous lane's x[g+1], its
-    // own x[g]) - wavefront shifts of the diagonal pair in the register file (DPP wave_shl / wave_shr) - and only the two
-    // end lanes fetch one element each (one load instruction with two active lanes).  A CU issues vector-memory
-    // instructions at a fixed rate whatever their width or lane count (4.1b): two 64-lane gathers fewer per 128 rows.
-    box_pair_t xp1 = {0.0, 0.0}, xm1 = {0.0, 0.0};
-    bool near1 = false;
-#pragma unroll
-    for (int j = 0; j < PER; ++j) near1 = near1 || R.delta8[0][j] == 8 || R.delta8[0][j] == -8;
-    if (near1) {
-        // lanes whose neighbour lane has no rows of this trip fetch the element themselves: lane 0 (x[g-1]), lane 63 and the
-        // last lane with rows (x[g+2]: beyond the block it is a halo row of the next rank, or a guard word at the end of x)
-        const bool nd = lane == 0, nu = lane == 63 || r0 + 2 >= nloc;
-        double xe = 0.0, xe2 = 0.0;
-        if (nd || nu) xe = *(const __attribute__((address_space(1))) double *)(xw + voff + (nd ? -8 : 16));
-        if (nd && nu) xe2 = *(const __attribute__((address_space(1))) double *)(xw + voff + 16);
-        const double up = dpp_get<0x130, 0xf, 0xf>(xd.x);       // wave_shl:1 - the next lane's x[g]
-        const double dn = dpp_get<0x138, 0xf, 0xf>(xd.y);       // wave_shr:1 - the previous lane's x[g+1]
-        xp1.x = xd.y;
-        xp1.y = nu ? (nd ? xe2 : xe) : up;
-        xm1.x = nd ? xe : dn;
-        xm1.y = xd.x;
-    }
     double acca = 0.0, accb = 0.0;
-    box_species<0, NS, PER>(R, c0, b0, va, vb, xw, voff, acca, accb, xp1, xm1);
+    box_species<0, NS, PER>(R, c0, b0, va, vb, xw, voff, acca, accb);
     if (NS > 1) box_species<(NS > 1 ? 1 : 0), NS, PER>(R, c1, b1, va, vb, xw, voff, acca, accb);
     if (NS > 2) box_species<(NS > 2 ? 2 : 0), NS, PER>(R, c2, b2, va, vb, xw, voff, acca, accb);
     if (NS > 3) box_species<(NS > 3 ? 3 : 0), NS, PER>(R, c3, b3, va, vb, xw, voff, acca, accb);
