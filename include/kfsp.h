@@ -120,6 +120,10 @@ int kfsp_update_matrix_ell(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, con
  * caller's order" passes through one all-gather of the whole vector (kfsp_set_vector / kfsp_get_vector /
  * kfsp_spmv / kfsp_get_basis; a few times per FSP change, never per product). */
 int kfsp_set_state_coords(kfsp_ctx *ctx, int32_t n, int32_t ns, int32_t ld, const int32_t *state);
+/* The same after the FSP GREW: the coordinates of the first n_unchanged states - a leading part of what the last
+ * kfsp_set_state_coords / kfsp_update_state_coords / kfsp_drop_rebuild left on the device - are not sent again (a listed
+ * state never changes; `state` is still the whole array).  n_unchanged is treated as 0 when those are not resident. */
+int kfsp_update_state_coords(kfsp_ctx *ctx, int32_t n, int32_t ns, int32_t ld, const int32_t *state, int32_t n_unchanged);
 /* 1 if the generator last set is held in the internal state order */
 int kfsp_state_order_active(const kfsp_ctx *ctx, int *active);
 /* Synthetic / pre-transposed input: gather rows [row0, row0+nrows) of an

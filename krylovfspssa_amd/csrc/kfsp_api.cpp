@@ -1295,7 +1295,7 @@ int kfsp_set_matrix_box(kfsp_ctx *ctx, int32_t ns, const int32_t *dims, int32_t 
     });
 }
 
-int kfsp_set_state_coords(kfsp_ctx *ctx, int32_t n, int32_t ns, int32_t ld, const int32_t *state)
+static int set_state_coords_impl(kfsp_ctx *ctx, int32_t n, int32_t ns, int32_t ld, const int32_t *state, int64_t keep)
 {
     return no_throw(ctx, [&]() -> int {
         if (!ctx) return -1;
@@ -1303,9 +1303,10 @@ int kfsp_set_state_coords(kfsp_ctx *ctx, int32_t n, int32_t ns, int32_t ld, cons
         if (ns < 1) return fail(ctx, -3, "ns < 1");
         if (ld < ns) return fail(ctx, -4, "ld < ns");
         if (!state) return fail(ctx, -5, "null state");
-        if (ctx->group) return kfsp::group_set_state_coords(ctx, n, ns, ld, state);
+        if (ctx->group) return kfsp::group_update_state_coords(ctx, n, ns, ld, state, (int32_t)keep);
         ctx->perm_pending_n = 0;
-        ctx->coords_n = 0;                                  // (set again below if the coordinates are uploaded)
+        const int64_t had = ctx->coords_n;                   // (coords_n is set again below if the coordinates are (partly) uploaded)
+        ctx->coords_n = 0;
         if (!ctx->opt_state_order || n < ctx->opt_state_order_min) return 0;
         // Sorting, relabelling and the extra upload cost about as much as 20 products (at 10^6 states)
         // save: worth it only while generators live that long.  The generator being
@@ -1314,12 +1315,24 @@ int kfsp_set_state_coords(kfsp_ctx *ctx, int32_t n, int32_t ns, int32_t ld, cons
         HIP_TRY(hipSetDevice(ctx->device));
         auto t0 = std::chrono::steady_clock::now();
         bool ok = false;
-        const int rc = kfsp::state_order_from_coords(ctx, n, ns, ld, state, &ok);
+        ctx->coords_n = had;
+        const int rc = kfsp::state_order_from_coords(ctx, n, ns, ld, state, &ok, keep);
         ctx->t_ms[KFSP_T_UPLOAD] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         if (rc) return rc;
         if (ok) ctx->perm_pending_n = n;
         return 0;
     });
+}
+
+int kfsp_set_state_coords(kfsp_ctx *ctx, int32_t n, int32_t ns, int32_t ld, const int32_t *state)
+{
+    return set_state_coords_impl(ctx, n, ns, ld, state, 0);
+}
+
+int kfsp_update_state_coords(kfsp_ctx *ctx, int32_t n, int32_t ns, int32_t ld, const int32_t *state, int32_t n_unchanged)
+{
+    if (n_unchanged < 0 || n_unchanged > n) return ctx ? fail(ctx, -6, "0 <= n_unchanged <= n") : -1;
+    return set_state_coords_impl(ctx, n, ns, ld, state, n_unchanged);
 }
 
 int kfsp_state_order_active(const kfsp_ctx *ctx, int *active)

@@ -387,9 +387,6 @@ int build_from_ell_device(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, cons
         return -3;
     }
     hipStream_t st = ctx->stream;
-    const int64_t row0 = ctx->row0, nloc = ctx->nloc;
-    const int64_t nchunks = (nloc + kChunk - 1) / kChunk;
-    const int64_t nact = nchunks * kChunk;
     const size_t nent = (size_t)n * (size_t)ld;
 
     // the reference arrays, verbatim.  Propensities of a listed state never change while it stays listed
@@ -874,15 +871,18 @@ void launch_gather_index(int64_t n, const int32_t *index, const double *src, dou
                            dst);
 }
 
-int state_order_from_coords(kfsp_ctx *ctx, int32_t n, int32_t ns, int32_t ld, const int32_t *state, bool *ok)
+int state_order_from_coords(kfsp_ctx *ctx, int32_t n, int32_t ns, int32_t ld, const int32_t *state, bool *ok, int64_t keep)
 {
     *ok = false;
+    // keep: leading states whose coordinates are resident and unchanged (the FSP only grew): only the rest travels
+    if (keep > ctx->coords_n || keep > n || ld != ctx->coords_ld || ns != ctx->coords_ns) keep = 0;
     ctx->coords_n = 0;
     if (ns > 16) return 0;                                 // more species than the key layout holds
     hipStream_t st = ctx->stream;
-    const size_t nent = (size_t)n * (size_t)ld;
-    HIP_TRY_B(ctx->d_coords.reserve(nent + 64, false));
-    HIP_TRY_B(hipMemcpyAsync(ctx->d_coords.p, state, nent * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    const size_t nent = (size_t)n * (size_t)ld, k0 = (size_t)keep * (size_t)ld;
+    HIP_TRY_B(ctx->d_coords.reserve_keep(nent + 64, k0, st));
+    if (nent > k0)
+        HIP_TRY_B(hipMemcpyAsync(ctx->d_coords.p + k0, state + k0, (nent - k0) * sizeof(int32_t), hipMemcpyHostToDevice, st));
     return state_order_from_resident(ctx, n, ns, ld, ok);
 }
 

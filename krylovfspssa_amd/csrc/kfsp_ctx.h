@@ -329,6 +329,7 @@ int group_spmv_bench(kfsp_ctx *h, int reps, int variant, float *ms_total);
 int group_get_timers(kfsp_ctx *h, double *ms, int reset);
 int group_layout_info(const kfsp_ctx *h, int64_t *v);
 int group_drop_rebuild(kfsp_ctx *h);
+int group_update_state_coords(kfsp_ctx *h, int32_t n, int32_t ns, int32_t ld, const int32_t *state, int32_t n_unchanged);
 int group_set_propensity_program(kfsp_ctx *h, int32_t ns, int32_t nr, int32_t np, const double *params, const int32_t *code_off,
                                  const int32_t *code, const int32_t *imm_off, const double *imm, const int32_t *tab_species,
                                  int32_t tab_len, const double *tab);
@@ -349,7 +350,7 @@ int build_sell_code(kfsp_ctx *ctx);
 int box_materialize(kfsp_ctx *ctx);
 // lexicographic order of n states given as ns coordinates each (host array, leading
 // dimension ld): fills d_perm / d_iperm; *ok = false when the packed key needs > 64 bits
-int state_order_from_coords(kfsp_ctx *ctx, int32_t n, int32_t ns, int32_t ld, const int32_t *state, bool *ok);
+int state_order_from_coords(kfsp_ctx *ctx, int32_t n, int32_t ns, int32_t ld, const int32_t *state, bool *ok, int64_t keep = 0);
 // dst[i'] = src[perm[i']] (host order -> device order) and dst[i] = src[iperm[i]] (back)
 void launch_gather_index(int64_t n, const int32_t *index, const double *src, double *dst, hipStream_t st);
 // DROP_STATES pieces (kfsp_drop.hip)

@@ -230,6 +230,11 @@ int group_set_state_coords(kfsp_ctx *h, int32_t n, int32_t ns, int32_t ld, const
     return gall(h, [&](kfsp_ctx *c, int) { return kfsp_set_state_coords(c, n, ns, ld, state); });
 }
 
+int group_update_state_coords(kfsp_ctx *h, int32_t n, int32_t ns, int32_t ld, const int32_t *state, int32_t n_unchanged)
+{
+    return gall(h, [&](kfsp_ctx *c, int) { return kfsp_update_state_coords(c, n, ns, ld, state, n_unchanged); });
+}
+
 int group_state_order_active(const kfsp_ctx *h, int *active) { return kfsp_state_order_active(h->group->sub[0], active); }
 
 int group_matrix_info(const kfsp_ctx *h, int64_t *nrows, int64_t *slots, int64_t *nnz)

@@ -406,9 +406,10 @@ CONTAINS
     IF (PRESENT(N_UNCHANGED)) KEEP = N_UNCHANGED
     ! the species counts let the device keep its own, locality-preserving state
     ! order if that was asked for (nothing changes on this side of the boundary)
-    RC = KFSP_SET_STATE_COORDS(CTX, INT(FSP%SIZE, C_INT32_T), INT(MODEL%NSPECIES, C_INT32_T), &
-         INT(SIZE(FSP%STATE, 1), C_INT32_T), FSP%STATE)
-    CALL CHECK(RC, 'kfsp_set_state_coords')
+    ! (after a growth step the coordinates of the first KEEP states are on the device already, like their propensity columns)
+    RC = KFSP_UPDATE_STATE_COORDS(CTX, INT(FSP%SIZE, C_INT32_T), INT(MODEL%NSPECIES, C_INT32_T), &
+         INT(SIZE(FSP%STATE, 1), C_INT32_T), FSP%STATE, INT(KEEP, C_INT32_T))
+    CALL CHECK(RC, 'kfsp_update_state_coords')
     RC = KFSP_UPDATE_MATRIX_ELL(CTX, INT(FSP%SIZE, C_INT32_T), INT(MODEL%NREACTIONS, C_INT32_T), &
          INT(SIZE(FSP%MATRIX%ADJ, 1), C_INT32_T), FSP%MATRIX%ADJ, FSP%MATRIX%OFFDIAG, FSP%MATRIX%DIAG, INT(KEEP, C_INT32_T))
     CALL CHECK(RC, 'kfsp_update_matrix_ell')

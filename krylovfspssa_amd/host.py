@@ -55,6 +55,7 @@ def load_library():
         "kfsp_update_matrix_ell": [vp, i32, i32, i32, vp, vp, vp, i32],
         "kfsp_set_matrix_csr": [vp, i64, i64, i64, vp, vp, vp],
         "kfsp_set_state_coords": [vp, i32, i32, i32, vp],
+        "kfsp_update_state_coords": [vp, i32, i32, i32, vp, i32],
         "kfsp_set_matrix_box": [vp, i32, vp, i32, vp, vp, vp, vp],
         "kfsp_state_order_active": [vp, C.POINTER(C.c_int)],
         "kfsp_matrix_info": [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)],
@@ -294,6 +295,12 @@ class KfspContext:
         state = np.ascontiguousarray(state, dtype=np.int32)
         n, ns = state.shape
         self._chk(self._lib.kfsp_set_state_coords(self._h, n, ns, ns, _p(state)), "kfsp_set_state_coords")
+
+    def update_state_coords(self, state, n_unchanged):
+        """set_state_coords after the FSP grew: only the coordinates behind the first n_unchanged states travel"""
+        state = np.ascontiguousarray(state, dtype=np.int32)
+        n, ns = state.shape
+        self._chk(self._lib.kfsp_update_state_coords(self._h, n, ns, ns, _p(state), int(n_unchanged)), "kfsp_update_state_coords")
 
     def state_order_active(self):
         a = C.c_int(0)

@@ -172,3 +172,32 @@ def test_sell_sigma_windows_keep_the_product_bit_identical(golden_dir):
     assert np.array_equal(out[0][0], out[128][0]) and np.array_equal(out[0][0], out[256][0])
     assert np.array_equal(out[0][2], x) and np.array_equal(out[256][2], x)
     assert out[256][1] < out[128][1] < out[0][1]
+
+
+def test_coordinates_of_a_grown_fsp_travel_incrementally(golden_dir):
+    """kfsp_update_state_coords + kfsp_update_matrix_ell after the FSP GREW (one-step sweeps only append: the reference's
+    assembly after 10 sweeps is a prefix of the one after 16): only the coordinates and propensity columns behind the first
+    n_unchanged states travel, the state order is recomputed from the resident + new coordinates, and the generator is the one a
+    fresh context builds from the whole arrays - products bit for bit."""
+    from krylovfspssa_amd import KfspContext
+    a = np.load(os.path.join(golden_dir, "assembly_goutsias_k10.npz"))
+    b = np.load(os.path.join(golden_dir, "assembly_goutsias_k16.npz"))
+    n0, n1 = a["adj"].shape[0], b["adj"].shape[0]
+    assert n1 > n0 and np.array_equal(b["state"][:n0], a["state"])
+    x = np.random.default_rng(4).random(n1)
+    with KfspContext(0) as c, KfspContext(0) as fresh:
+        for ctx in (c, fresh):
+            ctx.set_option("state_order", 1)
+            ctx.set_option("state_order_min", 1)
+            ctx.set_option("state_order_products", 0)
+        c.set_state_coords(a["state"])
+        c.set_matrix_ell(a["adj"], a["offdiag"], a["diag"])
+        assert c.state_order_active()
+        c.update_state_coords(b["state"], n0)
+        c.update_matrix_ell(b["adj"], b["offdiag"], b["diag"], n0)
+        fresh.set_state_coords(b["state"])
+        fresh.set_matrix_ell(b["adj"], b["offdiag"], b["diag"])
+        assert c.state_order_active() and fresh.state_order_active()
+        assert np.array_equal(c.spmv(x), fresh.spmv(x))
+        c.set_vector(x)
+        assert np.array_equal(c.get_vector(), x)
