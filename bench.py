@@ -65,6 +65,10 @@ def parse():
                     help="box workloads: the stored generator is written out by the device from the propensity tables "
                          "(kfsp_set_matrix_box, option box_store) instead of uploading gather rows made by numpy; always on for c5")
     ap.add_argument("--no-1e7", action="store_true", help="skip the spmv_1e7 block (c3x, 10^7 states per GPU) of the default run")
+    ap.add_argument("--fsp", action="store_true",
+                    help="add the spmv_fsp block: the generator product on a NON-BOX FSP of 1.0e7 states (Goutsias on an ellipsoid x 6 DNA "
+                         "configurations, listed in search order; SELL-64 in the caller's order, in the internal order, with coded columns); "
+                         "single GPU, ~40 s of input generation and upload")
     ap.add_argument("--variant", type=int, default=0, choices=[0, 2], help="SpMV kernel variant (0 auto: DIA/SELL, 2 SELL-64)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-expv", action="store_true")
@@ -516,6 +520,56 @@ def main():
             blk[label] = roofline(ms7, synth.spmv_alg_bytes(nnz7, bnr), ctx.matrix_bytes(), t7, t7src)
             blk[label]["self_check"] = {"ok": bool(e7 < 1e-12), "max_rel_err": e7}
         out["spmv_1e7"] = blk
+
+    # ------------------------------------------- a real (non-box) FSP at 10^7 states: the SELL kernel, HBM-resident
+    if args.fsp and world == 1:
+        t0 = time.time()
+        fsp = synth.GoutsiasEllipsoid()
+        fadj, foff, fdiag = fsp.ell()
+        nnz_f = int((fadj > 0).sum()) + fsp.n
+        xf = np.random.default_rng(777).random(fsp.n)
+        # numpy reference on sampled rows (gather form of the reference arrays: row r collects OFFDIAG(k, i) x_i over ADJ(k, i) = r)
+        rows = np.random.default_rng(8).integers(0, fsp.n, 1500)
+        want = np.isin(fadj, rows + 1)
+        src, slot = np.nonzero(want)
+        tgt = fadj[src, slot] - 1
+        ref = -fdiag[rows] * xf[rows]
+        acc = {int(r): 0.0 for r in rows}
+        mag = {int(r): abs(fdiag[r] * xf[r]) for r in rows}
+        for i, k, r in zip(src.tolist(), slot.tolist(), tgt.tolist()):
+            acc[r] += foff[i, k] * xf[i]
+            mag[r] += abs(foff[i, k] * xf[i])
+        ref = np.array([acc[int(r)] - fdiag[r] * xf[r] for r in rows])
+        magv = np.array([mag[int(r)] for r in rows])
+        blk = {"workload": f"Goutsias model on an ellipsoid of (M, D, RNA) x the 6 conserved DNA configurations, {fsp.n} states, {nnz_f} nonzeros, "
+                           "listed in the order of a reachability search (synth.GoutsiasEllipsoid); reference-layout upload (kfsp_set_matrix_ell)",
+               "input_generation_s": round(time.time() - t0, 1)}
+        for label, order, code in (("sell_caller_order", 0, 0), ("sell_internal_order", 1, 0), ("sell_internal_order_coded_columns", 1, 1)):
+            ctx.set_option("state_order", order)
+            ctx.set_option("state_order_min", 1)
+            ctx.set_option("state_order_products", 0)
+            ctx.set_option("sell_code", code)
+            ctx.set_option("m_max", 8)
+            ctx.set_state_coords(fsp.state)
+            ctx.set_matrix_ell(fadj, foff, fdiag)
+            yf = ctx.spmv(xf)
+            err = float(np.max(np.abs(yf[rows] - ref) / (magv + 1e-300)))
+            ctx.set_vector(xf)
+            ctx.begin_step()
+            ctx.spmv_bench(max(args.warmup, 1), 0)
+            msf = ctx.spmv_bench(args.steps, 0) / args.steps
+            key = {"sell_caller_order": "fsp_sell_search_order", "sell_internal_order": "fsp_sell", "sell_internal_order_coded_columns": "fsp_sell_coded"}[label]
+            tr, trs = pmc_traffic(key)
+            blk[label] = roofline(msf, synth.spmv_alg_bytes(nnz_f, fsp.n), ctx.matrix_bytes(), tr, trs)
+            blk[label]["self_check"] = {"ok": bool(err < 1e-12), "max_rel_err": err}
+            blk[label]["layout"] = ctx.layout_info()
+        out["spmv_fsp"] = blk
+        ctx.set_option("state_order", 1)
+        ctx.set_option("state_order_min", 32768)
+        ctx.set_option("state_order_products", 48)
+        ctx.set_option("sell_code", -1)
+        ctx.set_option("m_max", 100)
+        del fadj, foff, fdiag
 
     # ---------------------------------------------------------------- expv
     if not args.no_expv:
