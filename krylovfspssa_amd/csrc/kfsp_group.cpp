@@ -142,7 +142,21 @@ int group_create(int nranks, const int *devices, kfsp_ctx **out)
     }
     head->device = devices ? devices[0] : 0;
     head->group = g.get();
-    for (int p = 0; p < nranks; ++p) g->th.emplace_back(&Group::worker, g.get(), p);
+    try {
+        g->th.reserve((size_t)nranks);
+        for (int p = 0; p < nranks; ++p) g->th.emplace_back(&Group::worker, g.get(), p);
+    } catch (...) {
+        // (a thread could not be started: stop the ones that were, or their destructors would terminate the process)
+        {
+            std::lock_guard<std::mutex> lk(g->mu);
+            g->quit = true;
+        }
+        g->cv_go.notify_all();
+        for (std::thread &t : g->th) t.join();
+        for (kfsp_ctx *c : g->sub) (void)kfsp_destroy(c);
+        if (g->loop) (void)kfsp_loopback_destroy(g->loop);
+        return 4001;
+    }
     kfsp_ctx *h = head.get();
     if (nranks > 1) {
         unsigned char id[KFSP_UNIQUE_ID_BYTES];
