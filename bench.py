@@ -22,9 +22,9 @@ The same JSON line carries
                 library's own stream, measured over the timed region): `achieved` / `frac`
                 count the bytes that really cross the HBM interface per launch - the
                 kernel's own layout (kfsp_matrix_bytes) or the rocprofv3 PMC traffic
-                where that is larger - so frac <= 1 by construction; `alg_GBps` /
-                `frac_alg_csr` keep the SURVEY 8(d) CSR model (what `value` reports),
-                which the banded form does not move (it stores no column indices)
+                where that is larger - so frac <= 1 by construction; `alg_GBps` keeps
+                the SURVEY 8(d) CSR model (what `value` reports), which the banded form
+                does not move (it stores no column indices)
   spmv_1e7      (default run) the same product at 10^7 states per GPU - the size of the
                 60 % target: c3x = repressilator box 216^3, generator written out ON THE
                 DEVICE from the propensity tables, stored and matrix-free, same fields
@@ -392,7 +392,7 @@ def main():
         """The kernel against the HBM roofline.  `achieved` / `frac` count the bytes that really cross the HBM
         interface per launch - max(the layout's own byte count, the PMC-measured traffic) - so the fraction can
         not exceed 1; the SURVEY 8(d) CSR-model rate is kept beside it as alg_GBps (the banded and matrix-free forms
-        store no column indices, so that model overstates what they move)."""
+        store no column indices, so that model overstates what they move; no fraction of the peak is formed from it)."""
         moved = max(real_bytes, traffic or 0)
         sec = ms * 1e-3
         return {
@@ -406,7 +406,6 @@ def main():
             "frac_traffic": round(real_bytes / sec / 1e9 / HBM_PEAK_GBS, 4),
             "alg_bytes_per_launch": int(alg_bytes),
             "alg_GBps": round(alg_bytes / sec / 1e9, 2),
-            "frac_alg_csr": round(alg_bytes / sec / 1e9 / HBM_PEAK_GBS, 4),
         }
 
     # bytes the kernel's own layout moves per launch (kfsp_matrix_bytes) and, when this run is the
@@ -416,8 +415,8 @@ def main():
     roof = roofline(kern_ms, b_alg_local, real_bytes, traffic, traffic_src)
     roof["note"] = ("achieved/frac: bytes that cross the HBM interface per launch (the layout's own count: generator as stored + "
                     "24 B/row, or the rocprofv3 PMC traffic where it is larger) / HIP-event time of the timed launches / 8 TB/s. "
-                    "alg_GBps / frac_alg_csr: the SURVEY 8(d) CSR model (12 nnz + 20 N) over the same time - the figure `value` "
-                    "reports; it may exceed the peak because the banded kernel stores no column indices"
+                    "alg_GBps: the SURVEY 8(d) CSR model (12 nnz + 20 N) over the same time - the figure `value` reports; it is NOT "
+                    "a rate of bytes moved (the banded kernel stores no column indices) and may exceed the peak"
                     + ("; the time includes the exchange of the source vector" if world > 1 else ""))
 
     out = {
