@@ -118,7 +118,12 @@ __global__ void k_os_fill(int n, int lds, int lda, const int32_t *__restrict__ s
         if (adj[(size_t)j * lda + k] != 0) continue;
         unsigned long long key;
         bool neg;
-        if (!os_target(M, state + (size_t)j * lds, k, &key, &neg)) continue;
+        if (!os_target(M, state + (size_t)j * lds, k, &key, &neg)) {
+            // (a state whose column arrives unlinked - all zeros - gets its -1 links here; a column that was linked before has
+            // them already and no open link with a negative target)
+            if (neg) adj_out[(size_t)j * lda + k] = -1;
+            continue;
+        }
         const int p = os_find(okey, n, key);
         if (p >= 0) {
             adj_out[(size_t)j * lda + k] = oidx[p] + 1;
@@ -319,9 +324,10 @@ int onestep_device(kfsp_ctx *ctx, int32_t ns, int32_t nr, const int32_t *stoich,
     int *d_ugid = c2.take<int>(ncp), *d_ugid2 = c2.take<int>(ncp), *d_newidx = c2.take<int>(ncp);
     OS_TRY(hipMemcpyAsync(d_adj_out, d_adj, (size_t)n * lda * 4, hipMemcpyDeviceToDevice, st));
     int nu = 0;
+    // (also with no candidate at all: the -1 links of columns that arrive unlinked are written here)
+    hipLaunchKernelGGL(k_os_fill, dim3(blocks(n)), dim3(256), 0, st, n, lds, lda, d_state, d_adj, M, d_off, okey, oidx, d_ckey, d_cord,
+                       d_cj, d_ck, d_adj_out);
     if (nc > 0) {
-        hipLaunchKernelGGL(k_os_fill, dim3(blocks(n)), dim3(256), 0, st, n, lds, lda, d_state, d_adj, M, d_off, okey, oidx, d_ckey,
-                           d_cord, d_cj, d_ck, d_adj_out);
         // equal targets side by side, in order of appearance (stable); already listed ones (kNoKey) last
         OS_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_ckey, d_ckey2, d_cord, d_cord2, nc, 0, 64, st));
         OS_TRY(ctx->d_sorttmp.reserve(tmp_bytes + 256, false));

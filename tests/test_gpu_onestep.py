@@ -54,3 +54,25 @@ def test_population_cap_and_capacity(golden_dir):
         assert (adj[top] == 0).any()
         with pytest.raises(KfspError):
             c.onestep(nu, a["state"], a["adj"], capacity=len(a["state"]) + 1)
+
+
+@pytest.mark.parametrize("name,k0,k1", [("toggle", 5, 10), ("goutsias", 10, 16), ("repressilator", 5, 10)])
+def test_columns_that_arrive_unlinked_are_completed(golden_dir, name, k0, k1):
+    """A caller may hand over states it appended without linking them: their columns arrive as zeros, and
+    so do the entries of older states that point at them.  The sweep must then give what it gives from
+    the fully linked array - successors present, -1 for a negative population (StateSpace.f90:213-244)."""
+    from krylovfspssa_amd import KfspContext
+    a = np.load(os.path.join(golden_dir, f"assembly_{name}_k{k0}.npz"))
+    nu = _stoich(np.load(os.path.join(golden_dir, f"assembly_{name}_k{k1}.npz")))
+    state, adj = a["state"], a["adj"]
+    n = len(state)
+    lo = n - n // 3                                     # the last third plays the appended states
+    open_adj = adj.copy()
+    open_adj[lo:] = 0
+    open_adj[:lo][adj[:lo] > lo] = 0                    # links of older states into the tail: not made yet
+    assert (adj[lo:] == -1).any() and (adj[:lo] > lo).any()      # both kinds of entries are exercised
+    with KfspContext(0) as c:
+        s_ref, a_ref = c.onestep(nu, state, adj)
+        s_new, a_new = c.onestep(nu, state, open_adj)
+    assert np.array_equal(s_new, s_ref)
+    assert np.array_equal(a_new, a_ref)
