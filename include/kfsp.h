@@ -260,9 +260,13 @@ int kfsp_drop_rebuild(kfsp_ctx *ctx);
  * complete link array of all *n_new states (leading dimension ld_adj, room for capacity states).
  * stoich is [nr][ns]; max_count = MAXNUMBERMOLECULES (StateSpace.f90:11): targets above it are not
  * states.  Propensities (OFFDIAG, DIAG) of the new states and the caller's own look-up structures
- * stay with the caller.  Everything is host memory; deterministic (sorts, no hash table).
- * returns -9 when the packed state keys need more than 63 bits (the caller keeps its own sweep),
- * -11 when capacity is too small (the reference STOPs with 'FSP SIZE EXCEEDS MEMORY LIMIT'). */
+ * stay with the caller.  Everything is host memory.  Deterministic: the listed states and the candidates' targets
+ * go through two open-addressing tables, a slot keeps the SMALLEST candidate ordinal that named its target (atomic
+ * min - the survivor does not depend on the order of the insertions), and the heads are numbered by a scan over the
+ * states (csrc/kfsp_expand.hip; round 2's two radix sorts and its 63-bit key limit are gone).  A column that arrives
+ * as zeros (a state appended but not linked yet) is completed like any other.
+ * returns -9 for more than 2^31 (state, reaction) pairs, -11 when capacity is too small (the reference STOPs with
+ * 'FSP SIZE EXCEEDS MEMORY LIMIT'). */
 int kfsp_onestep(kfsp_ctx *ctx, int32_t ns, int32_t nr, const int32_t *stoich, int32_t n, const int32_t *state,
                  int32_t ld_state, const int32_t *adj, int32_t ld_adj, int32_t max_count, int32_t capacity, int32_t *n_new,
                  int32_t *state_new, int32_t *adj_out);
@@ -313,6 +317,25 @@ int kfsp_ssa_streams(kfsp_ctx *ctx, double timestep, int64_t seedmix, int32_t ns
                      const int32_t *state, int32_t ld_state, const int32_t *adj, const double *offdiag, int32_t ld_adj,
                      const double *diag, int32_t max_count, int32_t capacity_new, int32_t *n_found, int32_t *state_new,
                      double *offdiag_new, int32_t ld_off, double *diag_new);
+
+/* ---- the expansion step on the RESIDENT lists (KrylovSolver.f90:518-534) ---------------------------------------- */
+/* SSA_EXTENDER (the independent-stream walk of kfsp_ssa_streams; skipped when t_ssa <= 0) followed by ONESTEP_EXTENDER
+ * (kfsp_onestep_columns) on the device's OWN copy of the FSP - the coordinates kfsp_set_state_coords left there (option
+ * keep_coords = 1 makes them stay whatever the state order decides) and the reference arrays of kfsp_set_matrix_ell /
+ * kfsp_update_matrix_ell / kfsp_drop_rebuild.  The states the walk met are appended with their propensity columns and
+ * no links, the sweep completes every link and appends its own states, the gather form (and the state order, by the
+ * rule of kfsp_set_state_coords) is rebuilt from the grown arrays, the resident w gets zeros for the appended states
+ * (:530-533).  Nothing crosses the bus but counters; the same states in the same order, the same links and columns as
+ * the two calls above give on host copies of the lists (tests/test_gpu_expand.py).  *n_new = states afterwards,
+ * *n_from_ssa (may be null) = those the walk appended.  One context, no communicator (-9 otherwise, and when the
+ * arrays or coordinates of the current FSP are not resident); -11 when more than `capacity` states would be listed.
+ * A caller that keeps its own copy of the lists refreshes it with kfsp_download_fsp when it needs it. */
+int kfsp_expand_resident(kfsp_ctx *ctx, double t_ssa, int64_t seedmix, int32_t ns, int32_t nr, const int32_t *stoich,
+                         int32_t max_count, int32_t capacity, int64_t *n_new, int64_t *n_from_ssa);
+/* the resident lists -> host arrays (any pointer may be null): state[ld_state][n], adj / offdiag[ld_adj][n], diag[n] in
+ * the caller's order and the reference's encoding; n must be the current number of states */
+int kfsp_download_fsp(kfsp_ctx *ctx, int32_t n, int32_t *state, int32_t ld_state, int32_t *adj, double *offdiag, int32_t ld_adj,
+                      double *diag);
 
 /* single reductions over the resident w (tests; FIND_DROPTOL-style sums) */
 int kfsp_nrm2_w(kfsp_ctx *ctx, double *out);
@@ -485,7 +508,8 @@ int kfsp_add_timer(kfsp_ctx *ctx, int phase, double ms);
  * vector; 1, default: a SELL generator whose reach max |col - row| is at most one block - bounded under the internal state order -
  * exchanges halo strips like a banded one), "overlap", "small_kernel", "small_lds", "dia_mask", "box_lds" (1: the single-factor matrix-free product stages the part of x within "box_reach" rows - default
  * 512 - of a workgroup's rows in LDS and serves the near entries from there, kernel format 6; 0, default: every entry gathers from
- * global memory, format 4, which measured faster on every box; bit-identical products), "ssa_resident" (1: the caller vouches that the FSP arrays handed to kfsp_ssa_streams are the ones of its last
+ * global memory, format 4, which measured faster on every box; bit-identical products), "keep_coords" (1: the coordinates of kfsp_set_state_coords / kfsp_update_state_coords stay on the device
+ * even when no state order is derived from them - kfsp_expand_resident needs them; default 0), "ssa_resident" (1: the caller vouches that the FSP arrays handed to kfsp_ssa_streams are the ones of its last
  * kfsp_update_matrix_ell / kfsp_set_state_coords: they are taken from the device's copies instead of being uploaded again; default 0),
  * "sell_code" (dictionary-coded SELL columns, DESIGN.md 4.1c: -1 auto = under the internal state order,
  * 0 never, 1 always try), "m_max" (largest Krylov dimension the basis is allocated for, default and maximum 100 = M_MAX of

@@ -13,8 +13,8 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libkfsp_hip.so")
-SOURCES = ["kfsp_api.cpp", "kfsp_group.cpp", "kfsp_padm.cpp", "kfsp_stepper.cpp", "kfsp_kernels.hip", "kfsp_build.hip", "kfsp_drop.hip", "kfsp_onestep.hip", "kfsp_prop.hip", "kfsp_ssa.hip"]
-HEADERS = ["kfsp_internal.h", "kfsp_ctx.h", "kfsp_prop_dev.h", os.path.join("..", "..", "include", "kfsp.h")]
+SOURCES = ["kfsp_api.cpp", "kfsp_group.cpp", "kfsp_padm.cpp", "kfsp_stepper.cpp", "kfsp_kernels.hip", "kfsp_build.hip", "kfsp_drop.hip", "kfsp_expand.hip", "kfsp_prop.hip", "kfsp_ssa.hip"]
+HEADERS = ["kfsp_internal.h", "kfsp_ctx.h", "kfsp_prop_dev.h", "kfsp_hash_dev.h", os.path.join("..", "..", "include", "kfsp.h")]
 
 
 def _hipcc():

@@ -489,7 +489,8 @@ int resize(kfsp_ctx *ctx, int64_t n)
     const int64_t need = round_up(ctx->L + 2 * ctx->margin, 256);
     int64_t ldv = ctx->ldv;
     if (need > ctx->ldv || ctx->relayout) {
-        if (ctx->w_pending && !ctx->use_comm) return fail(ctx, -2, "the FSP grew between kfsp_drop_compact and the next generator");
+        if (ctx->w_pending && !ctx->use_comm && !ctx->w_pending_full)
+            return fail(ctx, -2, "the FSP grew between kfsp_drop_compact and the next generator");
         // (head room: half as much again, but no more than 2^24 rows - at 10^8 states 50 % would be 70 GB)
         ldv = ctx->relayout ? need : round_up(need + std::min<int64_t>(need / 2, (int64_t)1 << 24), 256);
         ctx->relayout = false;
@@ -702,7 +703,8 @@ int adopt_pending_vector(kfsp_ctx *ctx)
     ctx->w_pending = false;
     if (ctx->w_pending_n != ctx->n) return fail(ctx, -2, "generator size does not match the vector compacted by kfsp_drop_compact");
     HIP_TRY(hipMemsetAsync(ctx->d_w.p, 0, (size_t)ctx->ldv * sizeof(double), ctx->stream));
-    if (ctx->use_comm) {
+    if (ctx->use_comm || ctx->w_pending_full) {
+        ctx->w_pending_full = false;
         if (int rc = scatter_from_full(ctx, ctx->d_wfull.p, ctx->d_w.p)) return rc;
     } else if (ctx->perm_on)
         kfsp::launch_gather_index(ctx->n, ctx->d_perm.p, ctx->d_tmp.p, ctx->d_w.p, ctx->stream);
@@ -1307,16 +1309,16 @@ static int set_state_coords_impl(kfsp_ctx *ctx, int32_t n, int32_t ns, int32_t l
         ctx->perm_pending_n = 0;
         const int64_t had = ctx->coords_n;                   // (coords_n is set again below if the coordinates are (partly) uploaded)
         ctx->coords_n = 0;
-        if (!ctx->opt_state_order || n < ctx->opt_state_order_min) return 0;
         // Sorting, relabelling and the extra upload cost about as much as 20 products (at 10^6 states)
         // save: worth it only while generators live that long.  The generator being
         // replaced is the best predictor there is.
-        if (ctx->prod_count < ctx->opt_state_order_products) return 0;
+        const bool order = ctx->opt_state_order && n >= ctx->opt_state_order_min && ctx->prod_count >= ctx->opt_state_order_products;
+        if (!order && !ctx->opt_keep_coords) return 0;
         HIP_TRY(hipSetDevice(ctx->device));
         auto t0 = std::chrono::steady_clock::now();
         bool ok = false;
         ctx->coords_n = had;
-        const int rc = kfsp::state_order_from_coords(ctx, n, ns, ld, state, &ok, keep);
+        const int rc = kfsp::state_order_from_coords(ctx, n, ns, ld, state, &ok, keep, order);
         ctx->t_ms[KFSP_T_UPLOAD] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         if (rc) return rc;
         if (ok) ctx->perm_pending_n = n;
@@ -1436,6 +1438,7 @@ int kfsp_set_vector(kfsp_ctx *ctx, int64_t nlocal, const double *w)
     if (!w && nlocal > 0) return fail(ctx, -3, "null w");
     HIP_TRY(hipSetDevice(ctx->device));
     ctx->w_pending = false;
+    ctx->w_pending_full = false;
     ctx->drop_planned = false;
     HIP_TRY(hipMemsetAsync(ctx->d_w.p, 0, (size_t)ctx->ldv * sizeof(double), ctx->stream));
     if (int rc = upload_states(ctx, w, ctx->d_w.p, nlocal)) return rc;
@@ -2053,6 +2056,91 @@ int kfsp_drop_rebuild(kfsp_ctx *ctx)
     });
 }
 
+int kfsp_expand_resident(kfsp_ctx *ctx, double t_ssa, int64_t seedmix, int32_t ns, int32_t nr, const int32_t *stoich,
+                         int32_t max_count, int32_t capacity, int64_t *n_new, int64_t *n_from_ssa)
+{
+    return no_throw(ctx, [&]() -> int {
+        if (!ctx) return -1;
+        if (ctx->group || ctx->use_comm) return fail(ctx, -9, "the resident expansion runs on one context without a communicator");
+        if (ns < 1 || ns > 16) return fail(ctx, -4, "1 <= ns <= 16");
+        if (nr < 1 || nr > 64) return fail(ctx, -5, "1 <= nr <= 64");
+        if (!stoich) return fail(ctx, -6, "null stoich");
+        if (max_count < 1) return fail(ctx, -7, "max_count < 1");
+        if (!n_new) return fail(ctx, -9, "null n_new");
+        const int64_t n = ctx->n;
+        if (ctx->use_box || ctx->opt_host_build || ctx->w_pending || n < 1 || ctx->ell_cols != n || ctx->ell_bw != nr)
+            return fail(ctx, -9, "the reference arrays of the current FSP are not resident on the device (kfsp_set_matrix_ell)");
+        if (ctx->coords_n != n || ctx->coords_ns != ns)
+            return fail(ctx, -9, "the state coordinates of the current FSP are not resident on the device (option keep_coords, kfsp_set_state_coords)");
+        if (capacity < n) return fail(ctx, -8, "capacity < n");
+        if (!ctx->prop_ready || ctx->prop_ns != ns || ctx->prop_nr != nr)
+            return fail(ctx, -1, "no propensity program for this model (kfsp_set_propensity_program)");
+        HIP_TRY(hipSetDevice(ctx->device));
+        hipStream_t st = ctx->stream;
+        auto t0 = std::chrono::steady_clock::now();
+        // the vector in the caller's order, before the order changes under it
+        const double *full = nullptr;
+        if (int rc = gather_to_full(ctx, ctx->d_w.p, &full)) return rc;
+        int64_t n2 = n, nssa = 0;
+        int rc = kfsp::expand_resident_lists(ctx, t_ssa, seedmix, ns, nr, stoich, max_count, capacity, &n2, &nssa);
+        ctx->t_ms[KFSP_T_ONESTEP] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (rc) {
+            // the lists may hold states appended by the walk: the caller's count (n) still describes a consistent prefix
+            ctx->coords_n = n;
+            return rc;
+        }
+        if (n_from_ssa) *n_from_ssa = nssa;
+        *n_new = n2;
+        if (n2 == n) return 0;                              // nothing was appended: generator, order and vector stay
+        t0 = std::chrono::steady_clock::now();
+        HIP_TRY(ctx->d_wfull.reserve((size_t)n2 + 64, false));
+        HIP_TRY(hipMemcpyAsync(ctx->d_wfull.p, full, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
+        kfsp::launch_zero_pad(n, n2, ctx->d_wfull.p, st);
+        ctx->w_pending = true;
+        ctx->w_pending_full = true;
+        ctx->w_pending_n = n2;
+        ctx->ell_cols = n2;
+        // the state order of the grown FSP: the rule of kfsp_set_state_coords, on the coordinates that are here
+        const int cld = ctx->coords_ld;
+        const bool want_order = ctx->opt_state_order && n2 >= ctx->opt_state_order_min && ctx->prod_count >= ctx->opt_state_order_products;
+        ctx->perm_pending_n = 0;
+        bool ordered = false;
+        if (want_order)
+            if (int rc2 = kfsp::state_order_from_resident(ctx, (int32_t)n2, ns, cld, &ordered)) return rc2;
+        ctx->coords_n = n2;
+        ctx->coords_ld = cld;
+        ctx->coords_ns = ns;
+        if (int rc2 = resize(ctx, n2)) return rc2;
+        ctx->perm_on = ordered;
+        ctx->prod_last = ctx->prod_count;
+        ctx->prod_count = 0;
+        rc = kfsp::build_from_resident_ell(ctx, (int32_t)n2, nr, ctx->ell_ld);
+        if (!rc) rc = setup_exchange(ctx);
+        if (!rc) rc = adopt_pending_vector(ctx);
+        ctx->t_ms[KFSP_T_UPLOAD] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return rc;
+    });
+}
+
+int kfsp_download_fsp(kfsp_ctx *ctx, int32_t n, int32_t *state, int32_t ld_state, int32_t *adj, double *offdiag, int32_t ld_adj, double *diag)
+{
+    return no_throw(ctx, [&]() -> int {
+        if (!ctx) return -1;
+        if (ctx->group) ctx = kfsp::group_rank0(ctx);      // every rank holds the whole reference arrays
+        if (n < 1 || n != ctx->ell_cols) return fail(ctx, -2, "n is not the number of states of the resident reference arrays");
+        if (state && (ctx->coords_n != n || ld_state != ctx->coords_ld)) return fail(ctx, -3, "the state coordinates are not resident / ld_state differs");
+        if ((adj || offdiag) && ld_adj != ctx->ell_ld) return fail(ctx, -7, "ld_adj differs from the resident arrays'");
+        HIP_TRY(hipSetDevice(ctx->device));
+        hipStream_t st = ctx->stream;
+        if (state) HIP_TRY(hipMemcpyAsync(state, ctx->d_coords.p, (size_t)n * ld_state * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        if (adj) HIP_TRY(hipMemcpyAsync(adj, ctx->d_ell_adj.p, (size_t)n * ld_adj * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        if (offdiag) HIP_TRY(hipMemcpyAsync(offdiag, ctx->d_ell_off.p, (size_t)n * ld_adj * sizeof(double), hipMemcpyDeviceToHost, st));
+        if (diag) HIP_TRY(hipMemcpyAsync(diag, ctx->d_ell_diag.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        return 0;
+    });
+}
+
 static int reduce_w(kfsp_ctx *ctx, int squared, double *out)
 {
     if (!ctx) return -1;
@@ -2230,6 +2318,7 @@ int kfsp_set_option(kfsp_ctx *ctx, const char *name, int64_t value)
     else if (k == "box_store") ctx->opt_box_store = value;
     else if (k == "sell_code") ctx->opt_sell_code = value;
     else if (k == "ssa_resident") ctx->opt_ssa_resident = value;
+    else if (k == "keep_coords") ctx->opt_keep_coords = value;
     else if (k == "small_lds") ctx->opt_small_lds = value;
     else if (k == "state_order") ctx->opt_state_order = value;
     else if (k == "state_order_min") ctx->opt_state_order_min = value;

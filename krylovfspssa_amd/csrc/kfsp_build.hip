@@ -871,7 +871,7 @@ void launch_gather_index(int64_t n, const int32_t *index, const double *src, dou
                            dst);
 }
 
-int state_order_from_coords(kfsp_ctx *ctx, int32_t n, int32_t ns, int32_t ld, const int32_t *state, bool *ok, int64_t keep)
+int state_order_from_coords(kfsp_ctx *ctx, int32_t n, int32_t ns, int32_t ld, const int32_t *state, bool *ok, int64_t keep, bool order)
 {
     *ok = false;
     // keep: leading states whose coordinates are resident and unchanged (the FSP only grew): only the rest travels
@@ -883,6 +883,13 @@ int state_order_from_coords(kfsp_ctx *ctx, int32_t n, int32_t ns, int32_t ld, co
     HIP_TRY_B(ctx->d_coords.reserve_keep(nent + 64, k0, st));
     if (nent > k0)
         HIP_TRY_B(hipMemcpyAsync(ctx->d_coords.p + k0, state + k0, (nent - k0) * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    if (!order) {                                          // (option keep_coords: resident for the expansion, the caller's order stays)
+        HIP_TRY_B(hipStreamSynchronize(st));
+        ctx->coords_n = n;
+        ctx->coords_ld = ld;
+        ctx->coords_ns = ns;
+        return 0;
+    }
     return state_order_from_resident(ctx, n, ns, ld, ok);
 }
 

@@ -234,7 +234,7 @@ struct kfsp_ctx {
     int64_t w_pending_n = 0;
 
     // ONESTEP_EXTENDER on the device (kfsp_onestep.hip): two scratch arenas (+ one for the columns of the new states)
-    DevBuf<char> d_os1, d_os2, d_os3;
+    DevBuf<char> d_os1, d_os2, d_os3, d_os4;
     // the model's propensity program (kfsp_prop.hip): [code_off | imm_off | tab_species | code] and [params | imm | tables]
     DevBuf<int32_t> d_prop_i;
     DevBuf<double> d_prop_d;
@@ -247,6 +247,7 @@ struct kfsp_ctx {
     DevBuf<double> d_xg;   // nranks*L gathered source (nranks > 1) or scratch x (kfsp_spmv)
     DevBuf<double> d_tmp;  // ldv scratch (kfsp_spmv output)
     DevBuf<double> d_full;   // n: a whole vector in the caller's order (internal state order under a communicator)
+    bool w_pending_full = false;   // the pending vector is the whole vector in the caller's order in d_wfull (kfsp_expand_resident)
     DevBuf<double> d_wfull;  // n: the whole compacted w between kfsp_drop_compact and the next generator (communicator)
     DevBuf<uint8_t> d_flagloc;   // L * nranks: flags of the blocks in the internal order (communicator)
 
@@ -291,6 +292,7 @@ struct kfsp_ctx {
     int64_t opt_sell_code = -1;            // dictionary-coded SELL columns: -1 auto (under the internal state order), 0 never, 1 always try
     int64_t opt_box_store = 0;            // 1: kfsp_set_matrix_box writes the generator out as stored diagonals on the device (banded form)
     int64_t opt_state_order = 1;          // 1: use kfsp_set_state_coords for large, long-lived generators (0: never)
+    int64_t opt_keep_coords = 0;          // 1: coordinates handed over stay resident even when no order is derived from them
     int64_t opt_state_order_min = 32768;  // smallest generator that is reordered
     int64_t opt_state_order_products = 48;   // ... and only if its predecessor saw this many products
     double t_ms[KFSP_T_COUNT] = {0, 0, 0, 0, 0, 0, 0};
@@ -350,7 +352,8 @@ int build_sell_code(kfsp_ctx *ctx);
 int box_materialize(kfsp_ctx *ctx);
 // lexicographic order of n states given as ns coordinates each (host array, leading
 // dimension ld): fills d_perm / d_iperm; *ok = false when the packed key needs > 64 bits
-int state_order_from_coords(kfsp_ctx *ctx, int32_t n, int32_t ns, int32_t ld, const int32_t *state, bool *ok, int64_t keep = 0);
+int state_order_from_coords(kfsp_ctx *ctx, int32_t n, int32_t ns, int32_t ld, const int32_t *state, bool *ok, int64_t keep = 0,
+                            bool order = true);
 // dst[i'] = src[perm[i']] (host order -> device order) and dst[i] = src[iperm[i]] (back)
 void launch_gather_index(int64_t n, const int32_t *index, const double *src, double *dst, hipStream_t st);
 // DROP_STATES pieces (kfsp_drop.hip)
@@ -359,7 +362,7 @@ void launch_drop_flags(int64_t n, const double *w, const double *aw, double drop
                        unsigned long long *cnt, hipStream_t st);
 void launch_flags_to_caller(int64_t n, const uint8_t *all, const int32_t *perm, uint8_t *flag, hipStream_t st);
 int drop_compact_vector(kfsp_ctx *ctx, int64_t n, const double *src, double *dst, int *n_keep_dev);
-// ONESTEP_EXTENDER's integer work (kfsp_onestep.hip); all arrays are host memory
+// ONESTEP_EXTENDER's integer work (kfsp_expand.hip); all arrays are host memory
 // off_new / diag_new (may be null): the propensity columns of the appended states, made by the program of kfsp_prop.hip
 int onestep_device(kfsp_ctx *ctx, int32_t ns, int32_t nr, const int32_t *stoich, int32_t n, const int32_t *state, int32_t lds,
                    const int32_t *adj, int32_t lda, int32_t max_count, int32_t cap, int32_t *n_out, int32_t *state_new,
@@ -375,4 +378,12 @@ int ssa_streams_device(kfsp_ctx *ctx, double tstep, int64_t seedmix, int32_t ns,
                        int32_t max_count, int32_t cap_new, int32_t *n_found, int32_t *state_new, double *off_new, int32_t ldo,
                        double *diag_new);
 int prop_eval_host(kfsp_ctx *ctx, int32_t n, const int32_t *state, int32_t lds, double *offdiag, int32_t ldo, double *diag);
+// the same walk on lists that are on the device; the states met and their columns stay there (d_pstage)
+int ssa_streams_core(kfsp_ctx *ctx, double tstep, int64_t seedmix, int32_t ns, int32_t nr, const int32_t *stoich, int32_t n,
+                     const int32_t *d_state, int32_t lds, const int32_t *d_adj, const double *d_off, int32_t lda, const double *d_diag,
+                     int32_t max_count, int32_t cap_new, int32_t ldo, int32_t *n_found, int32_t **sn, double **on, double **dn);
+// SSA walk + one-step sweep on the resident lists (kfsp_expand.hip)
+int expand_resident_lists(kfsp_ctx *ctx, double tstep, int64_t seedmix, int32_t ns, int32_t nr, const int32_t *stoich,
+                          int32_t max_count, int32_t cap, int64_t *n_out, int64_t *n_ssa);
+void launch_zero_pad(int64_t n0, int64_t n1, double *w, hipStream_t st);
 }  // namespace kfsp

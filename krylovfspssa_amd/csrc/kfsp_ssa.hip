@@ -19,6 +19,7 @@
 // deterministic without a sort; duplicates are removed through a hash table with an atomic MIN on the record
 // index (the set of survivors does not depend on the order of the insertions).
 #include "kfsp_prop_dev.h"
+#include "kfsp_hash_dev.h"
 
 #include <hipcub/hipcub.hpp>
 
@@ -47,31 +48,8 @@ struct SsaDev {
     PropDev P;
 };
 
-__device__ __forceinline__ unsigned hash_state(const int32_t *x, int ns)
-{
-    unsigned long long h = 0x9E3779B97F4A7C15ull;
-    for (int s = 0; s < ns; ++s) {
-        h ^= (unsigned long long)(unsigned)x[s] + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
-        h *= 0xBF58476D1CE4E5B9ull;
-        h ^= h >> 29;
-    }
-    return (unsigned)(h ^ (h >> 32));
-}
-
 // index (1-based) of state y among the listed ones, 0 = not listed
-__device__ __forceinline__ int lookup_state(const SsaDev &A, const int32_t *y)
-{
-    unsigned slot = hash_state(y, A.ns) & A.tmask;
-    for (;;) {
-        const int e = A.tab[slot];
-        if (e == 0) return 0;
-        const int32_t *z = A.state + (int64_t)(e - 1) * A.lds;
-        bool same = true;
-        for (int s = 0; s < A.ns; ++s) same = same && z[s] == y[s];
-        if (same) return e;
-        slot = (slot + 1) & A.tmask;
-    }
-}
+__device__ __forceinline__ int lookup_state(const SsaDev &A, const int32_t *y) { return table_find(A.tab, A.tmask, A.state, A.lds, A.ns, y); }
 
 __global__ __launch_bounds__(kBlock) void k_ht_build(int n, int ns, int lds, const int32_t *__restrict__ state, int32_t *tab, unsigned mask)
 {
@@ -322,44 +300,31 @@ struct Arena {
         }                                                                                  \
     } while (0)
 
-int ssa_streams_device(kfsp_ctx *ctx, double tstep, int64_t seedmix, int32_t ns, int32_t nr, const int32_t *stoich, int32_t n,
-                       const int32_t *state, int32_t lds, const int32_t *adj, const double *offdiag, int32_t lda, const double *diag,
-                       int32_t max_count, int32_t cap_new, int32_t *n_found, int32_t *state_new, double *off_new, int32_t ldo,
-                       double *diag_new)
+void launch_table_build(int n, int ns, int lds, const int32_t *state, int32_t *tab, unsigned mask, hipStream_t st)
+{
+    if (n > 0) hipLaunchKernelGGL(k_ht_build, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, n, ns, lds, state, tab, mask);
+}
+
+// The walk on lists that are on the device (n states: d_state / d_adj / d_off / d_diag).  The states met, in (seed state,
+// position on the path) order of their first occurrence, stay on the device with their propensity columns:
+// *sn (nnew x lds), *on (nnew x ldo), *dn (nnew) point into ctx->d_pstage until that buffer is used again.
+int ssa_streams_core(kfsp_ctx *ctx, double tstep, int64_t seedmix, int32_t ns, int32_t nr, const int32_t *stoich, int32_t n,
+                     const int32_t *d_state, int32_t lds, const int32_t *d_adj, const double *d_off, int32_t lda, const double *d_diag,
+                     int32_t max_count, int32_t cap_new, int32_t ldo, int32_t *n_found, int32_t **sn, double **on, double **dn)
 {
     hipStream_t st = ctx->stream;
     const auto blocks = [](long long k) { return (int)std::max<long long>(1, (k + kBlock - 1) / kBlock); };
     unsigned slots = 64;
     while (slots < 2u * (unsigned)n) slots <<= 1;
-    // arena 1: the FSP as the host holds it, the table of its states, per-path counts and offsets
-    const size_t need1 = (size_t)n * lds * 4 + (size_t)n * lda * 12 + (size_t)n * 8 + (size_t)nr * ns * 4 + (size_t)slots * 4 +
-                         (size_t)(n + 1) * 12 + 16 * 256 + 4096;
-    SSA_TRY(ctx->d_os1.reserve(need1, false));
-    Arena a1{ctx->d_os1.p};
-    int32_t *d_state = a1.take<int32_t>((size_t)n * lds), *d_adj = a1.take<int32_t>((size_t)n * lda);
-    double *d_off = a1.take<double>((size_t)n * lda), *d_diag = a1.take<double>((size_t)n);
+    // arena 1: the table of the listed states, the reaction vectors, the record counter
+    const size_t need1 = (size_t)nr * ns * 4 + (size_t)slots * 4 + 4096;
+    SSA_TRY(ctx->d_os2.reserve(need1, false));
+    Arena a1{ctx->d_os2.p};
     int32_t *d_nu = a1.take<int32_t>((size_t)nr * ns), *d_tab = a1.take<int32_t>(slots);
-    int32_t *d_cnt = a1.take<int32_t>((size_t)n + 1);
-    long long *d_recoff = a1.take<long long>((size_t)n + 1);
-    // Option ssa_resident: the caller vouches that these arrays are what it uploaded last (kfsp_update_matrix_ell keeps the
-    // reference arrays verbatim, kfsp_set_state_coords the coordinates) - 152 MB per call stay where they are at 1e6 states.
-    const bool res_gen = ctx->opt_ssa_resident != 0 && ctx->ell_cols == n && ctx->ell_ld == lda;
-    const bool res_st = ctx->opt_ssa_resident != 0 && ctx->coords_n == n && ctx->coords_ld == lds;
-    if (res_st) d_state = ctx->d_coords.p;
-    else SSA_TRY(hipMemcpyAsync(d_state, state, (size_t)n * lds * 4, hipMemcpyHostToDevice, st));
-    if (res_gen) {
-        d_adj = ctx->d_ell_adj.p;
-        d_off = ctx->d_ell_off.p;
-        d_diag = ctx->d_ell_diag.p;
-    } else {
-        SSA_TRY(hipMemcpyAsync(d_adj, adj, (size_t)n * lda * 4, hipMemcpyHostToDevice, st));
-        SSA_TRY(hipMemcpyAsync(d_off, offdiag, (size_t)n * lda * 8, hipMemcpyHostToDevice, st));
-        SSA_TRY(hipMemcpyAsync(d_diag, diag, (size_t)n * 8, hipMemcpyHostToDevice, st));
-    }
+    unsigned long long *d_total = a1.take<unsigned long long>(2);
     SSA_TRY(hipMemcpyAsync(d_nu, stoich, (size_t)nr * ns * 4, hipMemcpyHostToDevice, st));
     SSA_TRY(hipMemsetAsync(d_tab, 0, (size_t)slots * 4, st));
-    SSA_TRY(hipMemsetAsync(d_cnt, 0, ((size_t)n + 1) * 4, st));
-    hipLaunchKernelGGL(k_ht_build, dim3(blocks(n)), dim3(kBlock), 0, st, n, ns, lds, d_state, d_tab, slots - 1);
+    launch_table_build(n, ns, lds, d_state, d_tab, slots - 1, st);
     SsaDev A;
     A.ns = ns;
     A.nr = nr;
@@ -380,13 +345,12 @@ int ssa_streams_device(kfsp_ctx *ctx, double tstep, int64_t seedmix, int32_t ns,
     // one wavefront per kSsaSeedsPerWave seed states (4 wavefronts per workgroup); the record list is sized by a guess
     // and, should the paths meet more unlisted states than that, by the count the first attempt returns
     const int wgrid = (int)(((long long)n + 4 * kSsaSeedsPerWave - 1) / (4 * kSsaSeedsPerWave));
-    unsigned long long *d_total = reinterpret_cast<unsigned long long *>(d_recoff);
     long long cap = std::max<long long>((long long)1 << 18, (long long)n / 2), nrec = 0;
     unsigned long long *d_keys = nullptr;
     int32_t *d_rec = nullptr;
     for (int attempt = 0; attempt < 2; ++attempt) {
-        SSA_TRY(ctx->d_os2.reserve((size_t)cap * 8 + (size_t)cap * ns * 4 + 1024, false));
-        Arena a2{ctx->d_os2.p};
+        SSA_TRY(ctx->d_os4.reserve((size_t)cap * 8 + (size_t)cap * ns * 4 + 1024, false));
+        Arena a2{ctx->d_os4.p};
         d_keys = a2.take<unsigned long long>((size_t)cap);
         d_rec = a2.take<int32_t>((size_t)cap * ns);
         SSA_TRY(hipMemsetAsync(d_total, 0, sizeof(unsigned long long), st));
@@ -403,6 +367,8 @@ int ssa_streams_device(kfsp_ctx *ctx, double tstep, int64_t seedmix, int32_t ns,
         cap = nrec + 1024;
     }
     *n_found = 0;
+    *sn = nullptr;
+    *on = *dn = nullptr;
     if (nrec == 0) return 0;
     // the records in (seed state, position) order, duplicates removed (first occurrence stays)
     unsigned slots2 = 64;
@@ -436,14 +402,59 @@ int ssa_streams_device(kfsp_ctx *ctx, double tstep, int64_t seedmix, int32_t ns,
         return -11;
     }
     // the new states in (seed state, position on the path) order of their first occurrence, and their columns
-    const size_t sb = (size_t)nnew * lds * 4, ob = (size_t)nnew * ldo * 8;
+    const size_t sb = (size_t)nnew * lds * 4;
     SSA_TRY(ctx->d_pstage.reserve(((size_t)nnew * ldo + (size_t)nnew + (sb + 7) / 8) + 256, false));
     double *d_on = ctx->d_pstage.p, *d_dn = d_on + (size_t)nnew * ldo;
     int32_t *d_sn = reinterpret_cast<int32_t *>(d_dn + nnew);
     hipLaunchKernelGGL(k_rec_gather, dim3(blocks(nnew)), dim3(kBlock), 0, st, nnew, ns, lds, d_sel, d_perm, d_rec, d_sn);
     if (int rc = prop_eval_device(ctx, nnew, d_sn, lds, d_on, ldo, d_dn)) return rc;
-    SSA_TRY(hipMemcpyAsync(state_new, d_sn, sb, hipMemcpyDeviceToHost, st));
-    SSA_TRY(hipMemcpyAsync(off_new, d_on, ob, hipMemcpyDeviceToHost, st));
+    *n_found = nnew;
+    *sn = d_sn;
+    *on = d_on;
+    *dn = d_dn;
+    return 0;
+}
+
+// host lists in, host lists out (kfsp_ssa_streams)
+int ssa_streams_device(kfsp_ctx *ctx, double tstep, int64_t seedmix, int32_t ns, int32_t nr, const int32_t *stoich, int32_t n,
+                       const int32_t *state, int32_t lds, const int32_t *adj, const double *offdiag, int32_t lda, const double *diag,
+                       int32_t max_count, int32_t cap_new, int32_t *n_found, int32_t *state_new, double *off_new, int32_t ldo,
+                       double *diag_new)
+{
+    hipStream_t st = ctx->stream;
+    // Option ssa_resident: the caller vouches that these arrays are what it uploaded last (kfsp_update_matrix_ell keeps the
+    // reference arrays verbatim, kfsp_set_state_coords the coordinates) - 152 MB per call stay where they are at 1e6 states.
+    const bool res_gen = ctx->opt_ssa_resident != 0 && ctx->ell_cols == n && ctx->ell_ld == lda;
+    const bool res_st = ctx->opt_ssa_resident != 0 && ctx->coords_n == n && ctx->coords_ld == lds;
+    const size_t need1 = (res_st ? 0 : (size_t)n * lds * 4) + (res_gen ? 0 : (size_t)n * lda * 12 + (size_t)n * 8) + 4096;
+    SSA_TRY(ctx->d_os1.reserve(need1, false));
+    Arena a1{ctx->d_os1.p};
+    const int32_t *d_state = ctx->d_coords.p, *d_adj = ctx->d_ell_adj.p;
+    const double *d_off = ctx->d_ell_off.p, *d_diag = ctx->d_ell_diag.p;
+    if (!res_st) {
+        int32_t *p = a1.take<int32_t>((size_t)n * lds);
+        SSA_TRY(hipMemcpyAsync(p, state, (size_t)n * lds * 4, hipMemcpyHostToDevice, st));
+        d_state = p;
+    }
+    if (!res_gen) {
+        int32_t *pa = a1.take<int32_t>((size_t)n * lda);
+        double *po = a1.take<double>((size_t)n * lda), *pd = a1.take<double>((size_t)n);
+        SSA_TRY(hipMemcpyAsync(pa, adj, (size_t)n * lda * 4, hipMemcpyHostToDevice, st));
+        SSA_TRY(hipMemcpyAsync(po, offdiag, (size_t)n * lda * 8, hipMemcpyHostToDevice, st));
+        SSA_TRY(hipMemcpyAsync(pd, diag, (size_t)n * 8, hipMemcpyHostToDevice, st));
+        d_adj = pa;
+        d_off = po;
+        d_diag = pd;
+    }
+    int32_t nnew = 0, *d_sn = nullptr;
+    double *d_on = nullptr, *d_dn = nullptr;
+    *n_found = 0;
+    if (int rc = ssa_streams_core(ctx, tstep, seedmix, ns, nr, stoich, n, d_state, lds, d_adj, d_off, lda, d_diag, max_count, cap_new,
+                                  ldo, &nnew, &d_sn, &d_on, &d_dn))
+        return rc;
+    if (nnew == 0) return 0;
+    SSA_TRY(hipMemcpyAsync(state_new, d_sn, (size_t)nnew * lds * 4, hipMemcpyDeviceToHost, st));
+    SSA_TRY(hipMemcpyAsync(off_new, d_on, (size_t)nnew * ldo * 8, hipMemcpyDeviceToHost, st));
     SSA_TRY(hipMemcpyAsync(diag_new, d_dn, (size_t)nnew * 8, hipMemcpyDeviceToHost, st));
     SSA_TRY(hipStreamSynchronize(st));
     *n_found = nnew;

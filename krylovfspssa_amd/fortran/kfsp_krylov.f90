@@ -55,6 +55,10 @@ MODULE KRYLOVSOLVER
   ! the model's propensity program is resident on the device (kfsp_set_propensity_program): one-step sweeps on the
   ! device return the complete columns of the states they append.  KFSP_DEVICE_PROPENSITY=0 keeps them on the host.
   LOGICAL, SAVE, PRIVATE :: PROGRAM_READY = .FALSE., PROGRAM_WANTED = .TRUE.
+  ! Resident mode (KFSP_RESIDENT=0 turns it off): with independent-stream SSA paths (KFSP_SSA_STREAMS=1) and the model's
+  ! program on one device, DROP_STATES and the expansion step run on the device's own copy of the FSP
+  ! (kfsp_drop_rebuild / kfsp_expand_resident); this side keeps the size only and fetches the lists when the solve is over.
+  LOGICAL, SAVE, PRIVATE :: RESIDENT_WANTED = .TRUE., RESIDENT = .FALSE., SINGLE_CONTEXT = .TRUE., SSA_ON_DEVICE = .TRUE.
   LOGICAL, SAVE, PRIVATE :: DEVICE_REBUILD = .TRUE.   ! KFSP_DEVICE_REBUILD=0: the compacted generator is uploaded after every drop
   ! wall seconds spent in the host state-space code of the current solve:
   ! (1) DROP_STATES decision + compaction, (2) SSA_EXTENDER, (3) ONESTEP_EXTENDER,
@@ -126,6 +130,10 @@ CONTAINS
     CUR_FSP => FSP
     CUR_MODEL => MODEL
     CUR_TRACE = ITRACE
+    RESIDENT = RESIDENT_WANTED .AND. PROGRAM_READY .AND. SSA_ON_DEVICE .AND. SINGLE_CONTEXT .AND. SSA_STREAMS_REQUESTED() &
+         .AND. .NOT. HOST_DROP .AND. DEVICE_REBUILD .AND. .NOT. ASSOCIATED(KFSP_STEP_OBSERVER) &
+         .AND. .NOT. ASSOCIATED(KFSP_REPLAY_SCRIPT)
+    RC = KFSP_SET_OPTION(CTX, 'keep_coords' // C_NULL_CHAR, INT(MERGE(1, 0, RESIDENT), C_INT64_T))
     CALL UPLOAD_FSP(FSP, MODEL)
 
     OPS%USER = C_NULL_PTR
@@ -151,6 +159,15 @@ CONTAINS
        CALL CHECK(RC, 'kfsp_dgexpv')
     ENDIF
 
+    IF (RESIDENT) THEN
+       ! the lists as the device left them; keys and look-up table of this side follow
+       N0 = FSP%SIZE
+       RC = KFSP_DOWNLOAD_FSP(CTX, INT(FSP%SIZE, C_INT32_T), FSP%STATE, INT(SIZE(FSP%STATE, 1), C_INT32_T), FSP%MATRIX%ADJ, &
+            FSP%MATRIX%OFFDIAG, INT(SIZE(FSP%MATRIX%ADJ, 1), C_INT32_T), FSP%MATRIX%DIAG)
+       CALL CHECK(RC, 'kfsp_download_fsp')
+       CALL ADOPT_LISTS(FSP, MODEL, N0)
+       RESIDENT = .FALSE.
+    ENDIF
     RC = KFSP_GET_VECTOR(CTX, INT(FSP%SIZE, C_INT64_T), FSP%VECTOR)
     CALL CHECK(RC, 'kfsp_get_vector')
     ! W is FSP%VECTOR itself when called through CME_SOLVE; a distinct W gets a copy
@@ -242,6 +259,11 @@ CONTAINS
     ENDIF
     CALL GET_ENVIRONMENT_VARIABLE('KFSP_HOST_DROP', ENV, L, STAT)
     HOST_DROP = (STAT == 0 .AND. L > 0 .AND. ENV(1:1) /= '0')
+    CALL GET_ENVIRONMENT_VARIABLE('KFSP_RESIDENT', ENV, L, STAT)
+    IF (STAT == 0 .AND. L > 0) RESIDENT_WANTED = ENV(1:1) /= '0'
+    CALL GET_ENVIRONMENT_VARIABLE('KFSP_DEVICE_SSA', ENV, L, STAT)
+    IF (STAT == 0 .AND. L > 0) SSA_ON_DEVICE = ENV(1:1) /= '0'
+    SINGLE_CONTEXT = NRANKS <= 1
     CALL GET_ENVIRONMENT_VARIABLE('KFSP_DEVICE_REBUILD', ENV, L, STAT)
     IF (STAT == 0 .AND. L > 0) DEVICE_REBUILD = ENV(1:1) /= '0'
     CALL GET_ENVIRONMENT_VARIABLE('KFSP_DEVICE_PROPENSITY', ENV, L, STAT)
@@ -447,6 +469,19 @@ CONTAINS
        N_NEW = N
        IF (DBLE(CNT) * 1.0D0 / (DBLE(N) * 1.0D0) <= 0.1D0) RETURN          ! :497
        T0 = WALL()
+       IF (RESIDENT) THEN
+          ! the vector and the device's own lists are compacted where they are; this side only learns the new size
+          RC = KFSP_DROP_COMPACT(CTX, NKEEP)
+          IF (RC /= 0) RETURN
+          RC = KFSP_DROP_REBUILD(CTX)
+          CALL CHECK(RC, 'kfsp_drop_rebuild')
+          CUR_FSP%SIZE = INT(NKEEP)
+          CUR_FSP%MATRIX%SIZE = INT(NKEEP)
+          HOST_SEC(1) = HOST_SEC(1) + (WALL() - T0)
+          N_NEW = NKEEP
+          RC = 0
+          RETURN
+       ENDIF
        ALLOCATE(FLAGS(N))
        RC = KFSP_DROP_FLAGS(CTX, INT(N, C_INT64_T), FLAGS)
        IF (RC /= 0) RETURN
@@ -499,8 +534,26 @@ CONTAINS
     REAL(C_DOUBLE), VALUE :: T_SSA
     INTEGER(C_INT64_T) :: N_NEW
     INTEGER(C_INT) :: RC
-    DOUBLE PRECISION :: TS, T0, T1, T2
+    DOUBLE PRECISION :: TS, T0, T1, T2, BASE
     INTEGER :: N_BEFORE
+    INTEGER(C_INT64_T) :: NN, NSSA
+    IF (RESIDENT) THEN
+       ! SSA_EXTENDER_STREAMS + ONESTEP_EXTENDER on the device's own lists (kfsp_expand_resident); the number that seeds
+       ! the paths' streams is drawn here, as SSA_EXTENDER_STREAMS draws it
+       T0 = WALL()
+       CALL RANDOM_NUMBER(BASE)
+       RC = KFSP_EXPAND_RESIDENT(CTX, T_SSA, INT(BASE * 2147483647.0D0, C_INT64_T), INT(CUR_MODEL%NSPECIES, C_INT32_T), &
+            INT(CUR_MODEL%NREACTIONS, C_INT32_T), CUR_MODEL%STOICHIOMETRY(1:CUR_MODEL%NSPECIES, 1:CUR_MODEL%NREACTIONS), &
+            INT(MAXNUMBERMOLECULES, C_INT32_T), INT(CUR_FSP%MAX_SIZE - 1, C_INT32_T), NN, NSSA)
+       IF (RC == -11) STOP 'OVERFLOW ERROR: FSP SIZE EXCEEDS MEMORY LIMIT.'
+       CALL CHECK(RC, 'kfsp_expand_resident')
+       CUR_FSP%SIZE = INT(NN)
+       CUR_FSP%MATRIX%SIZE = INT(NN)
+       HOST_SEC(2) = HOST_SEC(2) + (WALL() - T0)
+       N_NEW = NN
+       RC = 0
+       RETURN
+    ENDIF
     RC = KFSP_GET_VECTOR(CTX, INT(CUR_FSP%SIZE, C_INT64_T), CUR_FSP%VECTOR)
     IF (RC /= 0) RETURN
     N_BEFORE = CUR_FSP%SIZE

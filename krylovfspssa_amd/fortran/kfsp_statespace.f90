@@ -65,7 +65,7 @@ MODULE STATESPACE
      PROCEDURE :: INDEX => INDEX_STATE
   END TYPE FINITE_STATE_PROJECTION
 
-  PRIVATE :: ONESTEP_ON_DEVICE, SSA_STREAMS_ON_DEVICE, KFSP_PLOG, SSA_STREAMS_REQUESTED, SSA_EXTENDER_STREAMS, STREAM_PATH, TICK, STATE_HASH, LOOKUP, PROBE, INSERT_RANGE, APPEND_CANDIDATES, CUSTOMPROP_IS_PURE, TABLE_INSERT, REBUILD_TABLE, LEGAL, RESERVE_TABLE, APPEND_STATE, &
+  PRIVATE :: ONESTEP_ON_DEVICE, SSA_STREAMS_ON_DEVICE, KFSP_PLOG, SSA_EXTENDER_STREAMS, STREAM_PATH, TICK, STATE_HASH, LOOKUP, PROBE, INSERT_RANGE, APPEND_CANDIDATES, CUSTOMPROP_IS_PURE, TABLE_INSERT, REBUILD_TABLE, LEGAL, RESERVE_TABLE, APPEND_STATE, &
        LINK_ONE, LINK_NEW, HOST_THREADS
 
   INTEGER(8), PARAMETER, PRIVATE :: LOW32 = 4294967295_8
@@ -359,6 +359,26 @@ CONTAINS
     ENDDO
     TOUCH_SINK = INT(IAND(TOUCH, 1_8))
   END SUBROUTINE INSERT_RANGE
+
+  ! The lists STATE / MATRIX%ADJ / OFFDIAG / DIAG (1:N) were written from outside (the solver's resident mode downloads
+  ! them from the device when the solve is over): keys and look-up table are made to match.
+  SUBROUTINE ADOPT_LISTS(FSP, MODEL, N)
+    CLASS(FINITE_STATE_PROJECTION), INTENT(INOUT) :: FSP
+    TYPE(CME_MODEL), INTENT(IN) :: MODEL
+    INTEGER, INTENT(IN) :: N
+    INTEGER :: I, NT
+    FSP%SIZE = 0                                 ! (nothing to carry over into a regrown table)
+    CALL RESERVE_TABLE(FSP, MAX(N, 1))
+    NT = HOST_THREADS(N, 4096)
+    !$OMP PARALLEL DO NUM_THREADS(NT) SCHEDULE(STATIC) IF(NT > 1)
+    DO I = 1, N
+       FSP%KEY(I) = STATE_HASH(FSP%STATE(1:MODEL%NSPECIES, I))
+    ENDDO
+    !$OMP END PARALLEL DO
+    FSP%SIZE = N
+    FSP%MATRIX%SIZE = N
+    CALL REBUILD_TABLE(FSP)
+  END SUBROUTINE ADOPT_LISTS
 
   SUBROUTINE REBUILD_TABLE(FSP)
     CLASS(FINITE_STATE_PROJECTION), INTENT(INOUT) :: FSP

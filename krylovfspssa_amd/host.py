@@ -72,6 +72,8 @@ def load_library():
         "kfsp_drop_flags": [vp, i64, vp],
         "kfsp_drop_compact": [vp, C.POINTER(i64)],
         "kfsp_drop_rebuild": [vp],
+        "kfsp_expand_resident": [vp, dbl, i64, i32, i32, vp, i32, i32, C.POINTER(i64), C.POINTER(i64)],
+        "kfsp_download_fsp": [vp, i32, vp, i32, vp, vp, i32, vp],
         "kfsp_dgexpv": [vp, dbl, dbl, dbl, C.c_int, vp, vp],
         "kfsp_set_vector": [vp, i64, vp],
         "kfsp_get_vector": [vp, i64, vp],
@@ -359,6 +361,67 @@ class KfspContext:
                                          C.byref(n_new), _p(st_new), _p(adj_out)), "kfsp_onestep")
         m = n_new.value
         return np.concatenate([state, st_new[:m - n]]), adj_out[:m].copy()
+
+    def onestep_columns(self, stoich, state, adj, max_count=10000, capacity=None):
+        """onestep that also returns the propensity columns (offdiag [m][nr], diag [m]) of the appended states"""
+        state = np.ascontiguousarray(state, dtype=np.int32)
+        adj = np.ascontiguousarray(adj, dtype=np.int32)
+        stoich = np.ascontiguousarray(stoich, dtype=np.int32)
+        n, ns = state.shape
+        nr = adj.shape[1]
+        cap = int(capacity) if capacity else n * (nr + 1) + 16
+        n_new = C.c_int32(0)
+        st_new = np.zeros((cap - n + 1, ns), dtype=np.int32)
+        adj_out = np.zeros((cap, nr), dtype=np.int32)
+        off_new = np.zeros((cap - n + 1, nr))
+        diag_new = np.zeros(cap - n + 1)
+        self._chk(self._lib.kfsp_onestep_columns(self._h, ns, nr, _p(stoich), n, _p(state), ns, _p(adj), nr, int(max_count), cap,
+                                                 C.byref(n_new), _p(st_new), _p(adj_out), _p(off_new), nr, _p(diag_new)),
+                  "kfsp_onestep_columns")
+        m = n_new.value
+        return np.concatenate([state, st_new[:m - n]]), adj_out[:m].copy(), off_new[:m - n].copy(), diag_new[:m - n].copy()
+
+    def ssa_streams(self, timestep, seedmix, stoich, state, adj, offdiag, diag, max_count=10000, capacity_new=None):
+        """the independent-stream SSA walk: (new states [m][ns], offdiag [m][nr], diag [m]) in order of first occurrence"""
+        state = np.ascontiguousarray(state, dtype=np.int32)
+        adj = np.ascontiguousarray(adj, dtype=np.int32)
+        offdiag = np.ascontiguousarray(offdiag, dtype=np.float64)
+        diag = np.ascontiguousarray(diag, dtype=np.float64)
+        stoich = np.ascontiguousarray(stoich, dtype=np.int32)
+        n, ns = state.shape
+        nr = adj.shape[1]
+        cap = int(capacity_new) if capacity_new else 4 * n + 4096
+        nf = C.c_int32(0)
+        st_new = np.zeros((cap, ns), dtype=np.int32)
+        off_new = np.zeros((cap, nr))
+        diag_new = np.zeros(cap)
+        self._chk(self._lib.kfsp_ssa_streams(self._h, float(timestep), int(seedmix), ns, nr, _p(stoich), n, _p(state), ns, _p(adj),
+                                             _p(offdiag), nr, _p(diag), int(max_count), cap, C.byref(nf), _p(st_new), _p(off_new), nr,
+                                             _p(diag_new)), "kfsp_ssa_streams")
+        m = nf.value
+        return st_new[:m].copy(), off_new[:m].copy(), diag_new[:m].copy()
+
+    def expand_resident(self, t_ssa, seedmix, stoich, max_count=10000, capacity=None):
+        """SSA walk (t_ssa > 0) + one-step sweep on the resident lists; returns (n_new, n_from_ssa)"""
+        stoich = np.ascontiguousarray(stoich, dtype=np.int32)
+        nr, ns = stoich.shape
+        cap = int(capacity) if capacity else 2 ** 31 - 2
+        n_new, n_ssa = C.c_int64(0), C.c_int64(0)
+        self._chk(self._lib.kfsp_expand_resident(self._h, float(t_ssa), int(seedmix), ns, nr, _p(stoich), int(max_count), cap,
+                                                 C.byref(n_new), C.byref(n_ssa)), "kfsp_expand_resident")
+        self.n = n_new.value
+        self.row0, self.nloc = self.row_block(self.n)
+        return n_new.value, n_ssa.value
+
+    def download_fsp(self, ns, nr):
+        """the resident lists: (state [n][ns], adj [n][nr], offdiag [n][nr], diag [n])"""
+        n = self.n
+        state = np.zeros((n, ns), dtype=np.int32)
+        adj = np.zeros((n, nr), dtype=np.int32)
+        off = np.zeros((n, nr))
+        diag = np.zeros(n)
+        self._chk(self._lib.kfsp_download_fsp(self._h, n, _p(state), ns, _p(adj), _p(off), nr, _p(diag)), "kfsp_download_fsp")
+        return state, adj, off, diag
 
     def set_propensity_program(self, ns, params, programs, tables=None):
         """programs: per reaction (code list, immediates list); tables: None or (tab_species [nr], tab [nr][tab_len])"""

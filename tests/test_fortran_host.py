@@ -302,12 +302,16 @@ def test_device_ssa_walk_equals_the_host_walk(dump, tmp_path, fixture, case):
     identical: step log, state list, links, propensity columns and the probabilities, bit for bit."""
     base = {"KFSP_SSA_STREAMS": "1", "KFSP_HOST_THREADS": "4", "KFSP_HOST_PARALLEL_MIN": "1"}
     g, dh, logh = _solve(dump, tmp_path, fixture, case, env=dict(base, KFSP_DEVICE_SSA="0"))
-    g, dd, logd = _solve(dump, tmp_path, fixture, case, env=dict(base, KFSP_DEVICE_SSA_MIN="1"))
-    assert int(logd["n_ssa"]) == int(logh["n_ssa"]) and int(logd["n_ssa"]) >= 1
-    assert np.array_equal(logd["step_n"], logh["step_n"]) and np.array_equal(logd["step_tau"], logh["step_tau"])
-    assert np.array_equal(logd["step_m"], logh["step_m"]) and np.array_equal(logd["wsum"], logh["wsum"])
-    for key in ("state", "adj", "offdiag", "diag", "vector"):
-        assert np.array_equal(dd[key], dh[key]), key
+    # the walk on the device, lists and linking on the host - and the RESIDENT mode (the default with a device walk):
+    # drop, walk, one-step sweep and generator rebuild all on the device's own lists (kfsp_expand_resident /
+    # kfsp_drop_rebuild), the host fetching them when the solve is over
+    for mode in ({"KFSP_RESIDENT": "0"}, {"KFSP_RESIDENT": "1"}):
+        g, dd, logd = _solve(dump, tmp_path, fixture, case, env=dict(base, KFSP_DEVICE_SSA_MIN="1", **mode))
+        assert int(logd["n_ssa"]) == int(logh["n_ssa"]) and int(logd["n_ssa"]) >= 1, mode
+        assert np.array_equal(logd["step_n"], logh["step_n"]) and np.array_equal(logd["step_tau"], logh["step_tau"]), mode
+        assert np.array_equal(logd["step_m"], logh["step_m"]) and np.array_equal(logd["wsum"], logh["wsum"]), mode
+        for key in ("state", "adj", "offdiag", "diag", "vector"):
+            assert np.array_equal(dd[key], dh[key]), (mode, key)
     # and it is the consistent expansion the mode promises: the reference's solution within the two runs' FSP budgets
     ref = {tuple(s): v for s, v in zip(g["state"].tolist(), g["vector"].tolist())}
     got = {tuple(s): v for s, v in zip(dd["state"].tolist(), dd["vector"].tolist())}

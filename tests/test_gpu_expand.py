@@ -1,0 +1,180 @@
+"""The expansion step on the resident lists (kfsp_expand_resident, csrc/kfsp_expand.hip): SSA_EXTENDER (independent
+streams) + ONESTEP_EXTENDER of KrylovSolver.f90:518-534 without a trip to the host.  It must give exactly what the two
+calls it fuses - kfsp_ssa_streams and kfsp_onestep_columns, each pinned on its own (tests/test_fortran_host.py against
+the host walk, tests/test_gpu_onestep.py against the reference's assemblies) - give on host copies of the lists: the
+same states in the same order, the same links, the same propensity columns; the resident vector padded with zeros; the
+rebuilt generator's products bit-identical to those of a generator uploaded from the downloaded lists.  Then a whole
+cycle drop -> rebuild -> expand, all on the device."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _stoich(a):
+    nr = a["adj"].shape[1]
+    nu = [None] * nr
+    for i, row in enumerate(a["adj"]):
+        for r, j in enumerate(row):
+            if j > 0 and nu[r] is None:
+                nu[r] = a["state"][j - 1] - a["state"][i]
+    assert all(v is not None for v in nu)
+    return np.array(nu, dtype=np.int32)
+
+
+def _mass_action(nu):
+    """a_k = c_k * prod of the species reaction k consumes (postfix code of kfsp_set_propensity_program; + - * / only:
+    the device's columns are the same bits wherever they are made)"""
+    nr, ns = nu.shape
+    MUL = 5
+    progs, params = [], []
+    for k in range(nr):
+        params.append(0.05 + 0.01 * k)
+        code = [100 + ns + 1 + k]
+        for s in range(ns):
+            if nu[k, s] < 0:
+                code += [100 + s + 1, MUL]
+        progs.append((code, []))
+    return np.array(params), progs
+
+
+def _grown(c, name, golden_dir, sweeps):
+    a = np.load(os.path.join(golden_dir, f"assembly_{name}.npz"))
+    nu = _stoich(a)
+    state, adj = a["state"], a["adj"]
+    for _ in range(sweeps):
+        state, adj = c.onestep(nu, state, adj)
+    return nu, state, adj
+
+
+def _host_composition(c, t, seed, nu, state, adj, off, diag):
+    s1, o1, d1 = c.ssa_streams(t, seed, nu, state, adj, off, diag)
+    state1 = np.concatenate([state, s1])
+    adj1 = np.concatenate([adj, np.zeros((len(s1), adj.shape[1]), dtype=np.int32)])       # appended, not linked
+    state2, adj2, o2, d2 = c.onestep_columns(nu, state1, adj1)
+    return len(s1), state2, adj2, np.concatenate([off, o1, o2]), np.concatenate([diag, d1, d2])
+
+
+@pytest.mark.parametrize("name,sweeps,order", [("toggle_k20", 6, 0), ("goutsias_k16", 4, 0), ("goutsias_k16", 4, 1),
+                                               ("repressilator_k10", 3, 1)])
+def test_resident_expansion_equals_the_two_calls_on_host_lists(golden_dir, name, sweeps, order):
+    from krylovfspssa_amd import KfspContext
+    rng = np.random.default_rng(5)
+    with KfspContext(0) as c, KfspContext(0) as ref:
+        nu, state, adj = _grown(c, name, golden_dir, sweeps)
+        nr, ns = nu.shape
+        params, progs = _mass_action(nu)
+        for x in (c, ref):
+            x.set_propensity_program(ns, params, progs)
+            x.set_option("state_order", order)
+            x.set_option("state_order_min", 64)
+            x.set_option("state_order_products", 0)
+        off, diag = c.propensities(state)
+        n = len(state)
+        t = 2.0 / float(np.mean(diag[diag > 0]))
+        seed = 123456789
+        nssa_want, state2, adj2, off2, diag2 = _host_composition(ref, t, seed, nu, state, adj, off, diag)
+        assert nssa_want > 0 and len(state2) > n + nssa_want          # both halves of the step appended something
+
+        c.set_option("keep_coords", 1)
+        c.set_state_coords(state)
+        c.set_matrix_ell(adj, off, diag)
+        assert bool(c.state_order_active()) == bool(order)
+        w = rng.random(n)
+        c.set_vector(w)
+        n2, nssa = c.expand_resident(t, seed, nu)
+        assert (n2, nssa) == (len(state2), nssa_want)
+        s_r, a_r, o_r, d_r = c.download_fsp(ns, nr)
+        assert np.array_equal(s_r, state2)
+        assert np.array_equal(a_r, adj2)
+        assert np.array_equal(o_r, off2)
+        assert np.array_equal(d_r, diag2)
+        assert np.array_equal(c.get_vector(), np.concatenate([w, np.zeros(n2 - n)]))
+        assert bool(c.state_order_active()) == bool(order)
+
+        # the rebuilt generator against one uploaded from the same lists
+        ref.set_state_coords(state2)
+        ref.set_matrix_ell(adj2, off2, diag2)
+        x = rng.random(n2)
+        assert np.array_equal(c.spmv(x), ref.spmv(x))
+
+
+def test_drop_rebuild_expand_cycle_stays_on_the_device(golden_dir):
+    """three rounds of: products, a drop decided and applied on the device, the resident expansion - against a host that
+    carries its own copy of the lists through the same calls"""
+    from krylovfspssa_amd import KfspContext
+    rng = np.random.default_rng(11)
+    with KfspContext(0) as c, KfspContext(0) as ref:
+        nu, state, adj = _grown(c, "goutsias_k16", golden_dir, 4)
+        nr, ns = nu.shape
+        params, progs = _mass_action(nu)
+        for x in (c, ref):
+            x.set_propensity_program(ns, params, progs)
+            x.set_option("state_order_min", 64)
+            x.set_option("state_order_products", 0)
+        off, diag = c.propensities(state)
+        c.set_option("keep_coords", 1)
+        c.set_state_coords(state)
+        c.set_matrix_ell(adj, off, diag)
+        # a vector with a tail of tiny entries, so that the drop rule has something to drop
+        # (the later half of the list - the outer states - carries next to nothing: the drop rule has something to drop)
+        w = rng.random(len(state)) * np.where(np.arange(len(state)) >= len(state) // 2, 1e-14, 1.0)
+        w /= w.sum()
+        c.set_vector(w)
+        for cycle in range(3):
+            n = len(state)
+            droptol, cnt, nflag = c.drop_plan(1e-7)
+            assert nflag > n // 20, (cycle, nflag, n)            # (the 10 % rule is the caller's; the mechanics are tested here)
+            flags = c.drop_flags()
+            nk = c.drop_compact()
+            c.drop_rebuild()
+            keep = flags == 0
+            assert nk == int(keep.sum())
+            # the host's compaction of its copy (StateSpace.f90:500-546)
+            newidx = np.cumsum(keep) * keep
+            adj = np.where(adj > 0, newidx[np.maximum(adj, 1) - 1], adj)[keep].astype(np.int32)
+            state, off, diag, w = state[keep], off[keep], diag[keep], w[keep]
+            s_r, a_r, o_r, d_r = c.download_fsp(ns, nr)
+            assert np.array_equal(s_r, state) and np.array_equal(a_r, adj) and np.array_equal(o_r, off) and np.array_equal(d_r, diag)
+            t = 2.0 / float(np.mean(diag[diag > 0]))
+            seed = 1000 + cycle
+            _, state, adj, off, diag = _host_composition(ref, t, seed, nu, state, adj, off, diag)
+            n2, _ = c.expand_resident(t, seed, nu)
+            assert n2 == len(state)
+            s_r, a_r, o_r, d_r = c.download_fsp(ns, nr)
+            assert np.array_equal(s_r, state) and np.array_equal(a_r, adj) and np.array_equal(o_r, off) and np.array_equal(d_r, diag)
+            w = np.concatenate([w, np.zeros(n2 - len(w))])
+            assert np.array_equal(c.get_vector(), w)
+            ref.set_state_coords(state)
+            ref.set_matrix_ell(adj, off, diag)
+            x = rng.random(n2)
+            y = c.spmv(x)
+            assert np.array_equal(y, ref.spmv(x))
+            # the next cycle's vector: a few products' worth of spreading, tiny tail again
+            w = np.abs(x) * np.where(np.arange(n2) >= n2 // 2, 1e-14, 1.0)
+            w /= w.sum()
+            c.set_vector(w)
+
+
+def test_refusals(golden_dir):
+    from krylovfspssa_amd import KfspContext, KfspError
+    with KfspContext(0) as c:
+        nu, state, adj = _grown(c, "toggle_k20", golden_dir, 0)
+        nr, ns = nu.shape
+        params, progs = _mass_action(nu)
+        c.set_propensity_program(ns, params, progs)
+        off, diag = c.propensities(state)
+        c.set_matrix_ell(adj, off, diag)                       # no coordinates on the device
+        c.set_vector(np.ones(len(state)))
+        with pytest.raises(KfspError):
+            c.expand_resident(1.0, 1, nu)
+        c.set_option("keep_coords", 1)
+        c.set_state_coords(state)
+        c.set_matrix_ell(adj, off, diag)
+        with pytest.raises(KfspError):                          # capacity: the reference STOPs here
+            c.expand_resident(1.0, 1, nu, capacity=len(state) + 1)
+        # the refused expansion left the FSP as it was
+        s_r, a_r, _, _ = c.download_fsp(ns, nr)
+        assert np.array_equal(s_r, state) and np.array_equal(a_r, adj)
