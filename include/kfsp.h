@@ -508,7 +508,8 @@ int kfsp_add_timer(kfsp_ctx *ctx, int phase, double ms);
  * vector; 1, default: a SELL generator whose reach max |col - row| is at most one block - bounded under the internal state order -
  * exchanges halo strips like a banded one), "overlap", "small_kernel", "small_lds", "dia_mask", "box_lds" (1: the single-factor matrix-free product stages the part of x within "box_reach" rows - default
  * 512 - of a workgroup's rows in LDS and serves the near entries from there, kernel format 6; 0, default: every entry gathers from
- * global memory, format 4, which measured faster on every box; bit-identical products), "keep_coords" (1: the coordinates of kfsp_set_state_coords / kfsp_update_state_coords stay on the device
+ * global memory, format 4, which measured faster on every box; bit-identical products), "ssa_general" (1: kfsp_ssa_streams / kfsp_expand_resident walk with the general kernel even for models of <= 8 species and
+ * <= 16 reactions, which otherwise take the register-resident one; same paths; default 0), "keep_coords" (1: the coordinates of kfsp_set_state_coords / kfsp_update_state_coords stay on the device
  * even when no state order is derived from them - kfsp_expand_resident needs them; default 0), "ssa_resident" (1: the caller vouches that the FSP arrays handed to kfsp_ssa_streams are the ones of its last
  * kfsp_update_matrix_ell / kfsp_set_state_coords: they are taken from the device's copies instead of being uploaded again; default 0),
  * "sell_code" (dictionary-coded SELL columns, DESIGN.md 4.1c: -1 auto = under the internal state order,

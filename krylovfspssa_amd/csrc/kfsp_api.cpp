@@ -2319,6 +2319,7 @@ int kfsp_set_option(kfsp_ctx *ctx, const char *name, int64_t value)
     else if (k == "sell_code") ctx->opt_sell_code = value;
     else if (k == "ssa_resident") ctx->opt_ssa_resident = value;
     else if (k == "keep_coords") ctx->opt_keep_coords = value;
+    else if (k == "ssa_general") ctx->opt_ssa_general = value;
     else if (k == "small_lds") ctx->opt_small_lds = value;
     else if (k == "state_order") ctx->opt_state_order = value;
     else if (k == "state_order_min") ctx->opt_state_order_min = value;

@@ -292,6 +292,7 @@ struct kfsp_ctx {
     int64_t opt_sell_code = -1;            // dictionary-coded SELL columns: -1 auto (under the internal state order), 0 never, 1 always try
     int64_t opt_box_store = 0;            // 1: kfsp_set_matrix_box writes the generator out as stored diagonals on the device (banded form)
     int64_t opt_state_order = 1;          // 1: use kfsp_set_state_coords for large, long-lived generators (0: never)
+    int64_t opt_ssa_general = 0;          // 1: the SSA walk always runs its general kernel (A/B of the register-resident one)
     int64_t opt_keep_coords = 0;          // 1: coordinates handed over stay resident even when no order is derived from them
     int64_t opt_state_order_min = 32768;  // smallest generator that is reordered
     int64_t opt_state_order_products = 48;   // ... and only if its predecessor saw this many products

@@ -113,7 +113,7 @@ __device__ __forceinline__ double lcg_uniform(unsigned long long &rs)
 constexpr int kSsaSeedsPerWave = 256;
 constexpr int kSsaPosBits = 22;
 
-__global__ __launch_bounds__(kBlock) void k_ssa_walk(SsaDev A, unsigned long long *__restrict__ nrec_total, long long cap,
+__global__ __launch_bounds__(kBlock) void k_ssa_walk_any(SsaDev A, unsigned long long *__restrict__ nrec_total, long long cap,
                                                      unsigned long long *__restrict__ keys, int32_t *__restrict__ rec)
 {
     const int lane = threadIdx.x & 63;
@@ -126,10 +126,22 @@ __global__ __launch_bounds__(kBlock) void k_ssa_walk(SsaDev A, unsigned long lon
     int j0 = 0, j = 0, npos = 0;
     bool virt = false;
     unsigned long long rs = 0;
-    double tt = 0.0;
+    double tt = 0.0, a0 = 0.0;
     int32_t x[kSsaMaxS], y[kSsaMaxS];
     double pr[kSsaMaxR];
     int32_t aj[kSsaMaxR];
+    // the row of a listed state - DIAG, the OFFDIAG column, the ADJ column - is REQUESTED as soon as the state is known
+    // (when a path starts, and at the end of the jump that reaches it) and USED after the jump's random numbers and
+    // logarithm have been computed: the arithmetic that does not depend on the row runs while the row travels
+#define KFSP_SSA_LOAD_ROW()                                           \
+    do {                                                              \
+        const int64_t row_ = (int64_t)(j - 1) * A.lda;                \
+        a0 = A.diag[j - 1];                                           \
+        for (int k_ = 0; k_ < A.nr; ++k_) {                           \
+            pr[k_] = A.off[row_ + k_];                                \
+            aj[k_] = A.adj[row_ + k_];                                \
+        }                                                             \
+    } while (0)
     for (;;) {
         const unsigned long long idle = __ballot(!active);
         if (idle) {
@@ -143,6 +155,7 @@ __global__ __launch_bounds__(kBlock) void k_ssa_walk(SsaDev A, unsigned long lon
                     j = j0;
                     virt = false;
                     for (int s = 0; s < A.ns; ++s) x[s] = A.state[(int64_t)(j - 1) * A.lds + s];
+                    KFSP_SSA_LOAD_ROW();
                     tt = 0.0;
                     npos = 0;
                     active = true;
@@ -158,7 +171,7 @@ __global__ __launch_bounds__(kBlock) void k_ssa_walk(SsaDev A, unsigned long lon
             double r1 = lcg_uniform(rs);
             const double r2 = lcg_uniform(rs);
             if (r1 <= 0.0) r1 = 0x1p-54;
-            double a0;
+            const double wait = -plog(r1);
             if (virt) {
                 a0 = 0.0;
                 for (int k = 0; k < A.nr; ++k) {
@@ -166,16 +179,9 @@ __global__ __launch_bounds__(kBlock) void k_ssa_walk(SsaDev A, unsigned long lon
                     a0 = a0 + pr[k];
                     aj[k] = 0;
                 }
-            } else {
-                const int64_t row = (int64_t)(j - 1) * A.lda;
-                a0 = A.diag[j - 1];
-                for (int k = 0; k < A.nr; ++k) {
-                    pr[k] = A.off[row + k];
-                    aj[k] = A.adj[row + k];
-                }
             }
             if (!(a0 > 0.0)) break;                                // absorbing state
-            tt = fmin(A.tstep, tt + (-plog(r1) / a0));
+            tt = fmin(A.tstep, tt + (wait / a0));
             double acc = pr[0];
             int k = 0;
             const double r2a = fmin(r2 * a0, a0);
@@ -206,6 +212,7 @@ __global__ __launch_bounds__(kBlock) void k_ssa_walk(SsaDev A, unsigned long lon
                 record = true;                                     // x is an unlisted state: recorded below
             }
             if (!(tt < A.tstep)) break;
+            if (!virt) KFSP_SSA_LOAD_ROW();                        // (the next jump's row: on its way while the records are written)
             ended = false;
         } while (false);
         const unsigned long long rmask = __ballot(record);
@@ -226,6 +233,203 @@ __global__ __launch_bounds__(kBlock) void k_ssa_walk(SsaDev A, unsigned long lon
         }
         if (active && ended) active = false;
     }
+}
+
+#undef KFSP_SSA_LOAD_ROW
+
+// The same walk for models of at most NS species and NR reactions (8 and 16 cover every shipped model): all the per-path
+// state - coordinates, the row of the current state - is indexed with compile-time constants only, so it lives in
+// registers (the general kernel above indexes pr[k] / aj[k] / x[s] with run-time values and therefore keeps them in
+// scratch memory: every access a trip to the cache, on the critical path of every jump).  The reaction vectors sit in
+// LDS, one 64-bit word of signed bytes per reaction.  Same arithmetic in the same order: same paths, same records.
+template <int NS>
+__device__ __forceinline__ unsigned hash_regs(const int32_t (&x)[NS], int ns)
+{
+    unsigned long long h = 0x9E3779B97F4A7C15ull;
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+        if (s < ns) {
+            h ^= (unsigned long long)(unsigned)x[s] + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+            h *= 0xBF58476D1CE4E5B9ull;
+            h ^= h >> 29;
+        }
+    return (unsigned)(h ^ (h >> 32));
+}
+
+template <int NS>
+__device__ __forceinline__ int lookup_regs(const SsaDev &A, const int32_t (&y)[NS])
+{
+    unsigned slot = hash_regs<NS>(y, A.ns) & A.tmask;
+    for (;;) {
+        const int e = A.tab[slot];
+        if (e == 0) return 0;
+        const int32_t *z = A.state + (int64_t)(e - 1) * A.lds;
+        bool same = true;
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+            if (s < A.ns) same = same && z[s] == y[s];
+        if (same) return e;
+        slot = (slot + 1) & A.tmask;
+    }
+}
+
+template <int NS, int NR>
+__global__ __launch_bounds__(kBlock) void k_ssa_walk(SsaDev A, unsigned long long *__restrict__ nrec_total, long long cap,
+                                                     unsigned long long *__restrict__ keys, int32_t *__restrict__ rec)
+{
+    static_assert(NS <= 8, "one 64-bit word of signed bytes per reaction");
+    __shared__ unsigned long long s_nu[NR];
+    if (threadIdx.x < NR) {
+        unsigned long long w = 0;
+        if ((int)threadIdx.x < A.nr)
+            for (int s = 0; s < A.ns; ++s) w |= (unsigned long long)(unsigned char)(signed char)A.nu[threadIdx.x * A.ns + s] << (8 * s);
+        s_nu[threadIdx.x] = w;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const long long wave = ((long long)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const long long lo = wave * kSsaSeedsPerWave + 1;              // 1-based seed states of this wave, inclusive
+    if (lo > A.n0) return;
+    const int hi = (int)min((long long)A.n0, lo + kSsaSeedsPerWave - 1);
+    int next = (int)lo;                                            // wave-uniform: the next seed to hand out
+    bool active = false;
+    int j0 = 0, j = 0, npos = 0;
+    bool virt = false;
+    unsigned long long rs = 0;
+    double tt = 0.0, a0 = 0.0;
+    int32_t x[NS];
+    double pr[NR];
+    int32_t aj[NR];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) x[s] = 0;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        pr[k] = 0.0;
+        aj[k] = 0;
+    }
+    // the row of a listed state is REQUESTED as soon as the state is known (when a path starts, and at the end of the
+    // jump that reaches it) and USED after the next jump's random numbers and logarithm have been computed
+#define KFSP_SSA_ROW_REGS()                                                     \
+    do {                                                                        \
+        const int64_t row_ = (int64_t)(j - 1) * A.lda;                          \
+        a0 = A.diag[j - 1];                                                     \
+        _Pragma("unroll") for (int k_ = 0; k_ < NR; ++k_) if (k_ < A.nr) {      \
+            pr[k_] = A.off[row_ + k_];                                          \
+            aj[k_] = A.adj[row_ + k_];                                          \
+        }                                                                       \
+    } while (0)
+    for (;;) {
+        const unsigned long long idle = __ballot(!active);
+        if (idle) {
+            if (!active) {
+                j0 = next + __popcll(idle & ((1ull << lane) - 1ull));
+                if (j0 <= hi) {
+                    rs = (A.seedmix * 2654435761ull) ^ ((unsigned long long)j0 * 40503ull + 12345ull);
+                    rs = ((rs ^ (rs >> 29)) & 4294967295ull) * 1181783497ull;
+                    rs = 1ull + (((rs ^ (rs >> 32)) & 9223372036854775807ull) % (kLcgM - 1ull));
+                    j = j0;
+                    virt = false;
+#pragma unroll
+                    for (int s = 0; s < NS; ++s)
+                        if (s < A.ns) x[s] = A.state[(int64_t)(j - 1) * A.lds + s];
+                    KFSP_SSA_ROW_REGS();
+                    tt = 0.0;
+                    npos = 0;
+                    active = true;
+                }
+            }
+            next += __popcll(idle);
+        }
+        if (!__ballot(active)) break;                              // no path left in this wave
+        bool ended = active, record = false;
+        if (active) do {
+            double r1 = lcg_uniform(rs);
+            const double r2 = lcg_uniform(rs);
+            if (r1 <= 0.0) r1 = 0x1p-54;
+            const double wait = -plog(r1);
+            if (virt) {
+                // (rare: an unlisted state; its propensities come from the program, through memory)
+                int32_t xs[NS];
+                double ps[NR];
+#pragma unroll
+                for (int s = 0; s < NS; ++s) xs[s] = x[s];
+                for (int k = 0; k < A.nr; ++k) ps[k] = prop_eval(A.P, k, xs);
+                a0 = 0.0;
+#pragma unroll
+                for (int k = 0; k < NR; ++k)
+                    if (k < A.nr) {
+                        pr[k] = ps[k];
+                        a0 = a0 + pr[k];
+                        aj[k] = 0;
+                    }
+            }
+            if (!(a0 > 0.0)) break;                                // absorbing state
+            tt = fmin(A.tstep, tt + (wait / a0));
+            // the reaction whose cumulative propensity first reaches r2 a0 (the while loop of the general kernel, unrolled)
+            double acc = pr[0];
+            int k = 0;
+            const double r2a = fmin(r2 * a0, a0);
+#pragma unroll
+            for (int i = 1; i < NR; ++i)
+                if (i < A.nr && k == i - 1 && acc < r2a) {
+                    k = i;
+                    acc = acc + pr[i];
+                }
+            int ajk = 0;
+#pragma unroll
+            for (int i = 0; i < NR; ++i) ajk = i == k ? aj[i] : ajk;
+            const unsigned long long nuw = s_nu[k];
+            int32_t y[NS];
+            bool neg = false;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                y[s] = x[s] + (int)(signed char)(nuw >> (8 * s));   // (species beyond ns: 0 + 0)
+                neg = neg || y[s] < 0;
+            }
+            if (neg) break;
+            int idx = max(ajk, 0);
+            if (idx == 0) {
+                bool legal = true;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) legal = legal && y[s] <= A.max_count;
+                if (!legal) break;
+                idx = lookup_regs<NS>(A, y);
+            }
+#pragma unroll
+            for (int s = 0; s < NS; ++s) x[s] = y[s];
+            if (idx > 0) {
+                j = idx;
+                virt = false;
+                if (j < j0) break;                                 // fell back onto an earlier seed
+            } else {
+                virt = true;
+                record = true;                                     // x is an unlisted state: recorded below
+            }
+            if (!(tt < A.tstep)) break;
+            if (!virt) KFSP_SSA_ROW_REGS();                        // (the next jump's row: on its way while the records are written)
+            ended = false;
+        } while (false);
+        const unsigned long long rmask = __ballot(record);
+        if (rmask) {
+            unsigned long long first = 0;
+            const int leader = __ffsll((long long)rmask) - 1;
+            if (lane == leader) first = atomicAdd(nrec_total, (unsigned long long)__popcll(rmask));
+            first = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(first >> 32), leader) << 32) |
+                    (unsigned)__builtin_amdgcn_readlane((int)first, leader);
+            if (record) {
+                const unsigned long long slot = first + (unsigned long long)__popcll(rmask & ((1ull << lane) - 1ull));
+                if ((long long)slot < cap) {
+                    keys[slot] = ((unsigned long long)(unsigned)j0 << kSsaPosBits) | (unsigned long long)min(npos, (1 << kSsaPosBits) - 1);
+#pragma unroll
+                    for (int s = 0; s < NS; ++s)
+                        if (s < A.ns) rec[slot * A.ns + s] = x[s];
+                }
+                ++npos;
+            }
+        }
+        if (active && ended) active = false;
+    }
+#undef KFSP_SSA_ROW_REGS
 }
 
 // duplicates among the records, visited in the order of their keys (perm[r] = the record of rank r): one table slot
@@ -354,7 +558,10 @@ int ssa_streams_core(kfsp_ctx *ctx, double tstep, int64_t seedmix, int32_t ns, i
         d_keys = a2.take<unsigned long long>((size_t)cap);
         d_rec = a2.take<int32_t>((size_t)cap * ns);
         SSA_TRY(hipMemsetAsync(d_total, 0, sizeof(unsigned long long), st));
-        hipLaunchKernelGGL(k_ssa_walk, dim3(wgrid), dim3(kBlock), 0, st, A, d_total, cap, d_keys, d_rec);
+        if (ns <= 8 && nr <= 16 && !ctx->opt_ssa_general)
+            hipLaunchKernelGGL((k_ssa_walk<8, 16>), dim3(wgrid), dim3(kBlock), 0, st, A, d_total, cap, d_keys, d_rec);
+        else
+            hipLaunchKernelGGL(k_ssa_walk_any, dim3(wgrid), dim3(kBlock), 0, st, A, d_total, cap, d_keys, d_rec);
         unsigned long long got = 0;
         SSA_TRY(hipMemcpyAsync(&got, d_total, sizeof(got), hipMemcpyDeviceToHost, st));
         SSA_TRY(hipStreamSynchronize(st));
