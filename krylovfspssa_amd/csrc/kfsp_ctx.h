@@ -239,6 +239,10 @@ struct kfsp_ctx {
     DevBuf<int32_t> d_prop_i;
     DevBuf<double> d_prop_d;
     bool prop_ready = false;
+    // the program runs through prop_eval_light: whatever the populations / as long as they stay below prop_tab_len (its
+    // library functions sit in tabulated reactions only)
+    bool prop_light = false, prop_light_tab = false;
+    int prop_ncode = 0, prop_nimm = 0;
     int prop_ns = 0, prop_nr = 0, prop_np = 0, prop_np_pad = 1, prop_nimm_pad = 1, prop_tab_len = 0;
 
     // vectors

@@ -62,6 +62,7 @@ int prop_set_program(kfsp_ctx *ctx, int32_t ns, int32_t nr, int32_t np, const do
     ctx->prop_ready = false;
     // the code is checked once, here: every operand exists, the stack never exceeds the kernel's, variables are in range
     const int ncode = code_off[nr], nimm = imm_off[nr];
+    bool light = true, light_tab = true;         // (+ - * / NEG only, shallow: prop_eval_light may run it / all but tabulated reactions)
     for (int k = 0; k < nr; ++k) {
         if (code_off[k + 1] < code_off[k] || imm_off[k + 1] < imm_off[k]) {
             ctx->err = "propensity program: offsets not monotone";
@@ -70,6 +71,10 @@ int prop_set_program(kfsp_ctx *ctx, int32_t ns, int32_t nr, int32_t np, const do
         int sp = 0, ni = 0;
         for (int ip = code_off[k]; ip < code_off[k + 1]; ++ip) {
             const int c = code[ip];
+            if (c == 7 || (c >= 11 && c <= 24)) {
+                light = false;
+                if (tab_species[k] < 0 || tab_len <= 0) light_tab = false;
+            }
             if (c == 1) {
                 ++sp;
                 ++ni;
@@ -84,6 +89,7 @@ int prop_set_program(kfsp_ctx *ctx, int32_t ns, int32_t nr, int32_t np, const do
                 ctx->err = "propensity program: unknown opcode";
                 return -7;
             }
+            if (sp > kPropLightStack) light = light_tab = false;
             if (sp < 0 || sp > kPropStack) {
                 ctx->err = "propensity program: malformed expression or stack deeper than 32";
                 return -7;
@@ -121,6 +127,10 @@ int prop_set_program(kfsp_ctx *ctx, int32_t ns, int32_t nr, int32_t np, const do
     ctx->prop_np_pad = np_pad;
     ctx->prop_nimm_pad = nimm_pad;
     ctx->prop_tab_len = tab_len > 0 ? tab_len : 0;
+    ctx->prop_ncode = ncode;
+    ctx->prop_nimm = nimm;
+    ctx->prop_light = light;
+    ctx->prop_light_tab = light_tab;
     ctx->prop_ready = true;
     return 0;
 }

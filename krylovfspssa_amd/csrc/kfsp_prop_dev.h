@@ -9,6 +9,7 @@
 namespace kfsp {
 
 constexpr int kPropStack = 32;
+constexpr int kPropLightStack = 8;      // deepest stack of a program that may run through prop_eval_light
 
 struct PropDev {
     int ns, nr, np, tab_len;
@@ -78,6 +79,41 @@ __device__ inline double prop_eval(const PropDev &P, int k, const int32_t *__res
     return sp >= 1 ? st[0] : 0.0;
 }
 
+// The same for a program made of + - * / NEG, immediates and variables only (mass action, and everything whose other
+// reactions travel as tables) with a stack of at most kPropLightStack: none of the math library is pulled into the
+// caller, whose register budget stays that of its own loop (the SSA walk runs four times the wavefronts per SIMD with
+// it).  Same operations in the same order: same bits.  prop_set_program decides whether a program qualifies.
+__device__ inline double prop_eval_light(const PropDev &P, int k, const int32_t *__restrict__ x)
+{
+    const int ts = P.tab_species[k];
+    if (ts >= 0) {
+        const int v = x[ts];
+        if (v >= 0 && v < P.tab_len) return P.tab[(int64_t)k * P.tab_len + v];
+    }
+    double st[kPropLightStack];
+    int sp = 0;
+    const double *imm = P.imm + P.imm_off[k];
+    for (int ip = P.code_off[k]; ip < P.code_off[k + 1]; ++ip) {
+        const int c = P.code[ip];
+        switch (c) {
+        case 1: st[sp++] = *imm++; break;
+        case 2: st[sp - 1] = -st[sp - 1]; break;
+        case 3: st[sp - 2] = st[sp - 2] + st[sp - 1]; --sp; break;
+        case 4: st[sp - 2] = st[sp - 2] - st[sp - 1]; --sp; break;
+        case 5: st[sp - 2] = st[sp - 2] * st[sp - 1]; --sp; break;
+        case 6:
+            if (st[sp - 1] == 0.0) return 0.0;
+            st[sp - 2] = st[sp - 2] / st[sp - 1];
+            --sp;
+            break;
+        default: {
+            const int v = c - 101;                                   // 0-based variable
+            st[sp++] = v < P.ns ? (double)x[v] : P.params[v - P.ns];
+        }
+        }
+    }
+    return sp >= 1 ? st[0] : 0.0;
+}
 
 inline PropDev prop_dev(const kfsp_ctx *ctx)
 {

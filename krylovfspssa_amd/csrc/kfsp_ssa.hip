@@ -92,12 +92,23 @@ __device__ __forceinline__ double plog(double x)
 
 constexpr unsigned long long kLcgA = 48271ull, kLcgM = 2147483647ull, kLcgLow = 1073741823ull;
 
+// rs a mod (2^31 - 1) for 1 <= rs < 2^31 - 1 without a division: 2^31 = 1 (mod m), so the product's high part is folded
+// onto its low 31 bits, twice (rs a < 2^47), and one conditional subtraction lands in [0, m) - the value MOD() gives
+// the Fortran host, in a dozen instructions instead of the 64-bit remainder's sixty (four of these per jump)
+__device__ __forceinline__ unsigned long long lcg_next(unsigned long long rs)
+{
+    const unsigned long long p = rs * kLcgA;
+    unsigned long long y = (p & kLcgM) + (p >> 31);
+    y = (y & kLcgM) + (y >> 31);
+    return y >= kLcgM ? y - kLcgM : y;
+}
+
 __device__ __forceinline__ double lcg_uniform(unsigned long long &rs)
 {
     const unsigned long long g1 = rs;
-    rs = (rs * kLcgA) % kLcgM;
+    rs = lcg_next(rs);
     const unsigned long long g2 = rs;
-    rs = (rs * kLcgA) % kLcgM;
+    rs = lcg_next(rs);
     return (double)(((g1 << 30) | ((g2 - 1ull) & kLcgLow)) >> 7) * 0x1p-54;
 }
 
@@ -111,17 +122,23 @@ __device__ __forceinline__ double lcg_uniform(unsigned long long &rs)
 // the path).  Sorting the records by that key afterwards makes their order independent of how the hardware
 // scheduled the paths.
 constexpr int kSsaSeedsPerWave = 256;
+constexpr int kSsaLdsCode = 512, kSsaLdsDbl = 64;      // a light program's code words / immediates and parameters held in LDS
 constexpr int kSsaPosBits = 22;
+constexpr int kSsaChunk = 64;                          // record slots a wavefront takes from the list at a time
+// (an empty slot keeps the key the list was filled with, all ones: it sorts behind every record)
 
 __global__ __launch_bounds__(kBlock) void k_ssa_walk_any(SsaDev A, unsigned long long *__restrict__ nrec_total, long long cap,
                                                      unsigned long long *__restrict__ keys, int32_t *__restrict__ rec)
 {
     const int lane = threadIdx.x & 63;
     const long long wave = ((long long)blockIdx.x * kBlock + threadIdx.x) >> 6;
-    const long long lo = wave * kSsaSeedsPerWave + 1;              // 1-based seed states of this wave, inclusive
-    if (lo > A.n0) return;
-    const int hi = (int)min((long long)A.n0, lo + kSsaSeedsPerWave - 1);
-    int next = (int)lo;                                            // wave-uniform: the next seed to hand out
+    // kSsaSeedsPerWave seeds per wavefront, dealt in blocks of 64 consecutive seed states ROUND ROBIN over the wavefronts:
+    // the long paths start from the first states of the list (nothing earlier to fall back onto), and a wavefront that
+    // owned 256 consecutive ones of them walked four long paths per lane, one after the other, while the rest of the
+    // machine had long finished
+    const long long nwaves = ((long long)A.n0 + kSsaSeedsPerWave - 1) / kSsaSeedsPerWave;
+    if (wave >= nwaves) return;
+    int next = 0;                                                  // wave-uniform: seeds handed out so far
     bool active = false;
     int j0 = 0, j = 0, npos = 0;
     bool virt = false;
@@ -146,8 +163,10 @@ __global__ __launch_bounds__(kBlock) void k_ssa_walk_any(SsaDev A, unsigned long
         const unsigned long long idle = __ballot(!active);
         if (idle) {
             if (!active) {
-                j0 = next + __popcll(idle & ((1ull << lane) - 1ull));
-                if (j0 <= hi) {
+                const int t = next + __popcll(idle & ((1ull << lane) - 1ull));
+                const long long seed = ((((long long)(t >> 6)) * nwaves + wave) << 6) + (t & 63) + 1;
+                if (t < kSsaSeedsPerWave && seed <= A.n0) {
+                    j0 = (int)seed;
                     // the path's own stream: a 64-bit mix of (call, seed state) folded into the generator's range
                     rs = (A.seedmix * 2654435761ull) ^ ((unsigned long long)j0 * 40503ull + 12345ull);
                     rs = ((rs ^ (rs >> 29)) & 4294967295ull) * 1181783497ull;
@@ -219,7 +238,10 @@ __global__ __launch_bounds__(kBlock) void k_ssa_walk_any(SsaDev A, unsigned long
         if (rmask) {
             unsigned long long first = 0;
             const int leader = __ffsll((long long)rmask) - 1;
-            if (lane == leader) first = atomicAdd(nrec_total, (unsigned long long)__popcll(rmask));
+            if (lane == leader) {
+                first = atomicAdd(nrec_total, (unsigned long long)__popcll(rmask));
+                atomicAdd(nrec_total + 1, (unsigned long long)__popcll(rmask));      // (no empty slots in this kernel's list)
+            }
             first = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(first >> 32), leader) << 32) |
                     (unsigned)__builtin_amdgcn_readlane((int)first, leader);
             if (record) {
@@ -273,7 +295,7 @@ __device__ __forceinline__ int lookup_regs(const SsaDev &A, const int32_t (&y)[N
     }
 }
 
-template <int NS, int NR>
+template <int NS, int NR, bool LIGHT>
 __global__ __launch_bounds__(kBlock) void k_ssa_walk(SsaDev A, unsigned long long *__restrict__ nrec_total, long long cap,
                                                      unsigned long long *__restrict__ keys, int32_t *__restrict__ rec)
 {
@@ -285,13 +307,40 @@ __global__ __launch_bounds__(kBlock) void k_ssa_walk(SsaDev A, unsigned long lon
             for (int s = 0; s < A.ns; ++s) w |= (unsigned long long)(unsigned char)(signed char)A.nu[threadIdx.x * A.ns + s] << (8 * s);
         s_nu[threadIdx.x] = w;
     }
+    // a light program is small (kSsaLds* bound it): its code, immediates and parameters are read from LDS - an unlisted
+    // state costs nr passes through the interpreter, every opcode a dependent load, and the whole wavefront waits for it
+    __shared__ int32_t s_code[LIGHT ? kSsaLdsCode : 1], s_ioff[LIGHT ? 3 * (NR + 1) : 1];
+    __shared__ double s_dbl[LIGHT ? 2 * kSsaLdsDbl : 1];
+    PropDev P = A.P;
+    if (LIGHT) {
+        const int ncode = A.P.code_off[A.nr], nimm = A.P.imm_off[A.nr];
+        for (int i = threadIdx.x; i < ncode; i += kBlock) s_code[i] = A.P.code[i];
+        for (int i = threadIdx.x; i <= A.nr; i += kBlock) {
+            s_ioff[i] = A.P.code_off[i];
+            s_ioff[NR + 1 + i] = A.P.imm_off[i];
+            if (i < A.nr) s_ioff[2 * (NR + 1) + i] = A.P.tab_species[i];
+        }
+        for (int i = threadIdx.x; i < nimm; i += kBlock) s_dbl[i] = A.P.imm[i];
+        for (int i = threadIdx.x; i < A.P.np; i += kBlock) s_dbl[kSsaLdsDbl + i] = A.P.params[i];
+        P.code = s_code;
+        P.code_off = s_ioff;
+        P.imm_off = s_ioff + (NR + 1);
+        P.tab_species = s_ioff + 2 * (NR + 1);
+        P.imm = s_dbl;
+        P.params = s_dbl + kSsaLdsDbl;
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const long long wave = ((long long)blockIdx.x * kBlock + threadIdx.x) >> 6;
-    const long long lo = wave * kSsaSeedsPerWave + 1;              // 1-based seed states of this wave, inclusive
-    if (lo > A.n0) return;
-    const int hi = (int)min((long long)A.n0, lo + kSsaSeedsPerWave - 1);
-    int next = (int)lo;                                            // wave-uniform: the next seed to hand out
+    // kSsaSeedsPerWave seeds per wavefront, dealt in blocks of 64 consecutive seed states ROUND ROBIN over the wavefronts:
+    // the long paths start from the first states of the list (nothing earlier to fall back onto), and a wavefront that
+    // owned 256 consecutive ones of them walked four long paths per lane, one after the other, while the rest of the
+    // machine had long finished
+    const long long nwaves = ((long long)A.n0 + kSsaSeedsPerWave - 1) / kSsaSeedsPerWave;
+    if (wave >= nwaves) return;
+    int next = 0;                                                  // wave-uniform: seeds handed out so far
+    unsigned long long cbase = 0;                                  // wave-uniform: the wavefront's chunk of the record list
+    int cleft = 0, nvalid = 0;
     bool active = false;
     int j0 = 0, j = 0, npos = 0;
     bool virt = false;
@@ -322,8 +371,10 @@ __global__ __launch_bounds__(kBlock) void k_ssa_walk(SsaDev A, unsigned long lon
         const unsigned long long idle = __ballot(!active);
         if (idle) {
             if (!active) {
-                j0 = next + __popcll(idle & ((1ull << lane) - 1ull));
-                if (j0 <= hi) {
+                const int t = next + __popcll(idle & ((1ull << lane) - 1ull));
+                const long long seed = ((((long long)(t >> 6)) * nwaves + wave) << 6) + (t & 63) + 1;
+                if (t < kSsaSeedsPerWave && seed <= A.n0) {
+                    j0 = (int)seed;
                     rs = (A.seedmix * 2654435761ull) ^ ((unsigned long long)j0 * 40503ull + 12345ull);
                     rs = ((rs ^ (rs >> 29)) & 4294967295ull) * 1181783497ull;
                     rs = 1ull + (((rs ^ (rs >> 32)) & 9223372036854775807ull) % (kLcgM - 1ull));
@@ -353,7 +404,7 @@ __global__ __launch_bounds__(kBlock) void k_ssa_walk(SsaDev A, unsigned long lon
                 double ps[NR];
 #pragma unroll
                 for (int s = 0; s < NS; ++s) xs[s] = x[s];
-                for (int k = 0; k < A.nr; ++k) ps[k] = prop_eval(A.P, k, xs);
+                for (int k = 0; k < A.nr; ++k) ps[k] = LIGHT ? prop_eval_light(P, k, xs) : prop_eval(A.P, k, xs);
                 a0 = 0.0;
 #pragma unroll
                 for (int k = 0; k < NR; ++k)
@@ -411,11 +462,21 @@ __global__ __launch_bounds__(kBlock) void k_ssa_walk(SsaDev A, unsigned long lon
         } while (false);
         const unsigned long long rmask = __ballot(record);
         if (rmask) {
-            unsigned long long first = 0;
-            const int leader = __ffsll((long long)rmask) - 1;
-            if (lane == leader) first = atomicAdd(nrec_total, (unsigned long long)__popcll(rmask));
-            first = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(first >> 32), leader) << 32) |
-                    (unsigned)__builtin_amdgcn_readlane((int)first, leader);
+            // room for this jump's records: the wavefront takes slots of the list kSsaChunk at a time (ONE counter serves
+            // all wavefronts, and an atomic per recording jump - 1e5 of them per call on one address - was what the kernel
+            // waited for); what is left of a chunk when the next one is taken, or at the end, stays empty (its key keeps the all-ones fill)
+            const int c = __popcll(rmask);
+            if (c > cleft) {
+                unsigned long long first = 0;
+                if (lane == 0) first = atomicAdd(nrec_total, (unsigned long long)kSsaChunk);
+                cbase = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(first >> 32)) << 32) |
+                        (unsigned)__builtin_amdgcn_readfirstlane((int)first);
+                cleft = kSsaChunk;
+            }
+            const unsigned long long first = cbase;
+            cbase += (unsigned long long)c;
+            cleft -= c;
+            nvalid += c;
             if (record) {
                 const unsigned long long slot = first + (unsigned long long)__popcll(rmask & ((1ull << lane) - 1ull));
                 if ((long long)slot < cap) {
@@ -429,6 +490,7 @@ __global__ __launch_bounds__(kBlock) void k_ssa_walk(SsaDev A, unsigned long lon
         }
         if (active && ended) active = false;
     }
+    if (lane == 0 && nvalid > 0) atomicAdd(nrec_total + 1, (unsigned long long)nvalid);
 #undef KFSP_SSA_ROW_REGS
 }
 
@@ -546,10 +608,12 @@ int ssa_streams_core(kfsp_ctx *ctx, double tstep, int64_t seedmix, int32_t ns, i
     A.tab = d_tab;
     A.tmask = slots - 1;
     A.P = prop_dev(ctx);
+    const bool fast = ns <= 8 && nr <= 16 && !ctx->opt_ssa_general;
     // one wavefront per kSsaSeedsPerWave seed states (4 wavefronts per workgroup); the record list is sized by a guess
     // and, should the paths meet more unlisted states than that, by the count the first attempt returns
     const int wgrid = (int)(((long long)n + 4 * kSsaSeedsPerWave - 1) / (4 * kSsaSeedsPerWave));
-    long long cap = std::max<long long>((long long)1 << 18, (long long)n / 2), nrec = 0;
+    // (the register-resident kernel leaves up to kSsaChunk - 1 slots empty per wavefront and chunk change)
+    long long cap = std::max<long long>((long long)1 << 18, (long long)n), nrec = 0, nvalid = 0;
     unsigned long long *d_keys = nullptr;
     int32_t *d_rec = nullptr;
     for (int attempt = 0; attempt < 2; ++attempt) {
@@ -557,15 +621,22 @@ int ssa_streams_core(kfsp_ctx *ctx, double tstep, int64_t seedmix, int32_t ns, i
         Arena a2{ctx->d_os4.p};
         d_keys = a2.take<unsigned long long>((size_t)cap);
         d_rec = a2.take<int32_t>((size_t)cap * ns);
-        SSA_TRY(hipMemsetAsync(d_total, 0, sizeof(unsigned long long), st));
-        if (ns <= 8 && nr <= 16 && !ctx->opt_ssa_general)
-            hipLaunchKernelGGL((k_ssa_walk<8, 16>), dim3(wgrid), dim3(kBlock), 0, st, A, d_total, cap, d_keys, d_rec);
+        SSA_TRY(hipMemsetAsync(d_total, 0, 2 * sizeof(unsigned long long), st));
+        SSA_TRY(hipMemsetAsync(d_keys, 0xff, (size_t)cap * 8, st));
+        // (the program's library functions, if any, sit behind tables that cover every population a legal state can have)
+        const bool light = (ctx->prop_light || (ctx->prop_light_tab && ctx->prop_tab_len > max_count)) && ctx->prop_ncode <= kSsaLdsCode &&
+                           ctx->prop_nimm <= kSsaLdsDbl && ctx->prop_np <= kSsaLdsDbl;
+        if (fast && light)
+            hipLaunchKernelGGL((k_ssa_walk<8, 16, true>), dim3(wgrid), dim3(kBlock), 0, st, A, d_total, cap, d_keys, d_rec);
+        else if (fast)
+            hipLaunchKernelGGL((k_ssa_walk<8, 16, false>), dim3(wgrid), dim3(kBlock), 0, st, A, d_total, cap, d_keys, d_rec);
         else
             hipLaunchKernelGGL(k_ssa_walk_any, dim3(wgrid), dim3(kBlock), 0, st, A, d_total, cap, d_keys, d_rec);
-        unsigned long long got = 0;
-        SSA_TRY(hipMemcpyAsync(&got, d_total, sizeof(got), hipMemcpyDeviceToHost, st));
+        unsigned long long got[2] = {0, 0};
+        SSA_TRY(hipMemcpyAsync(got, d_total, sizeof(got), hipMemcpyDeviceToHost, st));
         SSA_TRY(hipStreamSynchronize(st));
-        nrec = (long long)got;
+        nrec = (long long)got[0];                                   // slots taken (empty ones included)
+        nvalid = (long long)got[1];                                 // records
         if (nrec <= cap) break;
         if (attempt == 1 || nrec > 2000000000LL) {
             ctx->err = "SSA paths met more unlisted states than the record list holds";
@@ -576,17 +647,17 @@ int ssa_streams_core(kfsp_ctx *ctx, double tstep, int64_t seedmix, int32_t ns, i
     *n_found = 0;
     *sn = nullptr;
     *on = *dn = nullptr;
-    if (nrec == 0) return 0;
-    // the records in (seed state, position) order, duplicates removed (first occurrence stays)
+    if (nvalid == 0) return 0;
+    // the records in (seed state, position) order (empty slots sort behind them), duplicates removed (first occurrence stays)
     unsigned slots2 = 64;
-    while (slots2 < 2u * (unsigned)nrec) slots2 <<= 1;
-    const size_t need3 = (size_t)nrec * (8 + 4 + 4 + 4 + 1) + (size_t)slots2 * 8 + 4096 + 10 * 256;
+    while (slots2 < 2u * (unsigned)nvalid) slots2 <<= 1;
+    const size_t need3 = (size_t)nrec * (8 + 4 + 4) + (size_t)nvalid * (4 + 1) + (size_t)slots2 * 8 + 4096 + 10 * 256;
     SSA_TRY(ctx->d_os3.reserve(need3, false));
     Arena a3x{ctx->d_os3.p};
     unsigned long long *d_keys2 = a3x.take<unsigned long long>((size_t)nrec);
-    int32_t *d_iota = a3x.take<int32_t>((size_t)nrec), *d_perm = a3x.take<int32_t>((size_t)nrec), *d_sel = a3x.take<int32_t>((size_t)nrec);
+    int32_t *d_iota = a3x.take<int32_t>((size_t)nrec), *d_perm = a3x.take<int32_t>((size_t)nrec), *d_sel = a3x.take<int32_t>((size_t)nvalid);
     int32_t *d_tab2 = a3x.take<int32_t>(slots2), *d_min = a3x.take<int32_t>(slots2);
-    uint8_t *d_first = a3x.take<uint8_t>((size_t)nrec);
+    uint8_t *d_first = a3x.take<uint8_t>((size_t)nvalid);
     int *d_nsel = a3x.take<int>(4);
     hipLaunchKernelGGL(k_iota, dim3(blocks(nrec)), dim3(kBlock), 0, st, nrec, d_iota);
     size_t tmp_bytes = 0;
@@ -595,12 +666,12 @@ int ssa_streams_core(kfsp_ctx *ctx, double tstep, int64_t seedmix, int32_t ns, i
     SSA_TRY(hipcub::DeviceRadixSort::SortPairs(ctx->d_sorttmp.p, tmp_bytes, d_keys, d_keys2, d_iota, d_perm, (int)nrec, 0, 31 + kSsaPosBits, st));
     SSA_TRY(hipMemsetAsync(d_tab2, 0, (size_t)slots2 * 4, st));
     SSA_TRY(hipMemsetAsync(d_min, 0x7f, (size_t)slots2 * 4, st));
-    SSA_TRY(hipMemsetAsync(d_first, 0, (size_t)nrec, st));
-    hipLaunchKernelGGL(k_rec_insert, dim3(blocks(nrec)), dim3(kBlock), 0, st, nrec, ns, d_rec, d_perm, d_tab2, d_min, slots2 - 1);
+    SSA_TRY(hipMemsetAsync(d_first, 0, (size_t)nvalid, st));
+    hipLaunchKernelGGL(k_rec_insert, dim3(blocks(nvalid)), dim3(kBlock), 0, st, nvalid, ns, d_rec, d_perm, d_tab2, d_min, slots2 - 1);
     hipLaunchKernelGGL(k_rec_first, dim3(blocks(slots2)), dim3(kBlock), 0, st, slots2, d_tab2, d_min, d_first);
-    SSA_TRY(hipcub::DeviceSelect::Flagged(nullptr, tmp_bytes, d_iota, d_first, d_sel, d_nsel, (int)nrec, st));
+    SSA_TRY(hipcub::DeviceSelect::Flagged(nullptr, tmp_bytes, d_iota, d_first, d_sel, d_nsel, (int)nvalid, st));
     SSA_TRY(ctx->d_sorttmp.reserve(tmp_bytes + 256, false));
-    SSA_TRY(hipcub::DeviceSelect::Flagged(ctx->d_sorttmp.p, tmp_bytes, d_iota, d_first, d_sel, d_nsel, (int)nrec, st));
+    SSA_TRY(hipcub::DeviceSelect::Flagged(ctx->d_sorttmp.p, tmp_bytes, d_iota, d_first, d_sel, d_nsel, (int)nvalid, st));
     int nnew = 0;
     SSA_TRY(hipMemcpyAsync(&nnew, d_nsel, sizeof(int), hipMemcpyDeviceToHost, st));
     SSA_TRY(hipStreamSynchronize(st));
