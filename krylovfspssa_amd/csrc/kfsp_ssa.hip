@@ -133,9 +133,10 @@ __global__ __launch_bounds__(kBlock) void k_ssa_walk_any(SsaDev A, unsigned long
     const int lane = threadIdx.x & 63;
     const long long wave = ((long long)blockIdx.x * kBlock + threadIdx.x) >> 6;
     // kSsaSeedsPerWave seeds per wavefront, dealt in blocks of 64 consecutive seed states ROUND ROBIN over the wavefronts:
-    // the long paths start from the first states of the list (nothing earlier to fall back onto), and a wavefront that
-    // owned 256 consecutive ones of them walked four long paths per lane, one after the other, while the rest of the
-    // machine had long finished
+    // the long paths start from neighbouring states (measured: the LAST states of the list, the FSP's rim - they step
+    // outside and walk through unlisted states to the horizon, hundreds of jumps, while a path from an inner state falls
+    // back onto an earlier seed after a handful), and a wavefront that owned 256 consecutive ones of them walked four
+    // long paths per lane, one after the other
     const long long nwaves = ((long long)A.n0 + kSsaSeedsPerWave - 1) / kSsaSeedsPerWave;
     if (wave >= nwaves) return;
     int next = 0;                                                  // wave-uniform: seeds handed out so far
@@ -333,9 +334,10 @@ __global__ __launch_bounds__(kBlock) void k_ssa_walk(SsaDev A, unsigned long lon
     const int lane = threadIdx.x & 63;
     const long long wave = ((long long)blockIdx.x * kBlock + threadIdx.x) >> 6;
     // kSsaSeedsPerWave seeds per wavefront, dealt in blocks of 64 consecutive seed states ROUND ROBIN over the wavefronts:
-    // the long paths start from the first states of the list (nothing earlier to fall back onto), and a wavefront that
-    // owned 256 consecutive ones of them walked four long paths per lane, one after the other, while the rest of the
-    // machine had long finished
+    // the long paths start from neighbouring states (measured: the LAST states of the list, the FSP's rim - they step
+    // outside and walk through unlisted states to the horizon, hundreds of jumps, while a path from an inner state falls
+    // back onto an earlier seed after a handful), and a wavefront that owned 256 consecutive ones of them walked four
+    // long paths per lane, one after the other
     const long long nwaves = ((long long)A.n0 + kSsaSeedsPerWave - 1) / kSsaSeedsPerWave;
     if (wave >= nwaves) return;
     int next = 0;                                                  // wave-uniform: seeds handed out so far
