@@ -628,7 +628,12 @@ int ssa_streams_core(kfsp_ctx *ctx, double tstep, int64_t seedmix, int32_t ns, i
         // (the program's library functions, if any, sit behind tables that cover every population a legal state can have)
         const bool light = (ctx->prop_light || (ctx->prop_light_tab && ctx->prop_tab_len > max_count)) && ctx->prop_ncode <= kSsaLdsCode &&
                            ctx->prop_nimm <= kSsaLdsDbl && ctx->prop_np <= kSsaLdsDbl;
-        if (fast && light)
+        // (the unrolled per-path code is as long as its bounds: the smallest instance that holds the model)
+        if (fast && light && ns <= 2 && nr <= 4)
+            hipLaunchKernelGGL((k_ssa_walk<2, 4, true>), dim3(wgrid), dim3(kBlock), 0, st, A, d_total, cap, d_keys, d_rec);
+        else if (fast && light && ns <= 6 && nr <= 12)
+            hipLaunchKernelGGL((k_ssa_walk<6, 12, true>), dim3(wgrid), dim3(kBlock), 0, st, A, d_total, cap, d_keys, d_rec);
+        else if (fast && light)
             hipLaunchKernelGGL((k_ssa_walk<8, 16, true>), dim3(wgrid), dim3(kBlock), 0, st, A, d_total, cap, d_keys, d_rec);
         else if (fast)
             hipLaunchKernelGGL((k_ssa_walk<8, 16, false>), dim3(wgrid), dim3(kBlock), 0, st, A, d_total, cap, d_keys, d_rec);
