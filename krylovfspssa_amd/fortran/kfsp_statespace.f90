@@ -91,7 +91,7 @@ MODULE STATESPACE
   ! ONESTEP_EXTENDER's integer work on the device (kfsp_onestep, include/kfsp.h): set by the solver
   ! module once it holds a device context; used for lists of at least ONESTEP_DEVICE_MIN states
   ! (environment KFSP_DEVICE_ONESTEP_MIN, default 20000; KFSP_DEVICE_ONESTEP=0 switches it off).
-  ! Returns 0, -9 (state keys need more than 63 bits: the host sweep runs instead) or -11 (capacity).
+  ! Returns 0, -9 (more than 2^31 (state, reaction) pairs: the host sweep runs instead) or -11 (capacity).
   ABSTRACT INTERFACE
      INTEGER FUNCTION ONESTEP_DEVICE_FN(NS, NR, STOICH, N, STATE, ADJ, MAXCOUNT, CAP, NNEW, OFFDIAG, DIAG, COLUMNS)
        INTEGER, INTENT(IN) :: NS, NR, N, MAXCOUNT, CAP
@@ -707,7 +707,7 @@ CONTAINS
     RC = ONESTEP_DEVICE(SD, PD, MODEL%STOICHIOMETRY(1:SD, 1:PD), N0, FSP%STATE, FSP%MATRIX%ADJ, MAXNUMBERMOLECULES, &
          FSP%MAX_SIZE - 1, NNEW, FSP%MATRIX%OFFDIAG, FSP%MATRIX%DIAG, COLUMNS)
     IF (RC == -11) STOP 'OVERFLOW ERROR: FSP SIZE EXCEEDS MEMORY LIMIT.'
-    IF (RC /= 0) RETURN                      ! (-9: keys too wide) the host sweep takes over
+    IF (RC /= 0) RETURN                      ! (-9: too many (state, reaction) pairs for 32-bit ordinals) the host sweep takes over
     CALL TICK(1, TCLK)
     DONE = .TRUE.
     IF (NNEW == N0) RETURN
