@@ -243,6 +243,7 @@ struct kfsp_ctx {
     // library functions sit in tabulated reactions only)
     bool prop_light = false, prop_light_tab = false;
     int prop_ncode = 0, prop_nimm = 0;
+    size_t prop_mono_off = 0, prop_monoc_off = 0;      // where the product-chain tables sit in d_prop_i / d_prop_d
     int prop_ns = 0, prop_nr = 0, prop_np = 0, prop_np_pad = 1, prop_nimm_pad = 1, prop_tab_len = 0;
 
     // vectors

@@ -104,6 +104,38 @@ int prop_set_program(kfsp_ctx *ctx, int32_t ns, int32_t nr, int32_t np, const do
             return -10;
         }
     }
+    // product chains  o_1 o_2 MUL o_3 MUL ...  of species, parameters and immediates (mass action) skip the interpreter
+    std::vector<int32_t> mono((size_t)nr * (1 + kPropMonoOps), 0);
+    std::vector<double> mono_c((size_t)nr * kPropMonoOps, 0.0);
+    for (int k = 0; k < nr; ++k) {
+        int32_t *m = mono.data() + (size_t)k * (1 + kPropMonoOps);
+        double *mc = mono_c.data() + (size_t)k * kPropMonoOps;
+        int n = 0, ii = imm_off[k];
+        bool ok = code_off[k + 1] > code_off[k];
+        for (int ip = code_off[k]; ok && ip < code_off[k + 1]; ++ip) {
+            const int c = code[ip];
+            // positions: 0 operand, 1 operand, 2 MUL, 3 operand, 4 MUL, ...
+            const int pos = ip - code_off[k];
+            if (pos == 0 || pos % 2 == 1) {
+                if (n >= kPropMonoOps) ok = false;
+                else if (c == 1) {
+                    m[1 + n] = -1;
+                    mc[n] = imm[ii++];
+                    ++n;
+                } else if (c >= 101 && c <= 100 + ns) {
+                    m[1 + n] = c - 101;
+                    ++n;
+                } else if (c > 100 + ns && c <= 100 + ns + np) {
+                    m[1 + n] = -1;
+                    mc[n] = params[c - 101 - ns];
+                    ++n;
+                } else ok = false;
+            } else if (c != 5) ok = false;
+        }
+        const int len = code_off[k + 1] - code_off[k];
+        if (ok && (len == 1 || (len >= 3 && len % 2 == 1)) && n == (len + 1) / 2) m[0] = n;
+        else m[0] = 0;
+    }
     hipStream_t st = ctx->stream;
     std::vector<int32_t> ib((size_t)(2 * (nr + 1) + nr + std::max(ncode, 1)));
     std::memcpy(ib.data(), code_off, sizeof(int32_t) * (size_t)(nr + 1));
@@ -116,6 +148,10 @@ int prop_set_program(kfsp_ctx *ctx, int32_t ns, int32_t nr, int32_t np, const do
     if (np > 0) std::memcpy(db.data(), params, sizeof(double) * (size_t)np);
     if (nimm > 0) std::memcpy(db.data() + np_pad, imm, sizeof(double) * (size_t)nimm);
     if (ntab > 0) std::memcpy(db.data() + np_pad + nimm_pad, tab, sizeof(double) * ntab);
+    ctx->prop_mono_off = ib.size();
+    ib.insert(ib.end(), mono.begin(), mono.end());
+    ctx->prop_monoc_off = db.size();
+    db.insert(db.end(), mono_c.begin(), mono_c.end());
     HIP_TRY_P(ctx->d_prop_i.reserve(ib.size(), false));
     HIP_TRY_P(ctx->d_prop_d.reserve(db.size(), false));
     HIP_TRY_P(hipMemcpyAsync(ctx->d_prop_i.p, ib.data(), ib.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));

@@ -11,14 +11,36 @@ namespace kfsp {
 constexpr int kPropStack = 32;
 constexpr int kPropLightStack = 8;      // deepest stack of a program that may run through prop_eval_light
 
+constexpr int kPropMonoOps = 4;         // a product chain of at most this many operands is evaluated without the interpreter
+
 struct PropDev {
     int ns, nr, np, tab_len;
     const int32_t *code_off, *code, *imm_off, *tab_species;
     const double *imm, *params, *tab;
+    // reaction k is a plain product  o_1 * o_2 * ... * o_n  (mass action: c X Y): mono[k][0] = n (0: it is not),
+    // mono[k][i] = species of operand i or -1 for a constant, whose value is mono_c[k][i - 1]
+    const int32_t *mono;                // [nr][1 + kPropMonoOps]
+    const double *mono_c;               // [nr][kPropMonoOps]
 };
+
+// ((o_1 * o_2) * o_3) ... : the multiplications of the postfix code  o_1 o_2 MUL o_3 MUL ...  in its order - same bits
+__device__ __forceinline__ double prop_mono(const PropDev &P, int k, int n, const int32_t *__restrict__ x)
+{
+    const int32_t *m = P.mono + k * (1 + kPropMonoOps);
+    const double *c = P.mono_c + k * kPropMonoOps;
+    double v = m[1] < 0 ? c[0] : (double)x[m[1]];
+    for (int i = 1; i < n; ++i) v = v * (m[1 + i] < 0 ? c[i] : (double)x[m[1 + i]]);
+    return v;
+}
 
 __device__ inline double prop_eval(const PropDev &P, int k, const int32_t *__restrict__ x)
 {
+    // (a product chain first: c X from two registers beats the host-made table's trip to memory, and is the same bits -
+    // the table entry IS that product, made by the host's interpreter)
+    {
+        const int n = P.mono[k * (1 + kPropMonoOps)];
+        if (n > 0) return prop_mono(P, k, n, x);
+    }
     const int ts = P.tab_species[k];
     if (ts >= 0) {
         const int v = x[ts];
@@ -85,6 +107,12 @@ __device__ inline double prop_eval(const PropDev &P, int k, const int32_t *__res
 // it).  Same operations in the same order: same bits.  prop_set_program decides whether a program qualifies.
 __device__ inline double prop_eval_light(const PropDev &P, int k, const int32_t *__restrict__ x)
 {
+    // (a product chain first: c X from two registers beats the host-made table's trip to memory, and is the same bits -
+    // the table entry IS that product, made by the host's interpreter)
+    {
+        const int n = P.mono[k * (1 + kPropMonoOps)];
+        if (n > 0) return prop_mono(P, k, n, x);
+    }
     const int ts = P.tab_species[k];
     if (ts >= 0) {
         const int v = x[ts];
@@ -131,6 +159,8 @@ inline PropDev prop_dev(const kfsp_ctx *ctx)
     P.params = db;
     P.imm = db + ctx->prop_np_pad;
     P.tab = db + ctx->prop_np_pad + ctx->prop_nimm_pad;
+    P.mono = ib + ctx->prop_mono_off;
+    P.mono_c = db + ctx->prop_monoc_off;
     return P;
 }
 

@@ -311,7 +311,8 @@ __global__ __launch_bounds__(kBlock) void k_ssa_walk(SsaDev A, unsigned long lon
     // a light program is small (kSsaLds* bound it): its code, immediates and parameters are read from LDS - an unlisted
     // state costs nr passes through the interpreter, every opcode a dependent load, and the whole wavefront waits for it
     __shared__ int32_t s_code[LIGHT ? kSsaLdsCode : 1], s_ioff[LIGHT ? 3 * (NR + 1) : 1];
-    __shared__ double s_dbl[LIGHT ? 2 * kSsaLdsDbl : 1];
+    __shared__ double s_dbl[LIGHT ? 2 * kSsaLdsDbl + NR * kPropMonoOps : 1];
+    __shared__ int32_t s_mono[LIGHT ? NR * (1 + kPropMonoOps) : 1];
     PropDev P = A.P;
     if (LIGHT) {
         const int ncode = A.P.code_off[A.nr], nimm = A.P.imm_off[A.nr];
@@ -323,6 +324,10 @@ __global__ __launch_bounds__(kBlock) void k_ssa_walk(SsaDev A, unsigned long lon
         }
         for (int i = threadIdx.x; i < nimm; i += kBlock) s_dbl[i] = A.P.imm[i];
         for (int i = threadIdx.x; i < A.P.np; i += kBlock) s_dbl[kSsaLdsDbl + i] = A.P.params[i];
+        for (int i = threadIdx.x; i < A.nr * (1 + kPropMonoOps); i += kBlock) s_mono[i] = A.P.mono[i];
+        for (int i = threadIdx.x; i < A.nr * kPropMonoOps; i += kBlock) s_dbl[2 * kSsaLdsDbl + i] = A.P.mono_c[i];
+        P.mono = s_mono;
+        P.mono_c = s_dbl + 2 * kSsaLdsDbl;
         P.code = s_code;
         P.code_off = s_ioff;
         P.imm_off = s_ioff + (NR + 1);
