@@ -327,8 +327,11 @@ int kfsp_ssa_streams(kfsp_ctx *ctx, double timestep, int64_t seedmix, int32_t ns
  * rule of kfsp_set_state_coords) is rebuilt from the grown arrays, the resident w gets zeros for the appended states
  * (:530-533).  Nothing crosses the bus but counters; the same states in the same order, the same links and columns as
  * the two calls above give on host copies of the lists (tests/test_gpu_expand.py).  *n_new = states afterwards,
- * *n_from_ssa (may be null) = those the walk appended.  One context, no communicator (-9 otherwise, and when the
- * arrays or coordinates of the current FSP are not resident); -11 when more than `capacity` states would be listed.
+ * *n_from_ssa (may be null) = those the walk appended.  -9 when the arrays or coordinates of the current FSP are not
+ * resident; -11 when more than `capacity` states would be listed.  Under a row partition (all ranks call; a group
+ * context does it for them) every rank holds the whole lists and expands them redundantly - deterministic kernels,
+ * identical results, nothing to exchange but the vector, which is assembled in the caller's order (one all-gather) and
+ * dealt out again in the new partition - and rebuilds its own row block.
  * A caller that keeps its own copy of the lists refreshes it with kfsp_download_fsp when it needs it. */
 int kfsp_expand_resident(kfsp_ctx *ctx, double t_ssa, int64_t seedmix, int32_t ns, int32_t nr, const int32_t *stoich,
                          int32_t max_count, int32_t capacity, int64_t *n_new, int64_t *n_from_ssa);

@@ -2061,12 +2061,14 @@ int kfsp_expand_resident(kfsp_ctx *ctx, double t_ssa, int64_t seedmix, int32_t n
 {
     return no_throw(ctx, [&]() -> int {
         if (!ctx) return -1;
-        if (ctx->group || ctx->use_comm) return fail(ctx, -9, "the resident expansion runs on one context without a communicator");
         if (ns < 1 || ns > 16) return fail(ctx, -4, "1 <= ns <= 16");
         if (nr < 1 || nr > 64) return fail(ctx, -5, "1 <= nr <= 64");
         if (!stoich) return fail(ctx, -6, "null stoich");
         if (max_count < 1) return fail(ctx, -7, "max_count < 1");
         if (!n_new) return fail(ctx, -9, "null n_new");
+        // (under a row partition every rank holds the WHOLE lists and expands them redundantly - same input, deterministic
+        // kernels, same output - and rebuilds its own block; the vector is assembled and re-dealt through the communicator)
+        if (ctx->group) return kfsp::group_expand_resident(ctx, t_ssa, seedmix, ns, nr, stoich, max_count, capacity, n_new, n_from_ssa);
         const int64_t n = ctx->n;
         if (ctx->use_box || ctx->opt_host_build || ctx->w_pending || n < 1 || ctx->ell_cols != n || ctx->ell_bw != nr)
             return fail(ctx, -9, "the reference arrays of the current FSP are not resident on the device (kfsp_set_matrix_ell)");

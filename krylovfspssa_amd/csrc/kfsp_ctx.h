@@ -337,6 +337,8 @@ int group_spmv_bench(kfsp_ctx *h, int reps, int variant, float *ms_total);
 int group_get_timers(kfsp_ctx *h, double *ms, int reset);
 int group_layout_info(const kfsp_ctx *h, int64_t *v);
 int group_drop_rebuild(kfsp_ctx *h);
+int group_expand_resident(kfsp_ctx *h, double t_ssa, int64_t seedmix, int32_t ns, int32_t nr, const int32_t *stoich, int32_t max_count,
+                          int32_t capacity, int64_t *n_new, int64_t *n_from_ssa);
 int group_update_state_coords(kfsp_ctx *h, int32_t n, int32_t ns, int32_t ld, const int32_t *state, int32_t n_unchanged);
 int group_set_propensity_program(kfsp_ctx *h, int32_t ns, int32_t nr, int32_t np, const double *params, const int32_t *code_off,
                                  const int32_t *code, const int32_t *imm_off, const double *imm, const int32_t *tab_species,

@@ -404,6 +404,24 @@ int group_drop_rebuild(kfsp_ctx *h)
     return after_matrix(h, rc, n);
 }
 
+int group_expand_resident(kfsp_ctx *h, double t_ssa, int64_t seedmix, int32_t ns, int32_t nr, const int32_t *stoich, int32_t max_count,
+                          int32_t capacity, int64_t *n_new, int64_t *n_from_ssa)
+{
+    Group *g = h->group;
+    std::vector<int64_t> nn((size_t)g->n, 0), ns_((size_t)g->n, 0);
+    int rc = gall(h, [&](kfsp_ctx *c, int p) {
+        return kfsp_expand_resident(c, t_ssa, seedmix, ns, nr, stoich, max_count, capacity, &nn[(size_t)p], &ns_[(size_t)p]);
+    });
+    if (!rc)
+        for (int p = 1; p < g->n; ++p)
+            if (nn[(size_t)p] != nn[0] || ns_[(size_t)p] != ns_[0]) return gfail(h, 4002, "ranks disagree on the expanded FSP");
+    if (!rc) {
+        *n_new = nn[0];
+        if (n_from_ssa) *n_from_ssa = ns_[0];
+    }
+    return after_matrix(h, rc, nn[0]);
+}
+
 int group_reduce_w(kfsp_ctx *h, int squared, double *out)
 {
     Group *g = h->group;

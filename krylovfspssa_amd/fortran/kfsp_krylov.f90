@@ -58,7 +58,7 @@ MODULE KRYLOVSOLVER
   ! Resident mode (KFSP_RESIDENT=0 turns it off): with independent-stream SSA paths (KFSP_SSA_STREAMS=1) and the model's
   ! program on one device, DROP_STATES and the expansion step run on the device's own copy of the FSP
   ! (kfsp_drop_rebuild / kfsp_expand_resident); this side keeps the size only and fetches the lists when the solve is over.
-  LOGICAL, SAVE, PRIVATE :: RESIDENT_WANTED = .TRUE., RESIDENT = .FALSE., SINGLE_CONTEXT = .TRUE., SSA_ON_DEVICE = .TRUE.
+  LOGICAL, SAVE, PRIVATE :: RESIDENT_WANTED = .TRUE., RESIDENT = .FALSE., SSA_ON_DEVICE = .TRUE.
   LOGICAL, SAVE, PRIVATE :: DEVICE_REBUILD = .TRUE.   ! KFSP_DEVICE_REBUILD=0: the compacted generator is uploaded after every drop
   ! wall seconds spent in the host state-space code of the current solve:
   ! (1) DROP_STATES decision + compaction, (2) SSA_EXTENDER, (3) ONESTEP_EXTENDER,
@@ -130,7 +130,7 @@ CONTAINS
     CUR_FSP => FSP
     CUR_MODEL => MODEL
     CUR_TRACE = ITRACE
-    RESIDENT = RESIDENT_WANTED .AND. PROGRAM_READY .AND. SSA_ON_DEVICE .AND. SINGLE_CONTEXT .AND. SSA_STREAMS_REQUESTED() &
+    RESIDENT = RESIDENT_WANTED .AND. PROGRAM_READY .AND. SSA_ON_DEVICE .AND. SSA_STREAMS_REQUESTED() &
          .AND. .NOT. HOST_DROP .AND. DEVICE_REBUILD .AND. .NOT. ASSOCIATED(KFSP_STEP_OBSERVER) &
          .AND. .NOT. ASSOCIATED(KFSP_REPLAY_SCRIPT)
     RC = KFSP_SET_OPTION(CTX, 'keep_coords' // C_NULL_CHAR, INT(MERGE(1, 0, RESIDENT), C_INT64_T))
@@ -263,7 +263,6 @@ CONTAINS
     IF (STAT == 0 .AND. L > 0) RESIDENT_WANTED = ENV(1:1) /= '0'
     CALL GET_ENVIRONMENT_VARIABLE('KFSP_DEVICE_SSA', ENV, L, STAT)
     IF (STAT == 0 .AND. L > 0) SSA_ON_DEVICE = ENV(1:1) /= '0'
-    SINGLE_CONTEXT = NRANKS <= 1
     CALL GET_ENVIRONMENT_VARIABLE('KFSP_DEVICE_REBUILD', ENV, L, STAT)
     IF (STAT == 0 .AND. L > 0) DEVICE_REBUILD = ENV(1:1) /= '0'
     CALL GET_ENVIRONMENT_VARIABLE('KFSP_DEVICE_PROPENSITY', ENV, L, STAT)

@@ -352,6 +352,27 @@ def test_cme_solve_adaptive_fsp(dump, tmp_path, fixture, case):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ranks", [2, 3])
+@pytest.mark.parametrize("fixture,case", [("goutsias_input_T40", "goutsias_input"), ("repressilator_input_T1", "repressilator_input"),
+                                          ("toggle_input_T05", "toggle_input")])
+def test_resident_mode_on_a_row_partition(dump, tmp_path, fixture, case, ranks):
+    """the resident mode (independent-stream paths; drop, walk, one-step sweep and generator rebuild on the device's own
+    lists) with KFSP_NRANKS = P: every rank of the group expands the whole lists redundantly, the vector is re-dealt through
+    the communicator.  Against the one-context resident run: same step log and state list, links and columns bit for bit,
+    probabilities to l1 < 1e-10 (partial sums are added in another order)."""
+    base = {"KFSP_SSA_STREAMS": "1", "KFSP_DEVICE_SSA_MIN": "1", "KFSP_RESIDENT": "1"}
+    g, d1, log1 = _solve(dump, tmp_path, fixture, case, env=base)
+    g, d, log = _solve(dump, tmp_path, fixture, case, env=dict(base, KFSP_NRANKS=str(ranks)))
+    assert int(log["n_ssa"]) == int(log1["n_ssa"]) and int(log["n_ssa"]) >= 1 and d["n"] == d1["n"]
+    assert np.array_equal(log["step_n"], log1["step_n"])
+    assert np.array_equal(log["step_tau"], log1["step_tau"]) and np.array_equal(log["step_m"], log1["step_m"])
+    for key in ("state", "adj", "offdiag", "diag"):
+        assert np.array_equal(d[key], d1[key]), key
+    assert np.abs(log["wsum"] - log1["wsum"]).max() < 1e-10
+    assert np.abs(d["vector"] - d1["vector"]).sum() < 1e-10
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("state_order", [0, 1])
 @pytest.mark.parametrize("ranks", [2, 3])
 @pytest.mark.parametrize("fixture,case,exact", [("goutsias_input_T40", "goutsias_input", True),

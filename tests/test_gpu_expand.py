@@ -158,6 +158,52 @@ def test_drop_rebuild_expand_cycle_stays_on_the_device(golden_dir):
             c.set_vector(w)
 
 
+@pytest.mark.parametrize("P", [2, 3])
+@pytest.mark.parametrize("order", [0, 1])
+def test_resident_expansion_under_a_row_partition(golden_dir, P, order):
+    """a group context (P loop-back ranks): every rank holds the whole lists and expands them redundantly, the vector is
+    assembled and dealt out again in the new partition - the head must give what one context gives"""
+    from krylovfspssa_amd import KfspContext
+    rng = np.random.default_rng(3)
+    res = []
+    for group in (None, P):
+        with KfspContext(0, group=group) as c:
+            nu, state, adj = _grown(c, "goutsias_k16", golden_dir, 3)
+            nr, ns = nu.shape
+            params, progs = _mass_action(nu)
+            c.set_propensity_program(ns, params, progs)
+            c.set_option("state_order", order)
+            c.set_option("state_order_min", 64)
+            c.set_option("state_order_products", 0)
+            c.set_option("small_kernel", 0)
+            c.set_option("keep_coords", 1)
+            off, diag = c.propensities(state)
+            c.set_state_coords(state)
+            c.set_matrix_ell(adj, off, diag)
+            n = len(state)
+            w = np.random.default_rng(8).random(n)
+            c.set_vector(w)
+            t = 2.0 / float(np.mean(diag[diag > 0]))
+            n2, nssa = c.expand_resident(t, 4242, nu)
+            lists = c.download_fsp(ns, nr)
+            x = np.random.default_rng(9).random(n2)
+            res.append(dict(n2=n2, nssa=nssa, lists=lists, w=c.get_vector(), y=c.spmv(x)))
+            # a second round on the grown FSP, after a drop decided on the device
+            wv = np.random.default_rng(10).random(n2) * np.where(np.arange(n2) >= n2 // 2, 1e-14, 1.0)
+            c.set_vector(wv / wv.sum())
+            c.drop_plan(1e-7)
+            nk = c.drop_compact()
+            c.drop_rebuild()
+            n3, _ = c.expand_resident(t, 4243, nu)
+            res[-1].update(nk=nk, n3=n3, lists3=c.download_fsp(ns, nr), w3=c.get_vector())
+    a, b = res
+    assert (a["n2"], a["nssa"], a["nk"], a["n3"]) == (b["n2"], b["nssa"], b["nk"], b["n3"]) and a["nssa"] > 0 and a["n2"] > a["nssa"]
+    for u, v in zip(a["lists"] + a["lists3"], b["lists"] + b["lists3"]):
+        assert np.array_equal(u, v)
+    assert np.array_equal(a["w"], b["w"]) and np.array_equal(a["w3"], b["w3"])
+    assert np.array_equal(a["y"], b["y"])                  # every row is summed in FMATVEC's order whoever owns it
+
+
 def test_refusals(golden_dir):
     from krylovfspssa_amd import KfspContext, KfspError
     with KfspContext(0) as c:
