@@ -1925,7 +1925,7 @@ int kfsp_drop_plan(kfsp_ctx *ctx, double dsum, double *droptol, int64_t *drop_co
     HIP_TRY(hipMemsetAsync(ctx->d_dropcnt.p, 0, 4 * sizeof(unsigned long long), st));
     unsigned long long cnt[4] = {0, 0, 0, 0};
     if (!comm) {
-        kfsp::launch_drop_flags(n, ctx->d_w.p, aw, found, ctx->perm_on ? ctx->d_perm.p : nullptr, ctx->d_dropflag.p,
+        kfsp::launch_drop_flags(n, ctx->d_w.p, aw, found, ctx->perm_on ? ctx->d_iperm.p : nullptr, ctx->d_dropflag.p,
                                 ctx->d_dropcnt.p, st);
         HIP_TRY(hipMemcpyAsync(cnt, ctx->d_dropcnt.p, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
@@ -1946,7 +1946,7 @@ int kfsp_drop_plan(kfsp_ctx *ctx, double dsum, double *droptol, int64_t *drop_co
         double hr[3] = {0, 0, 0};
         HIP_TRY(hipMemcpyAsync(hr, stg, sizeof(hr), hipMemcpyDeviceToHost, st));
         if (int rc = comm_allgather_bytes(ctx, mine, all, Lb, st)) return rc;
-        kfsp::launch_flags_to_caller(n, all, ctx->perm_on ? ctx->d_perm.p : nullptr, ctx->d_dropflag.p, st);
+        kfsp::launch_flags_to_caller(n, all, ctx->perm_on ? ctx->d_iperm.p : nullptr, ctx->d_dropflag.p, st);
         HIP_TRY(hipStreamSynchronize(st));
         for (int i = 0; i < 3; ++i) cnt[i] = (unsigned long long)hr[i];
     }

@@ -366,9 +366,9 @@ int state_order_from_coords(kfsp_ctx *ctx, int32_t n, int32_t ns, int32_t ld, co
 void launch_gather_index(int64_t n, const int32_t *index, const double *src, double *dst, hipStream_t st);
 // DROP_STATES pieces (kfsp_drop.hip)
 void launch_drop_sums(int grid, int64_t npairs, const double *w, const DropLevels &L, double *partial, double *out, hipStream_t st);
-void launch_drop_flags(int64_t n, const double *w, const double *aw, double droptol, const int32_t *perm, uint8_t *flag,
+void launch_drop_flags(int64_t n, const double *w, const double *aw, double droptol, const int32_t *iperm, uint8_t *flag,
                        unsigned long long *cnt, hipStream_t st);
-void launch_flags_to_caller(int64_t n, const uint8_t *all, const int32_t *perm, uint8_t *flag, hipStream_t st);
+void launch_flags_to_caller(int64_t n, const uint8_t *all, const int32_t *iperm, uint8_t *flag, hipStream_t st);
 int drop_compact_vector(kfsp_ctx *ctx, int64_t n, const double *src, double *dst, int *n_keep_dev);
 // ONESTEP_EXTENDER's integer work (kfsp_expand.hip); all arrays are host memory
 // off_new / diag_new (may be null): the propensity columns of the appended states, made by the program of kfsp_prop.hip

@@ -76,17 +76,19 @@ __global__ __launch_bounds__(kBlock) void k_drop_finish(int nblocks, const doubl
 // mark w < droptol, un-mark where (A w)_i > 1e-8 (StateSpace.f90:475-495); counters:
 // cnt[0] = #(w < droptol), cnt[1] = #(A w > 1e-8) - DROP_COUNT is their DIFFERENCE in the
 // reference, whether or not the guarded state was marked -, cnt[2] = states actually flagged.
-// Flags are stored in the CALLER's state order (perm: internal -> caller index, or null).
+// Flags are stored in the CALLER's state order (iperm: caller index -> internal, or null): the sweep runs over the caller's
+// indices and GATHERS w and A w (scattered single-byte stores through the inverse map cost 140 us at 1e6 states).
 __global__ __launch_bounds__(kBlock) void k_drop_flags(int64_t n, const double *__restrict__ w, const double *__restrict__ aw,
-                                                       double droptol, const int32_t *__restrict__ perm,
+                                                       double droptol, const int32_t *__restrict__ iperm,
                                                        uint8_t *__restrict__ flag, unsigned long long *__restrict__ cnt)
 {
     unsigned c0 = 0, c1 = 0, c2 = 0;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += (int64_t)gridDim.x * kBlock) {
+        const int64_t i = iperm ? iperm[j] : j;
         const bool marked = w[i] < droptol;
         const bool guarded = aw[i] > 1.0e-8;
         const bool drop = marked && !guarded;
-        flag[perm ? perm[i] : i] = drop ? 1 : 0;
+        flag[j] = drop ? 1 : 0;
         c0 += marked;
         c1 += guarded;
         c2 += drop;
@@ -110,18 +112,18 @@ __global__ __launch_bounds__(kBlock) void k_keep_from_drop(int64_t n, const uint
 }
 
 // flags of all blocks in the device's order (entry g at all[g]: blocks are contiguous) -> the caller's order
-__global__ __launch_bounds__(kBlock) void k_flags_to_caller(int64_t n, const uint8_t *__restrict__ all, const int32_t *__restrict__ perm,
+__global__ __launch_bounds__(kBlock) void k_flags_to_caller(int64_t n, const uint8_t *__restrict__ all, const int32_t *__restrict__ iperm,
                                                             uint8_t *__restrict__ flag)
 {
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) flag[perm ? perm[i] : i] = all[i];
+    for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += (int64_t)gridDim.x * kBlock) flag[j] = all[iperm ? iperm[j] : j];
 }
 
 }  // namespace
 
-void launch_flags_to_caller(int64_t n, const uint8_t *all, const int32_t *perm, uint8_t *flag, hipStream_t st)
+void launch_flags_to_caller(int64_t n, const uint8_t *all, const int32_t *iperm, uint8_t *flag, hipStream_t st)
 {
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (n + kBlock - 1) / kBlock));
-    hipLaunchKernelGGL(k_flags_to_caller, dim3(grid), dim3(kBlock), 0, st, n, all, perm, flag);
+    hipLaunchKernelGGL(k_flags_to_caller, dim3(grid), dim3(kBlock), 0, st, n, all, iperm, flag);
 }
 
 void launch_drop_sums(int grid, int64_t npairs, const double *w, const DropLevels &L, double *partial, double *out, hipStream_t st)
@@ -130,11 +132,11 @@ void launch_drop_sums(int grid, int64_t npairs, const double *w, const DropLevel
     hipLaunchKernelGGL(k_drop_finish, dim3(1), dim3(kBlock), 0, st, grid, partial, out);
 }
 
-void launch_drop_flags(int64_t n, const double *w, const double *aw, double droptol, const int32_t *perm, uint8_t *flag,
+void launch_drop_flags(int64_t n, const double *w, const double *aw, double droptol, const int32_t *iperm, uint8_t *flag,
                        unsigned long long *cnt, hipStream_t st)
 {
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (n + kBlock - 1) / kBlock));
-    hipLaunchKernelGGL(k_drop_flags, dim3(grid), dim3(kBlock), 0, st, n, w, aw, droptol, perm, flag, cnt);
+    hipLaunchKernelGGL(k_drop_flags, dim3(grid), dim3(kBlock), 0, st, n, w, aw, droptol, iperm, flag, cnt);
 }
 
 // dst[0..n_keep) = the entries of src (caller order) whose flag is 0, order kept; *n_keep_dev receives the count
