@@ -463,7 +463,12 @@ int dgexpv_impl(kfsp_ctx *ctx, double t, double fsptol, double krytol, int n_rea
                 t_step = row[2];
             }
             ++st.nexph;                                        // :489-493, order MX this time
-            if ((rc = kfsp_padm(kIdeg, mx, S.sgn * t_step, H.data(), mh, E.data(), &ns, nullptr))) return 3000 - rc;
+            {
+                const auto t0 = std::chrono::steady_clock::now();
+                rc = kfsp_padm(kIdeg, mx, S.sgn * t_step, H.data(), mh, E.data(), &ns, nullptr);
+                kfsp_add_timer(ctx, KFSP_T_HOST_PADE, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+                if (rc) return 3000 - rc;
+            }
             st.nscale += ns;
         }
         if (rp && ls.out_of_step) break;
