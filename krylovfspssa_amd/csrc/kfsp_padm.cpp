@@ -66,6 +66,10 @@ __attribute__((target("avx2,fma"))) void matmul_avx2(double alpha, const Dense &
 {
     KFSP_MATMUL_BODY
 }
+__attribute__((target("avx512f,avx512vl,fma"))) void matmul_avx512(double alpha, const Dense &A, const Dense &B, Dense &C)
+{
+    KFSP_MATMUL_BODY
+}
 #undef KFSP_MATMUL_BODY
 
 // Dense case (the squaring phase): two output columns share every load of A and
@@ -168,19 +172,31 @@ __attribute__((target("avx2,fma"))) void matmul_dense_avx2(double alpha, const D
 {
     KFSP_MATMUL_DENSE_BODY
 }
+// 512-bit lanes where the host has them (EPYC 9575F of the MI355X boxes: 0.67 -> 0.51 ms at order 102).  The fused
+// operations per element are those of the 256-bit build: the bits do not change with the width - checked bitwise against
+// the previous library on 400 random matrices on both an AVX-512 Xeon and the EPYC (the check is how any change to these
+// bodies has to be accepted: which product of "a b + c d" the compiler fuses is its choice, and a restructured
+// body - a template over the column count was tried - can come out with other bits).
+__attribute__((target("avx512f,avx512vl,fma"))) void matmul_dense_avx512(double alpha, const Dense &A, const Dense &B, Dense &C)
+{
+    KFSP_MATMUL_DENSE_BODY
+}
 #undef KFSP_MATMUL_DENSE_BODY
 
 void matmul(double alpha, const Dense &A, const Dense &B, Dense &C)
 {
     static const bool wide = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma");
+    static const bool wider = wide && __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl");
     size_t nz = 0;
     for (double v : B.a) nz += v != 0.0;
     if (2 * nz > B.a.size()) {                            // mostly non-zero: no point in skipping
-        if (wide) matmul_dense_avx2(alpha, A, B, C);
+        if (wider) matmul_dense_avx512(alpha, A, B, C);
+        else if (wide) matmul_dense_avx2(alpha, A, B, C);
         else matmul_dense_base(alpha, A, B, C);
         return;
     }
-    if (wide) matmul_avx2(alpha, A, B, C);
+    if (wider) matmul_avx512(alpha, A, B, C);
+    else if (wide) matmul_avx2(alpha, A, B, C);
     else matmul_base(alpha, A, B, C);
 }
 
