@@ -224,3 +224,51 @@ def test_refusals(golden_dir):
         # the refused expansion left the FSP as it was
         s_r, a_r, _, _ = c.download_fsp(ns, nr)
         assert np.array_equal(s_r, state) and np.array_equal(a_r, adj)
+
+
+def test_random_networks_resident_equals_host_lists():
+    """40 random networks (1-4 species, 1-6 reactions with entries in [-2, 2]; mass-action propensities, so the walk's
+    product-chain path and the interpreter both occur - a reaction that consumes nothing is a constant) on random subsets
+    of small boxes, random horizon: the resident expansion against the two calls on host copies of the lists"""
+    from krylovfspssa_amd import KfspContext
+    rng = np.random.default_rng(99)
+    for case in range(40):
+        ns, nr = int(rng.integers(1, 5)), int(rng.integers(1, 7))
+        nu = rng.integers(-2, 3, size=(nr, ns)).astype(np.int32)
+        side = int(rng.integers(3, 7))
+        box = np.array(np.meshgrid(*[np.arange(side)] * ns, indexing="ij")).reshape(ns, -1).T
+        keep = rng.random(len(box)) < rng.uniform(0.3, 1.0)
+        keep[int(rng.integers(0, len(box)))] = True
+        state = box[keep][rng.permutation(int(keep.sum()))].astype(np.int32)
+        params, progs = _mass_action(nu)
+        with KfspContext(0) as c, KfspContext(0) as ref:
+            for x in (c, ref):
+                x.set_propensity_program(ns, params, progs)
+                x.set_option("state_order", case % 2)
+                x.set_option("state_order_min", 1)
+                x.set_option("state_order_products", 0)
+            idx = {tuple(v): i + 1 for i, v in enumerate(state.tolist())}
+            adj = np.zeros((len(state), nr), dtype=np.int32)                # complete links among the listed states
+            for j, v in enumerate(state):
+                for k in range(nr):
+                    y = v + nu[k]
+                    adj[j, k] = -1 if y.min() < 0 else idx.get(tuple(y.tolist()), 0)
+            off, diag = c.propensities(state)
+            n = len(state)
+            t = float(rng.uniform(0.5, 6.0)) / max(float(diag.max()), 1e-3)
+            seed = int(rng.integers(1, 2 ** 31 - 2))
+            s1, o1, d1 = ref.ssa_streams(t, seed, nu, state, adj, off, diag, max_count=side + 3)
+            st1 = np.concatenate([state, s1])
+            ad1 = np.concatenate([adj, np.zeros((len(s1), nr), dtype=np.int32)])
+            st2, ad2, o2, d2 = ref.onestep_columns(nu, st1, ad1, max_count=side + 3)
+            c.set_option("keep_coords", 1)
+            c.set_state_coords(state)
+            c.set_matrix_ell(adj, off, diag)
+            w = rng.random(n)
+            c.set_vector(w)
+            n2, nssa = c.expand_resident(t, seed, nu, max_count=side + 3)
+            assert (n2, nssa) == (len(st2), len(s1)), case
+            s_r, a_r, o_r, d_r = c.download_fsp(ns, nr)
+            assert np.array_equal(s_r, st2) and np.array_equal(a_r, ad2), case
+            assert np.array_equal(o_r, np.concatenate([off, o1, o2])) and np.array_equal(d_r, np.concatenate([diag, d1, d2])), case
+            assert np.array_equal(c.get_vector(), np.concatenate([w, np.zeros(n2 - n)])), case
