@@ -1925,8 +1925,15 @@ int kfsp_drop_plan(kfsp_ctx *ctx, double dsum, double *droptol, int64_t *drop_co
     HIP_TRY(hipMemsetAsync(ctx->d_dropcnt.p, 0, 4 * sizeof(unsigned long long), st));
     unsigned long long cnt[4] = {0, 0, 0, 0};
     if (!comm) {
-        kfsp::launch_drop_flags(n, ctx->d_w.p, aw, found, ctx->perm_on ? ctx->d_iperm.p : nullptr, ctx->d_dropflag.p,
-                                ctx->d_dropcnt.p, st);
+        if (ctx->perm_on) {
+            // marks in the device's order (streaming reads, streaming byte stores), then the BYTES go to the caller's order:
+            // gathering one byte per state from an array that fits the L2 costs a tenth of gathering w and A w
+            HIP_TRY(ctx->d_flagloc.reserve((size_t)n + 256, false));
+            kfsp::launch_drop_flags(n, ctx->d_w.p, aw, found, nullptr, ctx->d_flagloc.p, ctx->d_dropcnt.p, st);
+            kfsp::launch_flags_to_caller(n, ctx->d_flagloc.p, ctx->d_iperm.p, ctx->d_dropflag.p, st);
+        } else {
+            kfsp::launch_drop_flags(n, ctx->d_w.p, aw, found, nullptr, ctx->d_dropflag.p, ctx->d_dropcnt.p, st);
+        }
         HIP_TRY(hipMemcpyAsync(cnt, ctx->d_dropcnt.p, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
     } else {

@@ -740,24 +740,29 @@ int build_sell_code(kfsp_ctx *ctx)
 
 // DROP_STATES on the device's own copy of the reference arrays (StateSpace.f90:500-546): the kept states move up in list order
 // (scan[i] = kept states before i), links are renumbered through the same scan, a dropped target becomes 0 (:540-545), -1 stays.
+// one lane per ENTRY of the link / propensity arrays (consecutive lanes read consecutive words; a lane per state walked its
+// column with a stride of ld words), the first lane of a column also moves DIAG and the coordinates
 __global__ __launch_bounds__(kBlock) void k_ell_compact(int64_t n, int bw, int ld, int ns, int lds, const uint8_t *__restrict__ keep,
                                                         const int32_t *__restrict__ scan, const int32_t *__restrict__ adj,
                                                         const double *__restrict__ off, const double *__restrict__ diag,
                                                         const int32_t *__restrict__ coords, int32_t *__restrict__ adj2,
                                                         double *__restrict__ off2, double *__restrict__ diag2, int32_t *__restrict__ coords2)
 {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n || !keep[i]) return;
+    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (e >= n * ld) return;
+    const int64_t i = e / ld;
+    if (!keep[i]) return;
+    const int k = (int)(e - i * ld);
     const int64_t q = scan[i];
-    for (int k = 0; k < ld; ++k) {
-        int32_t a = adj[i * ld + k];
-        if (k < bw && a > 0) a = keep[a - 1] ? scan[a - 1] + 1 : 0;
-        adj2[q * ld + k] = a;
-        off2[q * ld + k] = off[i * ld + k];
+    int32_t a = adj[e];
+    if (k < bw && a > 0) a = keep[a - 1] ? scan[a - 1] + 1 : 0;
+    adj2[q * ld + k] = a;
+    off2[q * ld + k] = off[e];
+    if (k == 0) {
+        diag2[q] = diag[i];
+        if (coords)
+            for (int s = 0; s < lds; ++s) coords2[q * lds + s] = coords[i * lds + s];
     }
-    diag2[q] = diag[i];
-    if (coords)
-        for (int s = 0; s < lds; ++s) coords2[q * lds + s] = coords[i * lds + s];
 }
 
 __global__ __launch_bounds__(kBlock) void k_u8_to_i32(int64_t n, const uint8_t *__restrict__ a, int32_t *__restrict__ b)
@@ -784,7 +789,8 @@ int compact_resident_ell(kfsp_ctx *ctx, int64_t n, int bw, int ld, const uint8_t
     HIP_TRY_B(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, flag32, scan, (int)n, st));
     HIP_TRY_B(ctx->d_sorttmp.reserve(tmp_bytes + 256, false));
     HIP_TRY_B(hipcub::DeviceScan::ExclusiveSum(ctx->d_sorttmp.p, tmp_bytes, flag32, scan, (int)n, st));
-    hipLaunchKernelGGL(k_ell_compact, dim3(grid), dim3(kBlock), 0, st, n, bw, ld, lds, lds, keep, scan, ctx->d_ell_adj.p,
+    const int grid_e = (int)((n * (int64_t)ld + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_ell_compact, dim3(grid_e), dim3(kBlock), 0, st, n, bw, ld, lds, lds, keep, scan, ctx->d_ell_adj.p,
                        ctx->d_ell_off.p, ctx->d_ell_diag.p, with_coords ? ctx->d_coords.p : (const int32_t *)nullptr, ctx->d_ell_adj2.p,
                        ctx->d_ell_off2.p, ctx->d_ell_diag2.p, with_coords ? ctx->d_coords2.p : (int32_t *)nullptr);
     HIP_TRY_B(hipStreamSynchronize(st));
