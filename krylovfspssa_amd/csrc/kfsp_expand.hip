@@ -105,33 +105,48 @@ __device__ __forceinline__ void x_insert2(const XDev &A, const int32_t *y, int c
     }
 }
 
+// The sweeps over the link array run one lane per ENTRY (j, k): consecutive lanes read consecutive words of ADJ (a lane per
+// state walked its column with a stride of lda words: 120 us per sweep at 8e5 states instead of 25), and only the lanes
+// that find an open link do anything more.
+__device__ __forceinline__ bool x_entry(const XDev &A, int64_t e, int *j, int *k)
+{
+    if (e >= (int64_t)A.n * A.lda) return false;
+    *j = (int)(e / A.lda);
+    *k = (int)(e - (int64_t)*j * A.lda);
+    return *k < A.nr;
+}
+
 // step 2: resolve or mark the open links; *ncand += the number of marks
 __global__ __launch_bounds__(kBlock) void k_x_mark(XDev A, unsigned long long *__restrict__ ncand)
 {
-    const int j = blockIdx.x * kBlock + threadIdx.x;
-    int c = 0;
-    if (j < A.n) {
+    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    int j, k, c = 0;
+    if (x_entry(A, e, &j, &k) && A.adj[e] == 0) {
         const int32_t *x = A.state + (int64_t)j * A.lds;
-        int32_t *a = A.adj + (int64_t)j * A.lda;
-        for (int k = 0; k < A.nr; ++k) {
-            if (a[k] != 0) continue;
-            int32_t y[kXMaxS];
-            bool neg;
-            if (!x_target(A, x, k, y, &neg)) {
-                if (neg) a[k] = -1;
-                continue;
-            }
-            const int e = table_find(A.tab, A.tmask, A.state, A.lds, A.ns, y);
-            if (e > 0) {
-                a[k] = e;
+        int32_t y[kXMaxS];
+        bool neg;
+        if (!x_target(A, x, k, y, &neg)) {
+            if (neg) A.adj[e] = -1;
+        } else {
+            const int f = table_find(A.tab, A.tmask, A.state, A.lds, A.ns, y);
+            if (f > 0) {
+                A.adj[e] = f;
             } else {
-                a[k] = kOpen;
-                ++c;
+                A.adj[e] = kOpen;
+                c = 1;
             }
         }
     }
+    // (one atomic per workgroup: adds on ONE address cost ~10 ns each)
+    __shared__ int sc[kBlock / 64];
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-    if ((threadIdx.x & 63) == 0 && c > 0) atomicAdd(ncand, (unsigned long long)c);
+    if ((threadIdx.x & 63) == 0) sc[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int v = 0; v < kBlock / 64; ++v) t += sc[v];
+        if (t > 0) atomicAdd(ncand, (unsigned long long)t);
+    }
 }
 
 // (a sweep that fails after the marks - capacity - takes them back, and with them the links to states beyond n_keep)
@@ -144,102 +159,88 @@ __global__ __launch_bounds__(kBlock) void k_x_unmark(XDev A, int n_keep)
 // step 3
 __global__ __launch_bounds__(kBlock) void k_x_insert(XDev A)
 {
-    const int j = blockIdx.x * kBlock + threadIdx.x;
-    if (j >= A.n) return;
-    const int32_t *x = A.state + (int64_t)j * A.lds;
-    const int32_t *a = A.adj + (int64_t)j * A.lda;
-    for (int k = 0; k < A.nr; ++k) {
-        if (a[k] != kOpen) continue;
-        int32_t y[kXMaxS];
-        bool neg;
-        x_target(A, x, k, y, &neg);
-        x_insert2(A, y, j * A.nr + k);
-    }
+    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    int j, k;
+    if (!x_entry(A, e, &j, &k) || A.adj[e] != kOpen) return;
+    int32_t y[kXMaxS];
+    bool neg;
+    x_target(A, A.state + (int64_t)j * A.lds, k, y, &neg);
+    x_insert2(A, y, j * A.nr + k);
 }
 
-// step 4: heads per state
+// step 4: heads per state (cnt is zero on entry)
 __global__ __launch_bounds__(kBlock) void k_x_heads(XDev A, int *__restrict__ cnt)
 {
-    const int j = blockIdx.x * kBlock + threadIdx.x;
-    if (j > A.n) return;
-    int h = 0;
-    if (j < A.n) {
-        const int32_t *x = A.state + (int64_t)j * A.lds;
-        const int32_t *a = A.adj + (int64_t)j * A.lda;
-        for (int k = 0; k < A.nr; ++k) {
-            if (a[k] != kOpen) continue;
-            int32_t y[kXMaxS];
-            bool neg;
-            x_target(A, x, k, y, &neg);
-            const int slot = x_find2(A, y);
-            h += A.tab2[slot] == j * A.nr + k;
-        }
-    }
-    cnt[j] = h;                              // (cnt[n] = 0: the scan's last element is the total)
+    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    int j, k;
+    if (!x_entry(A, e, &j, &k) || A.adj[e] != kOpen) return;
+    int32_t y[kXMaxS];
+    bool neg;
+    x_target(A, A.state + (int64_t)j * A.lds, k, y, &neg);
+    if (A.tab2[x_find2(A, y)] == j * A.nr + k) atomicAdd(&cnt[j], 1);
 }
 
-// step 5a: the heads append their targets
+// step 5a: the heads append their targets; a head's place among the heads of its state is the number of heads before
+// it in the state's column (few lanes get here, and a column holds nr entries)
 __global__ __launch_bounds__(kBlock) void k_x_new(XDev A, const int *__restrict__ cnt, const int *__restrict__ off)
 {
-    const int j = blockIdx.x * kBlock + threadIdx.x;
-    if (j >= A.n || cnt[j] == 0) return;
+    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    int j, k;
+    if (!x_entry(A, e, &j, &k) || A.adj[e] != kOpen) return;
     const int32_t *x = A.state + (int64_t)j * A.lds;
-    const int32_t *a = A.adj + (int64_t)j * A.lda;
+    int32_t y[kXMaxS];
+    bool neg;
+    x_target(A, x, k, y, &neg);
+    const int slot = x_find2(A, y);
+    if (A.tab2[slot] != j * A.nr + k) return;
     int r = off[j];
-    for (int k = 0; k < A.nr; ++k) {
-        if (a[k] != kOpen) continue;
-        int32_t y[kXMaxS];
-        bool neg;
-        x_target(A, x, k, y, &neg);
-        const int slot = x_find2(A, y);
-        if (A.tab2[slot] != j * A.nr + k) continue;
-        int32_t *z = A.state_new + (int64_t)r * A.lds;
-        for (int s = 0; s < A.lds; ++s) z[s] = s < A.ns ? y[s] : 0;
-        A.newidx[slot] = A.n + r + 1;
-        ++r;
+    if (cnt[j] > 1) {
+        const int32_t *a = A.adj + (int64_t)j * A.lda;
+        for (int kk = 0; kk < k; ++kk) {
+            if (a[kk] != kOpen) continue;
+            int32_t yy[kXMaxS];
+            x_target(A, x, kk, yy, &neg);
+            r += A.tab2[x_find2(A, yy)] == j * A.nr + kk;
+        }
     }
+    int32_t *z = A.state_new + (int64_t)r * A.lds;
+    for (int s = 0; s < A.lds; ++s) z[s] = s < A.ns ? y[s] : 0;
+    A.newidx[slot] = A.n + r + 1;
 }
 
 // step 5b: every candidate is linked to the state its target became
 __global__ __launch_bounds__(kBlock) void k_x_link(XDev A)
 {
-    const int j = blockIdx.x * kBlock + threadIdx.x;
-    if (j >= A.n) return;
-    const int32_t *x = A.state + (int64_t)j * A.lds;
-    int32_t *a = A.adj + (int64_t)j * A.lda;
-    for (int k = 0; k < A.nr; ++k) {
-        if (a[k] != kOpen) continue;
-        int32_t y[kXMaxS];
-        bool neg;
-        x_target(A, x, k, y, &neg);
-        a[k] = A.newidx[x_find2(A, y)];
-    }
+    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    int j, k;
+    if (!x_entry(A, e, &j, &k) || A.adj[e] != kOpen) return;
+    int32_t y[kXMaxS];
+    bool neg;
+    x_target(A, A.state + (int64_t)j * A.lds, k, y, &neg);
+    A.adj[e] = A.newidx[x_find2(A, y)];
 }
 
 // step 5c: the columns of the appended states (LINK_NEW without back links, StateSpace.f90:213-230)
 __global__ __launch_bounds__(kBlock) void k_x_newcols(XDev A, int nu)
 {
-    const int r = blockIdx.x * kBlock + threadIdx.x;
-    if (r >= nu) return;
-    const int32_t *x = A.state_new + (int64_t)r * A.lds;
-    int32_t *a = A.adj_new + (int64_t)r * A.lda;
-    for (int k = 0; k < A.lda; ++k) {
-        int link = 0;
-        if (k < A.nr) {
-            int32_t y[kXMaxS];
-            bool neg;
-            if (x_target(A, x, k, y, &neg)) {
-                link = table_find(A.tab, A.tmask, A.state, A.lds, A.ns, y);
-                if (link == 0) {
-                    const int slot = x_find2(A, y);
-                    if (slot >= 0) link = A.newidx[slot];
-                }
-            } else if (neg) {
-                link = -1;
+    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;      // one lane per entry: every one is two table look-ups
+    if (e >= (int64_t)nu * A.lda) return;
+    const int r = (int)(e / A.lda), k = (int)(e - (int64_t)r * A.lda);
+    int link = 0;
+    if (k < A.nr) {
+        int32_t y[kXMaxS];
+        bool neg;
+        if (x_target(A, A.state_new + (int64_t)r * A.lds, k, y, &neg)) {
+            link = table_find(A.tab, A.tmask, A.state, A.lds, A.ns, y);
+            if (link == 0) {
+                const int slot = x_find2(A, y);
+                if (slot >= 0) link = A.newidx[slot];
             }
+        } else if (neg) {
+            link = -1;
         }
-        a[k] = link;
     }
+    A.adj_new[e] = link;
 }
 
 __global__ __launch_bounds__(kBlock) void k_x_zero_pad(int64_t n0, int64_t n1, double *__restrict__ w)
@@ -312,7 +313,8 @@ int sweep_count(kfsp_ctx *ctx, XDev &A, int **cnt_out, int **off_out, int *nu_ou
     launch_table_build(n, A.ns, A.lds, A.state, d_tab, slots - 1, st);
     A.tab = d_tab;
     A.tmask = slots - 1;
-    hipLaunchKernelGGL(k_x_mark, dim3(blocks(n)), dim3(kBlock), 0, st, A, d_ncand);
+    const int64_t nent = (int64_t)n * A.lda;
+    hipLaunchKernelGGL(k_x_mark, dim3(blocks(nent)), dim3(kBlock), 0, st, A, d_ncand);
     unsigned long long nc = 0;
     X_TRY(hipMemcpyAsync(&nc, d_ncand, sizeof(nc), hipMemcpyDeviceToHost, st));
     X_TRY(hipStreamSynchronize(st));
@@ -328,8 +330,9 @@ int sweep_count(kfsp_ctx *ctx, XDev &A, int **cnt_out, int **off_out, int *nu_ou
     A.newidx = a2.take<int32_t>(slots2);
     A.tmask2 = slots2 - 1;
     X_TRY(hipMemsetAsync(A.tab2, 0x7f, (size_t)slots2 * 4, st));
-    hipLaunchKernelGGL(k_x_insert, dim3(blocks(n)), dim3(kBlock), 0, st, A);
-    hipLaunchKernelGGL(k_x_heads, dim3(blocks((int64_t)n + 1)), dim3(kBlock), 0, st, A, d_cnt);
+    X_TRY(hipMemsetAsync(d_cnt, 0, ((size_t)n + 1) * sizeof(int), st));      // (cnt[n] = 0: the scan's last element is the total)
+    hipLaunchKernelGGL(k_x_insert, dim3(blocks(nent)), dim3(kBlock), 0, st, A);
+    hipLaunchKernelGGL(k_x_heads, dim3(blocks(nent)), dim3(kBlock), 0, st, A, d_cnt);
     size_t tmp_bytes = 0;
     X_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_cnt, d_off, n + 1, st));
     X_TRY(ctx->d_sorttmp.reserve(tmp_bytes + 256, false));
@@ -346,9 +349,10 @@ void sweep_append(kfsp_ctx *ctx, const XDev &A, const int *cnt, const int *off, 
 {
     if (nu <= 0) return;
     hipStream_t st = ctx->stream;
-    hipLaunchKernelGGL(k_x_new, dim3(blocks(A.n)), dim3(kBlock), 0, st, A, cnt, off);
-    hipLaunchKernelGGL(k_x_link, dim3(blocks(A.n)), dim3(kBlock), 0, st, A);
-    hipLaunchKernelGGL(k_x_newcols, dim3(blocks(nu)), dim3(kBlock), 0, st, A, nu);
+    const int64_t nent = (int64_t)A.n * A.lda;
+    hipLaunchKernelGGL(k_x_new, dim3(blocks(nent)), dim3(kBlock), 0, st, A, cnt, off);
+    hipLaunchKernelGGL(k_x_link, dim3(blocks(nent)), dim3(kBlock), 0, st, A);
+    hipLaunchKernelGGL(k_x_newcols, dim3(blocks((int64_t)nu * A.lda)), dim3(kBlock), 0, st, A, nu);
 }
 
 }  // namespace
