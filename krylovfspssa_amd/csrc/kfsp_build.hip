@@ -300,19 +300,20 @@ __global__ __launch_bounds__(kBlock) void k_sell_fill(int64_t n, int bw, int ld,
                                                       const int64_t *__restrict__ off, int32_t *__restrict__ ticket,
                                                       int32_t *__restrict__ col, double *__restrict__ val)
 {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    for (int j = 0; j < bw; ++j) {
-        const int k = adj[i * ld + j];
-        if (k < 1) continue;
-        const int64_t r = (int64_t)k - 1 - row0;
-        if (r < 0 || r >= nloc) continue;
-        const int p = atomicAdd(&ticket[r], 1);
-        const int64_t o = off[r >> 6];
-        const int64_t pos = sell_pos(o, (int)((off[(r >> 6) + 1] - o) >> 6), p, (int)(r & 63));
-        col[pos] = (int32_t)i;
-        val[pos] = offd[i * ld + j];
-    }
+    // one lane per entry of the reference arrays (consecutive lanes, consecutive words)
+    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (e >= n * ld) return;
+    const int64_t i = e / ld;
+    if ((int)(e - i * ld) >= bw) return;
+    const int k = adj[e];
+    if (k < 1) return;
+    const int64_t r = (int64_t)k - 1 - row0;
+    if (r < 0 || r >= nloc) return;
+    const int p = atomicAdd(&ticket[r], 1);
+    const int64_t o = off[r >> 6];
+    const int64_t pos = sell_pos(o, (int)((off[(r >> 6) + 1] - o) >> 6), p, (int)(r & 63));
+    col[pos] = (int32_t)i;
+    val[pos] = offd[e];
 }
 
 // each row's entries ascending by (source, value): deterministic, and the order
@@ -560,7 +561,7 @@ int build_from_resident_ell(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld)
     if (nchunks > 0) {
         hipLaunchKernelGGL(k_sell_init, dim3((int)((nchunks + 3) / 4)), dim3(kBlock), 0, st, nchunks, nloc, row0,
                            ctx->d_off.p, ctx->d_col.p, ctx->d_val.p, ell_diag, ctx->d_diag.p);
-        hipLaunchKernelGGL(k_sell_fill, dim3(gsrc), dim3(kBlock), 0, st, (int64_t)n, (int)bw, (int)ld, ell_adj,
+        hipLaunchKernelGGL(k_sell_fill, dim3((int)(((int64_t)n * ld + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, (int64_t)n, (int)bw, (int)ld, ell_adj,
                            ell_off, row0, nloc, ctx->d_off.p, ctx->d_ticket.p, ctx->d_col.p, ctx->d_val.p);
         hipLaunchKernelGGL(k_sell_sort_rows, dim3((int)((nloc + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, nloc,
                            ctx->d_cnt.p, ctx->d_off.p, ctx->d_col.p, ctx->d_val.p,
