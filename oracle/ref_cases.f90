@@ -198,6 +198,17 @@ CONTAINS
     CASE DEFAULT
        STOP 'ref_cases: unknown solve case'
     END SELECT
+    ! (scaling experiments: KFSP_CASE_FSPTOL overrides the FSP tolerance of the named case - a tighter one grows a larger FSP)
+    BLOCK
+      CHARACTER(LEN=32) :: ENV
+      INTEGER :: L, STAT
+      DOUBLE PRECISION :: V
+      CALL GET_ENVIRONMENT_VARIABLE('KFSP_CASE_FSPTOL', ENV, L, STAT)
+      IF (STAT == 0 .AND. L > 0) THEN
+         READ(ENV(1:L), *, IOSTAT=STAT) V
+         IF (STAT == 0 .AND. V > 0.0D0) FSPTOL = V
+      ENDIF
+    END BLOCK
   END SUBROUTINE SETUP_SOLVE_CASE
 
   ! fsp file : int32 ns, nr, n ; int32 STATE(ns,n) ; int32 ADJ(nr,n) ;
