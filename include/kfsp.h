@@ -75,8 +75,24 @@ int kfsp_partition(int64_t n, int nranks, int rank, int64_t *row0, int64_t *nrow
  * host (KrylovSolver.f90:40) is one - uses several GPUs: every entry point below accepts a head; kfsp_dgexpv and
  * its drop / expand callbacks (KrylovSolver.f90:509-534) run once, on the caller's thread and the caller's one copy
  * of the state space.  Scalars all ranks must agree on (beta, H, AVNORM, WSUM, the drop plan) are compared bit
- * for bit on the way back: 4002 if they ever differ.  Not on a head: kfsp_comm_init*, kfsp_selftest_stream. */
+ * for bit on the way back: 4002 if they ever differ.  Not on a head: kfsp_comm_init*, kfsp_selftest_stream.
+ * WATCHDOG: the fan-out of a call never waits for ever.  Once a rank has returned an error its peers get "group_grace_ms"
+ * (option on the head; default 15 s, environment KFSP_GROUP_GRACE_S) to come back, and every call has "group_timeout_ms"
+ * (default 1800 s, KFSP_GROUP_TIMEOUT_S) in all; when either expires the communicators of all ranks are aborted
+ * (ncclCommAbort / the loop-back transport's release), which brings back the ranks that sat in a collective their peer never
+ * entered; the call returns the failing rank's code with "rank p: ..." as the error text (2999 when no rank failed and only
+ * the deadline expired), and the group is BROKEN: every later call returns 2999 at once - destroy it and create a new one.
+ * 2998: ranks did not come back even after the abort ("group_settle_ms", default 30 s); their threads are abandoned, the
+ * caller still gets control back.  The process is never ended.  (KFSP_NRANKS with distinct KFSP_DEVICES - RCCL between real
+ * devices - has not run on hardware yet: no multi-GPU box was available to the builder; tests/test_gpu_two_ranks.py is the
+ * first thing to run on one.) */
 int kfsp_create_group(int nranks, const int *devices, kfsp_ctx **out);
+/* The watchdog alone, without any device (tests/test_group_watchdog.py): nranks worker threads over a loop-back transport;
+ * every rank works work_ms, then rank failing_rank (-1: none) returns -77 before the collective, rank hanging_rank (-1:
+ * none) sleeps hang_ms instead of entering it, the others wait in one collective.  Out: the code the fan-out returned,
+ * the rank it blamed (-1: none), the seconds it took, whether the group ended broken / stuck. */
+int kfsp_group_selftest(int nranks, int failing_rank, int hanging_rank, int work_ms, int hang_ms, int timeout_ms, int grace_ms,
+                        int settle_ms, int *rc_out, int *who_out, double *seconds, int *broken, int *stuck);
 /* ranks behind a context: 1 for an ordinary one */
 int kfsp_group_size(const kfsp_ctx *ctx, int *nranks);
 
@@ -518,7 +534,8 @@ int kfsp_add_timer(kfsp_ctx *ctx, int phase, double ms);
  * "sell_code" (dictionary-coded SELL columns, DESIGN.md 4.1c: -1 auto = under the internal state order,
  * 0 never, 1 always try), "m_max" (largest Krylov dimension the basis is allocated for, default and maximum 100 = M_MAX of
  * KrylovSolver.f90:47; a smaller value saves 8 * rows bytes per column - 90 GB at 10^8 states - and makes kfsp_arnoldi refuse
- * a larger m; kfsp_dgexpv needs the default), "box_store" (1: kfsp_set_matrix_box stores the generator as diagonals), "box_generic" (1: matrix-free boxes take
+ * a larger m; it takes effect when the NEXT generator is set - until then every bound follows the basis that is allocated, so
+ * raising it and calling kfsp_arnoldi with the larger m before a new generator returns -2; kfsp_dgexpv needs the default), "box_store" (1: kfsp_set_matrix_box stores the generator as diagonals), "box_generic" (1: matrix-free boxes take
  * the run-time interpreted kernel even when the single-factor fast path applies), "state_order" (1: use
  * kfsp_set_state_coords, the default; 0: never), "state_order_min" (smallest generator that is
  * reordered, default 32768), "state_order_products" (products the previous

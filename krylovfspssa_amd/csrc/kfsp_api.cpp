@@ -157,6 +157,8 @@ constexpr int kLoopScratch = 64 * kLoopVals + kLoopVals;   // doubles: up to 64 
 int comm_allreduce(kfsp_ctx *ctx, double *buf, int count, bool take_max, hipStream_t st)
 {
     if (!ctx->loop) {
+        std::lock_guard<std::mutex> lk(ctx->comm_mu);
+        if (ctx->comm_aborted) return fail(ctx, 2999, "the communicator was aborted");
         NCCL_TRY(ncclAllReduce(buf, buf, (size_t)count, ncclDouble, take_max ? ncclMax : ncclSum, ctx->comm, st));
         return 0;
     }
@@ -185,6 +187,8 @@ int comm_allreduce(kfsp_ctx *ctx, double *buf, int count, bool take_max, hipStre
 int comm_allgather(kfsp_ctx *ctx, const double *send, double *recv, size_t count, hipStream_t st)
 {
     if (!ctx->loop) {
+        std::lock_guard<std::mutex> lk(ctx->comm_mu);
+        if (ctx->comm_aborted) return fail(ctx, 2999, "the communicator was aborted");
         NCCL_TRY(ncclAllGather(send, recv, count, ncclDouble, ctx->comm, st));
         return 0;
     }
@@ -203,6 +207,8 @@ int comm_allgather(kfsp_ctx *ctx, const double *send, double *recv, size_t count
 int comm_allgather_bytes(kfsp_ctx *ctx, const void *send, void *recv, size_t bytes, hipStream_t st)
 {
     if (!ctx->loop) {
+        std::lock_guard<std::mutex> lk(ctx->comm_mu);
+        if (ctx->comm_aborted) return fail(ctx, 2999, "the communicator was aborted");
         NCCL_TRY(ncclAllGather(send, recv, bytes, ncclUint8, ctx->comm, st));
         return 0;
     }
@@ -216,6 +222,29 @@ int comm_allgather_bytes(kfsp_ctx *ctx, const void *send, void *recv, size_t byt
     if (!g->barrier()) return fail(ctx, 2999, "loop-back barrier timed out");
     return 0;
 }
+
+}  // namespace
+
+namespace kfsp {
+// Called from ANOTHER thread than the one that drives ctx (the watchdog of a group context, kfsp_group.cpp) when a peer
+// failed or a deadline expired: the rank may sit in hipStreamSynchronize behind a collective its peers never entered.
+// ncclCommAbort makes the collective's kernel give up; the loop-back transport releases its barriers.  The rank's
+// pending call then returns an error, later collectives return 2999.  comm_mu keeps the abort from running while
+// the driving thread is in the middle of enqueuing on the same communicator.
+void comm_abort(kfsp_ctx *ctx)
+{
+    if (ctx->loop) {
+        ctx->loop->abort();
+        return;
+    }
+    std::lock_guard<std::mutex> lk(ctx->comm_mu);
+    if (ctx->comm && !ctx->comm_aborted) (void)ncclCommAbort(ctx->comm);
+    ctx->comm = nullptr;
+    ctx->comm_aborted = true;
+}
+}  // namespace kfsp
+
+namespace {
 
 // Make block partials a scalar every rank agrees on.
 int publish(kfsp_ctx *ctx, Pending local, Pending *out)
@@ -371,6 +400,8 @@ int exchange_strips(kfsp_ctx *ctx, const double *src_local, hipStream_t st)
         // nranks * 2H doubles to every rank for the 2H it needs).
         const bool up = ctx->rank > 0, down = ctx->rank + 1 < ctx->nranks;
         if (!ctx->loop) {
+            std::lock_guard<std::mutex> lk(ctx->comm_mu);
+            if (ctx->comm_aborted) return fail(ctx, 2999, "the communicator was aborted");
             NCCL_TRY(ncclGroupStart());
             if (up) {
                 NCCL_TRY(ncclSend(src_local, (size_t)H, ncclDouble, ctx->rank - 1, ctx->comm, st));
@@ -468,7 +499,11 @@ int setup_exchange(kfsp_ctx *ctx)
 
 // (Re)size everything that depends on the number of states.
 // M_MAX + 2 basis columns and one scratch column (option m_max caps it: at 10^8 states 105 columns are 90 GB)
-inline int num_cols(const kfsp_ctx *c) { return (int)c->opt_mmax + 3; }
+// num_cols: the columns d_V HAS (option m_max only takes effect when the next generator re-lays the basis, so every
+// bound and the scratch-column index follow v_mmax, the value the allocation was made with); mmax_now: the largest m
+// a caller may use right now
+inline int num_cols(const kfsp_ctx *c) { return (int)(c->v_mmax ? c->v_mmax : c->opt_mmax) + 3; }
+inline int64_t mmax_now(const kfsp_ctx *c) { return c->v_mmax ? std::min(c->v_mmax, c->opt_mmax) : c->opt_mmax; }
 
 // column j (0-based) of the basis: `margin` halo rows sit on either side of it
 inline double *vcol(const kfsp_ctx *c, int j) { return c->d_V.p + (size_t)j * (size_t)c->ldv + (size_t)c->margin; }
@@ -494,6 +529,7 @@ int resize(kfsp_ctx *ctx, int64_t n)
         // (head room: half as much again, but no more than 2^24 rows - at 10^8 states 50 % would be 70 GB)
         ldv = ctx->relayout ? need : round_up(need + std::min<int64_t>(need / 2, (int64_t)1 << 24), 256);
         ctx->relayout = false;
+        ctx->v_mmax = ctx->opt_mmax;
         HIP_TRY(ctx->d_V.reserve((size_t)ldv * num_cols(ctx), false));
         HIP_TRY(ctx->d_w.reserve((size_t)ldv, false));
         HIP_TRY(ctx->d_tmp.reserve((size_t)ldv, false));
@@ -775,6 +811,17 @@ int kfsp_create_group(int nranks, const int *devices, kfsp_ctx **out)
     }
 }
 
+int kfsp_group_selftest(int nranks, int failing_rank, int hanging_rank, int work_ms, int hang_ms, int timeout_ms, int grace_ms,
+                        int settle_ms, int *rc_out, int *who_out, double *seconds, int *broken, int *stuck)
+{
+    try {
+        return kfsp::group_selftest(nranks, failing_rank, hanging_rank, work_ms, hang_ms, timeout_ms, grace_ms, settle_ms, rc_out,
+                                    who_out, seconds, broken, stuck);
+    } catch (...) {
+        return 4000;
+    }
+}
+
 int kfsp_group_size(const kfsp_ctx *ctx, int *nranks)
 {
     if (!ctx) return -1;
@@ -845,6 +892,7 @@ int kfsp_comm_init(kfsp_ctx *ctx, int nranks, int rank, const void *id_bytes)
         ctx->comm = nullptr;
     }
     ctx->loop = nullptr;
+    ctx->comm_aborted = false;
     ctx->nranks = nranks;
     ctx->rank = rank;
     // a unique id with nranks == 1 still creates a (one-rank) communicator, so the
@@ -1496,7 +1544,7 @@ int kfsp_arnoldi(kfsp_ctx *ctx, int m, int jold, int qiop, double break_tol, dou
     // m >= n is legal: the reference only caps M at N-1 when a step starts (:211),
     // a dimension change (:404) may exceed it and runs into a breakdown instead
     if (m < 1 || m > kMMax) return fail(ctx, -2, "bad m (need 1 <= m <= 100)");
-    if (m > ctx->opt_mmax) return fail(ctx, -2, "m exceeds option m_max (the basis was allocated for fewer columns)");
+    if (m > mmax_now(ctx)) return fail(ctx, -2, "m exceeds option m_max (the basis was allocated for fewer columns; a raised m_max applies from the next generator)");
     if (jold < 1 || jold > kMMax) return fail(ctx, -3, "bad jold");
     if (qiop < 0) return fail(ctx, -4, "bad qiop");
     if (!H) return fail(ctx, -6, "null H");
@@ -1658,7 +1706,7 @@ int kfsp_combine(kfsp_ctx *ctx, int mx, double beta, const double *y, double *ws
 {
     if (!ctx) return -1;
     if (ctx->ldv == 0) return fail(ctx, -1, "no matrix set");
-    if (mx < 1 || mx > ctx->opt_mmax + 2) return fail(ctx, -2, "bad mx");
+    if (mx < 1 || mx > mmax_now(ctx) + 2) return fail(ctx, -2, "bad mx");
     if (!y) return fail(ctx, -4, "null y");
     if (!wsum) return fail(ctx, -5, "null wsum");
     if (ctx->group) return kfsp::group_combine(ctx, mx, beta, y, wsum);
@@ -2177,7 +2225,7 @@ int kfsp_get_basis(kfsp_ctx *ctx, int j, int64_t nlocal, double *v)
     if (!ctx) return -1;
     if (ctx->ldv == 0) return fail(ctx, -1, "no matrix set");
     if (ctx->group) return kfsp::group_get_basis(ctx, j, nlocal, v);
-    if (j < 1 || j > ctx->opt_mmax + 2) return fail(ctx, -2, "bad column");
+    if (j < 1 || j > mmax_now(ctx) + 2) return fail(ctx, -2, "bad column");
     if (nlocal != ctx->nloc) return fail(ctx, -3, "nlocal is not this rank's block size");
     if (!v && nlocal > 0) return fail(ctx, -4, "null v");
     HIP_TRY(hipSetDevice(ctx->device));
@@ -2195,7 +2243,7 @@ int kfsp_expv_fixed(kfsp_ctx *ctx, int m, double tau, int nsteps, double *wsums)
     return no_throw(ctx, [&]() -> int {
         if (!ctx) return -1;
         if (ctx->ldv == 0) return fail(ctx, -1, "no matrix set");
-        if (m < 1 || m > ctx->opt_mmax || (int64_t)m >= ctx->n) return fail(ctx, -2, "bad m");
+        if (m < 1 || m > mmax_now(ctx) || (int64_t)m >= ctx->n) return fail(ctx, -2, "bad m");
         if (nsteps < 0) return fail(ctx, -4, "bad nsteps");
         const int mh = m + 2;
         std::vector<double> H((size_t)mh * mh), E((size_t)mh * mh);

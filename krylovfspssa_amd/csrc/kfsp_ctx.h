@@ -104,10 +104,12 @@ struct LoopGroup {
     int arrived = 0;
     uint64_t generation = 0;
     std::vector<const void *> slot;   // what each rank contributes to the collective in flight
-    // false = a peer did not arrive within 120 s (its thread died): the caller reports an error
+    bool aborted = false;             // sticky: a peer failed or a deadline expired (abort()); every barrier returns false
+    // false = a peer did not arrive within 120 s (its thread died) or the group was aborted: the caller reports an error
     bool barrier()
     {
         std::unique_lock<std::mutex> lk(mu);
+        if (aborted) return false;
         const uint64_t gen = generation;
         if (++arrived == n) {
             arrived = 0;
@@ -115,7 +117,17 @@ struct LoopGroup {
             cv.notify_all();
             return true;
         }
-        return cv.wait_for(lk, std::chrono::seconds(120), [&] { return generation != gen; });
+        const bool ok = cv.wait_for(lk, std::chrono::seconds(120), [&] { return aborted || generation != gen; });
+        return ok && generation != gen;
+    }
+    // releases every rank waiting in a barrier (they report 2999); the transport is dead afterwards
+    void abort()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            aborted = true;
+        }
+        cv.notify_all();
     }
 };
 
@@ -140,6 +152,8 @@ struct kfsp_ctx {
     // partition
     int nranks = 1, rank = 0;
     ncclComm_t comm = nullptr;
+    std::mutex comm_mu;                // held while a collective is ENQUEUED on comm, and by comm_abort (kfsp_api.cpp)
+    bool comm_aborted = false;         // sticky (under comm_mu): the communicator was aborted, every collective returns 2999
     kfsp::LoopGroup *loop = nullptr;   // loop-back transport instead of RCCL (kfsp_comm_init_loopback)
     double *h_loop = nullptr;          // its pinned scratch
     bool use_comm = false;   // collectives on the data path (nranks > 1, or a 1-rank communicator for testing)
@@ -290,7 +304,8 @@ struct kfsp_ctx {
                                           // measured slower than format 4 on every box: DESIGN.md 4.1b - off by default)
     int64_t opt_box_reach = 512;          // largest shift (rows) served from that window
     int64_t opt_box_generic = 0;          // 1: matrix-free boxes always take the run-time interpreted kernel
-    int64_t opt_mmax = kfsp::kMMax;        // largest Krylov dimension the basis is allocated for (m_max + 3 columns)
+    int64_t opt_mmax = kfsp::kMMax;        // largest Krylov dimension the NEXT basis is allocated for (m_max + 3 columns)
+    int64_t v_mmax = 0;                    // ... and the one the basis in d_V WAS allocated for (resize); 0: no basis yet
     int64_t opt_ssa_resident = 0;          // 1: the caller vouches that the arrays given to kfsp_ssa_streams are the ones last uploaded
     int64_t coords_n = 0;                  // states whose coordinates sit in d_coords (kfsp_set_state_coords), 0: none
     int32_t coords_ld = 0, coords_ns = 0;
@@ -306,6 +321,9 @@ struct kfsp_ctx {
 
 namespace kfsp {
 // group contexts (kfsp_group.cpp): what each entry point of include/kfsp.h does when it is handed a head
+void comm_abort(kfsp_ctx *ctx);      // kfsp_api.cpp: release a rank blocked in a collective (called from the group's watchdog)
+int group_selftest(int nranks, int failing_rank, int hanging_rank, int work_ms, int hang_ms, int timeout_ms, int grace_ms,
+                   int settle_ms, int *rc_out, int *who_out, double *seconds, int *broken, int *stuck);
 int group_create(int nranks, const int *devices, kfsp_ctx **out);
 int group_destroy(kfsp_ctx *h);
 int group_size(const kfsp_ctx *h);

@@ -13,6 +13,9 @@
 // the head.
 #include "kfsp_ctx.h"
 
+#include <algorithm>
+#include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <memory>
@@ -32,6 +35,21 @@ struct Group {
     bool quit = false;
     std::function<int(int)> job;
     std::vector<int> rc;
+    std::vector<char> done;
+    // Watchdog.  A rank that fails BEFORE a collective leaves its peers inside that collective for ever (RCCL), or until
+    // the loop-back barrier's own 120 s guard; a rank that hangs keeps everyone.  So run() waits with two clocks: once
+    // any rank has returned an error the others get grace_s to come back, and the whole fan-out gets timeout_s; when
+    // either expires the communicators of ALL ranks are aborted (comm_abort: ncclCommAbort / the loop-back release), which
+    // makes the blocked ranks return, the failing rank's error is reported ("rank p: ..."), and the group is BROKEN:
+    // every later call returns 2999 at once (a partition whose ranks have lost step cannot be continued - destroy it and
+    // make a new one).  Ranks that do not return even after the abort (settle_s) are left behind: the group is STUCK, its
+    // threads are detached at destruction, code 2998.  Nothing here ever ends the process.
+    // Options on the head: "group_timeout_ms", "group_grace_ms", "group_settle_ms"; environment KFSP_GROUP_TIMEOUT_S,
+    // KFSP_GROUP_GRACE_S for callers without access to options (the Fortran host).
+    double timeout_s = 1800.0, grace_s = 15.0, settle_s = 30.0;
+    bool broken = false, stuck = false;
+    int inject_rank = -1;              // test hook (option "group_inject_failure"): this rank fails its next job with -77
+    std::function<void()> abort_all;   // releases ranks blocked in a collective
 
     void worker(int p)
     {
@@ -54,30 +72,63 @@ struct Group {
             {
                 std::lock_guard<std::mutex> lk(mu);
                 rc[(size_t)p] = r;
-                if (--pending == 0) cv_done.notify_all();
+                done[(size_t)p] = 1;
+                --pending;
+                if (pending == 0 || r != 0) cv_done.notify_all();
             }
         }
     }
 
-    // f(p) on the thread of rank p, all ranks at once; first non-zero return code (and that rank)
+    // f(p) on the thread of rank p, all ranks at once; first non-zero return code (and that rank).  *who = -1 with 2999 /
+    // 2998: the group was aborted earlier, or no rank failed and the deadline expired.
     int run(const std::function<int(int)> &f, int *who = nullptr)
     {
+        using clock = std::chrono::steady_clock;
+        if (who) *who = -1;
         {
             std::lock_guard<std::mutex> lk(mu);
+            if (stuck) return 2998;
+            if (broken) return 2999;
             job = f;
             pending = n;
+            std::fill(done.begin(), done.end(), 0);
+            std::fill(rc.begin(), rc.end(), 0);
             ++gen;
         }
         cv_go.notify_all();
+        bool expired = false;
         {
             std::unique_lock<std::mutex> lk(mu);
-            cv_done.wait(lk, [&] { return pending == 0; });
+            const clock::time_point t_end = clock::now() + std::chrono::duration_cast<clock::duration>(std::chrono::duration<double>(timeout_s));
+            clock::time_point t_fail = clock::time_point::max();
+            while (pending != 0) {
+                if (t_fail == clock::time_point::max())
+                    for (int p = 0; p < n; ++p)
+                        if (done[(size_t)p] && rc[(size_t)p] != 0)
+                            t_fail = clock::now() + std::chrono::duration_cast<clock::duration>(std::chrono::duration<double>(grace_s));
+                const clock::time_point wake = std::min(t_end, t_fail);
+                if (clock::now() >= wake) {
+                    expired = true;
+                    break;
+                }
+                cv_done.wait_until(lk, wake);
+            }
         }
+        if (expired) {
+            if (abort_all) abort_all();
+            std::unique_lock<std::mutex> lk(mu);
+            broken = true;
+            const bool back = cv_done.wait_for(lk, std::chrono::duration<double>(settle_s), [&] { return pending == 0; });
+            if (!back) stuck = true;
+        }
+        std::lock_guard<std::mutex> lk(mu);
+        // the rank that failed on its own is the one to name: ranks released by the abort report 2999
         for (int p = 0; p < n; ++p)
-            if (rc[(size_t)p] != 0) {
+            if (done[(size_t)p] && rc[(size_t)p] != 0 && !(expired && rc[(size_t)p] == 2999)) {
                 if (who) *who = p;
                 return rc[(size_t)p];
             }
+        if (expired) return stuck ? 2998 : 2999;
         return 0;
     }
 };
@@ -94,9 +145,22 @@ int gfail(kfsp_ctx *h, int code, const char *what)
 int gall(kfsp_ctx *h, const std::function<int(kfsp_ctx *, int)> &f)
 {
     Group *g = h->group;
-    int who = 0;
-    const int rc = g->run([&](int p) { return f(g->sub[(size_t)p], p); }, &who);
-    if (rc) h->err = std::string("rank ") + std::to_string(who) + ": " + kfsp_last_error(g->sub[(size_t)who]);
+    int who = -1;
+    const int inject = g->inject_rank;
+    g->inject_rank = -1;
+    const int rc = g->run([&](int p) {
+        if (p == inject) {
+            g->sub[(size_t)p]->err = "injected failure (option group_inject_failure)";
+            return -77;
+        }
+        return f(g->sub[(size_t)p], p);
+    }, &who);
+    if (rc) {
+        if (who >= 0) h->err = std::string("rank ") + std::to_string(who) + ": " + kfsp_last_error(g->sub[(size_t)who]);
+        else h->err = rc == 2998 ? "group context: ranks did not return even after their communicators were aborted"
+                                 : "group context: aborted (a rank failed or the deadline of a call expired earlier); destroy it";
+        if (g->broken && who >= 0) h->err += " [the other ranks were released by aborting the communicator; the group is unusable now]";
+    }
     return rc;
 }
 
@@ -126,6 +190,15 @@ int group_create(int nranks, const int *devices, kfsp_ctx **out)
     g->n = nranks;
     g->sub.assign((size_t)nranks, nullptr);
     g->rc.assign((size_t)nranks, 0);
+    g->done.assign((size_t)nranks, 0);
+    if (const char *e = std::getenv("KFSP_GROUP_TIMEOUT_S")) {
+        const double v = std::atof(e);
+        if (v > 0.0) g->timeout_s = v;
+    }
+    if (const char *e = std::getenv("KFSP_GROUP_GRACE_S")) {
+        const double v = std::atof(e);
+        if (v > 0.0) g->grace_s = v;
+    }
     // distinct devices: RCCL between them; a device named twice: the loop-back transport
     bool distinct = true;
     for (int p = 0; p < nranks; ++p)
@@ -158,6 +231,13 @@ int group_create(int nranks, const int *devices, kfsp_ctx **out)
         return 4001;
     }
     kfsp_ctx *h = head.get();
+    {
+        Group *gp = g.get();
+        gp->abort_all = [gp] {
+            for (kfsp_ctx *c : gp->sub)
+                if (c) comm_abort(c);
+        };
+    }
     if (nranks > 1) {
         unsigned char id[KFSP_UNIQUE_ID_BYTES];
         if (distinct) rc = kfsp_comm_unique_id(id);
@@ -181,10 +261,29 @@ int group_create(int nranks, const int *devices, kfsp_ctx **out)
 int group_destroy(kfsp_ctx *h)
 {
     Group *g = h->group;
+    bool stuck;
+    {
+        std::lock_guard<std::mutex> lk(g->mu);
+        stuck = g->stuck;
+        g->broken = false;             // (the contexts of a broken group are still destroyed on their own threads)
+    }
+    if (stuck) {
+        // some rank never came back from its last call: its thread, its context and the shared state it may still touch
+        // are abandoned (leaked) rather than joined - the caller gets its thread back
+        for (std::thread &t : g->th) t.detach();
+        delete h;
+        return 2998;
+    }
     (void)g->run([&](int p) { return kfsp_destroy(g->sub[(size_t)p]); });
     {
         std::lock_guard<std::mutex> lk(g->mu);
         g->quit = true;
+        stuck = g->stuck;
+    }
+    if (stuck) {
+        for (std::thread &t : g->th) t.detach();
+        delete h;
+        return 2998;
     }
     g->cv_go.notify_all();
     for (std::thread &t : g->th) t.join();
@@ -198,6 +297,18 @@ int group_size(const kfsp_ctx *h) { return h->group->n; }
 
 int group_set_option(kfsp_ctx *h, const char *name, int64_t value)
 {
+    Group *g = h->group;
+    const std::string k(name ? name : "");
+    if (k == "group_timeout_ms" || k == "group_grace_ms" || k == "group_settle_ms") {
+        if (value < 1) return gfail(h, -3, "a positive number of milliseconds");
+        (k == "group_timeout_ms" ? g->timeout_s : k == "group_grace_ms" ? g->grace_s : g->settle_s) = 1e-3 * (double)value;
+        return 0;
+    }
+    if (k == "group_inject_failure") {      // test hook: rank `value` fails the NEXT fan-out with -77 before doing anything
+        if (value < -1 || value >= g->n) return gfail(h, -3, "no such rank");
+        g->inject_rank = (int)value;
+        return 0;
+    }
     return gall(h, [&](kfsp_ctx *c, int) { return kfsp_set_option(c, name, value); });
 }
 
@@ -493,6 +604,61 @@ int group_get_timers(kfsp_ctx *h, double *ms, int reset)
     for (int i = 0; i < KFSP_T_COUNT; ++i) ms[i] = t0[i] + h->t_ms[i];
     if (reset)
         for (double &t : h->t_ms) t = 0.0;
+    return 0;
+}
+
+// The watchdog on its own, no device anywhere (tests/test_group_watchdog.py, runs without a GPU): `nranks` worker threads
+// and a loop-back transport; every rank sleeps work_ms, rank `failing_rank` (or none: -1) then returns -77 BEFORE the
+// collective, rank `hanging_rank` (or none) sleeps hang_ms instead of entering it, the others enter one loop-back barrier
+// (returning 2999 when it is released by the abort).  Out: the code run() returned, the rank it blamed, the seconds it
+// took, and whether the group ended broken / stuck.
+int group_selftest(int nranks, int failing_rank, int hanging_rank, int work_ms, int hang_ms, int timeout_ms, int grace_ms,
+                   int settle_ms, int *rc_out, int *who_out, double *seconds, int *broken, int *stuck)
+{
+    if (nranks < 1 || nranks > 64 || !rc_out || !who_out || !seconds || !broken || !stuck) return -1;
+    Group *g = new (std::nothrow) Group;       // (leaked when a rank is left behind - it may still touch it)
+    LoopGroup *loop = new (std::nothrow) LoopGroup;
+    if (!g || !loop) return 4001;
+    g->n = nranks;
+    g->rc.assign((size_t)nranks, 0);
+    g->done.assign((size_t)nranks, 0);
+    g->timeout_s = 1e-3 * timeout_ms;
+    g->grace_s = 1e-3 * grace_ms;
+    g->settle_s = 1e-3 * settle_ms;
+    loop->n = nranks;
+    loop->slot.assign((size_t)nranks, nullptr);
+    g->abort_all = [loop] { loop->abort(); };
+    for (int p = 0; p < nranks; ++p) g->th.emplace_back(&Group::worker, g, p);
+    const auto t0 = std::chrono::steady_clock::now();
+    int who = -1;
+    const int rc = g->run([&](int p) {
+        std::this_thread::sleep_for(std::chrono::milliseconds(work_ms));
+        if (p == failing_rank) return -77;
+        if (p == hanging_rank) {
+            std::this_thread::sleep_for(std::chrono::milliseconds(hang_ms));
+            return 0;
+        }
+        return loop->barrier() ? 0 : 2999;
+    }, &who);
+    *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    *rc_out = rc;
+    *who_out = who;
+    *broken = g->broken ? 1 : 0;
+    *stuck = g->stuck ? 1 : 0;
+    // a second call on a broken group must come back at once
+    if (g->broken && g->run([](int) { return 0; }) == 0) return -2;
+    if (g->stuck) {
+        for (std::thread &t : g->th) t.detach();
+        return 0;
+    }
+    {
+        std::lock_guard<std::mutex> lk(g->mu);
+        g->quit = true;
+    }
+    g->cv_go.notify_all();
+    for (std::thread &t : g->th) t.join();
+    delete loop;
+    delete g;
     return 0;
 }
 

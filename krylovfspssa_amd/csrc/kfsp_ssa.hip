@@ -615,7 +615,10 @@ int ssa_streams_core(kfsp_ctx *ctx, double tstep, int64_t seedmix, int32_t ns, i
     A.tab = d_tab;
     A.tmask = slots - 1;
     A.P = prop_dev(ctx);
-    const bool fast = ns <= 8 && nr <= 16 && !ctx->opt_ssa_general;
+    bool fast = ns <= 8 && nr <= 16 && !ctx->opt_ssa_general;
+    // (the register-resident kernels keep a reaction vector as signed bytes: a coefficient outside them takes the general kernel)
+    for (size_t i = 0; i < (size_t)nr * ns; ++i)
+        if (stoich[i] < -128 || stoich[i] > 127) fast = false;
     // one wavefront per kSsaSeedsPerWave seed states (4 wavefronts per workgroup); the record list is sized by a guess
     // and, should the paths meet more unlisted states than that, by the count the first attempt returns
     const int wgrid = (int)(((long long)n + 4 * kSsaSeedsPerWave - 1) / (4 * kSsaSeedsPerWave));

@@ -106,6 +106,7 @@ CONTAINS
     REAL(C_DOUBLE) :: TMS(7)
     INTEGER :: I, N0, RC
     INTEGER(8) :: C0, C1, CRATE
+    LOGICAL :: WAS_RESIDENT
 
     IFLAG = 0
     ! the device context comes first: the threads its runtime starts must not
@@ -159,6 +160,7 @@ CONTAINS
        CALL CHECK(RC, 'kfsp_dgexpv')
     ENDIF
 
+    WAS_RESIDENT = RESIDENT
     IF (RESIDENT) THEN
        ! the lists as the device left them; keys and look-up table of this side follow
        N0 = FSP%SIZE
@@ -183,6 +185,10 @@ CONTAINS
        PRINT '(A,F12.1,A,7(1X,A,F11.1))', ' KFSP WALL MS =', 1.0D3 * DBLE(C1 - C0) / DBLE(CRATE), ' :', &
             'ARNOLDI', TMS(1), 'COMBINE', TMS(2), 'BEGIN_STEP', TMS(3), 'FSP_CALLBACKS', TMS(4), &
             'HOST_PADE', TMS(5), 'UPLOAD', TMS(6), 'DEVICE_ONESTEP', TMS(7)
+       ! which side kept the lists (RESIDENT: the device, DESIGN.md 10.6), whether the model's propensities were there, and
+       ! how the SSA paths were sampled (REFERENCE: one stream, the reference's order; STREAMS: one stream per path)
+       PRINT '(A,A,A,A,A,A)', ' KFSP MODE: LISTS = ', TRIM(MERGE('RESIDENT', 'HOST    ', WAS_RESIDENT)), ' PROPENSITIES = ', &
+            TRIM(MERGE('DEVICE', 'HOST  ', PROGRAM_READY)), ' SSA = ', TRIM(MERGE('STREAMS  ', 'REFERENCE', SSA_STREAMS_REQUESTED()))
        PRINT '(A,I8,A,I8,A,I8,A,I6,A,I6)', ' KFSP STATS: NMULT =', LAST_SOLVE_STATS%NMULT, ' NEXPH =', &
             LAST_SOLVE_STATS%NEXPH, ' WSUM_EVALS =', LAST_SOLVE_STATS%N_WSUM, ' EXPANSIONS =', &
             LAST_SOLVE_STATS%N_EXPAND, ' DROP_CALLS =', LAST_SOLVE_STATS%N_DROP_CALLS

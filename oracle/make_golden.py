@@ -363,7 +363,49 @@ def save_goutsias_T300(binfile, logtext):
     print(f"goutsias T=300: N={d['n']} steps={len(log['step_no'])} mass={d['vector'].sum()!r}")
 
 
+# G9: digests of whole reference runs at the horizons the end-to-end times are quoted on (name -> case, T, FSPTOL,
+# KRYTOL, FSP capacity); `make_golden.py digest [name ...]` runs the compiled reference, `make_golden.py digest
+# name file.bin file.log` digests an existing run.  goutsias_example = examples/transcr6d.f90 (compiled-in propensities,
+# ~40 min on one core), repressilator_example = examples/repressilator.f90, toggle_example = examples/toggle.f90.
+DIGEST_CASES = {
+    "toggle_input_T1000": ("toggle_input", 1000.0, 1e-4, 1e-10, None),
+    "repressilator_input_T10": ("repressilator_input", 10.0, 1e-4, 1e-10, 2097169),
+    "toggle_example_T100": ("toggle_example", 100.0, 1e-4, 1e-8, None),
+    "repressilator_example_T10": ("repressilator_example", 10.0, 1e-4, 1e-14, 2097169),
+    "goutsias_example_T300": ("goutsias_example", 300.0, 1e-6, 1e-8, 2097169),
+}
+
+
+def save_digest(name, binfile, logtext):
+    case, T, fsptol, krytol, cap = DIGEST_CASES[name]
+    d = read_fsp(binfile)
+    log = parse_log(logtext)
+    np.savez_compressed(os.path.join(GOLDEN, f"digest_{name}.npz"), T=T, fsptol=fsptol, krytol=krytol,
+                        steps=np.int32(len(log["step_no"])), n_ssa=log["n_ssa"], peak_n=np.int64(log["step_n"].max()),
+                        **fsp_digest(d))
+    print(f"digest {name}: N={d['n']} steps={len(log['step_no'])} mass={d['vector'].sum()!r}")
+
+
+def make_digests(only=()):
+    tmp = tempfile.mkdtemp(prefix="kfsp_golden_")
+    for name, (case, T, fsptol, krytol, cap) in DIGEST_CASES.items():
+        if only and name not in only:
+            continue
+        p = os.path.join(tmp, name + ".bin")
+        env = dict(os.environ, MKL_NUM_THREADS="1", **({"KFSP_CASE_CAPACITY": str(cap)} if cap else {}))
+        cmd = f"ulimit -s unlimited && exec ../ref_dump solve {case} {p} {T!r}"
+        text = subprocess.run(["bash", "-c", cmd], cwd=os.path.join(REF_DIR, "models"), env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, check=True, text=True).stdout
+        save_digest(name, p, text)
+
+
 def main():
+    if sys.argv[1:2] == ["digest"]:
+        if len(sys.argv) == 5 and sys.argv[2] in DIGEST_CASES and os.path.exists(sys.argv[3]):
+            save_digest(sys.argv[2], sys.argv[3], open(sys.argv[4]).read())      # from an existing run
+        else:
+            make_digests(set(sys.argv[2:]))
+        return
     if sys.argv[1:2] == ["goutsias300"]:
         if len(sys.argv) > 3:
             save_goutsias_T300(sys.argv[2], open(sys.argv[3]).read())      # from an existing run

@@ -38,6 +38,35 @@ CONTAINS
     IF (REACTION == 4) TOGGLE_EXAMPLE_PROP = PARAMETERS(6) * STATE(2)
   END FUNCTION TOGGLE_EXAMPLE_PROP
 
+  DOUBLE PRECISION FUNCTION REPRESSILATOR_EXAMPLE_PROP(STATE, REACTION, PARAMETERS)
+    ! the propensities of examples/repressilator.f90:50-69, restated (Hill exponent 6, births and deaths interleaved)
+    INTEGER, INTENT(IN) :: STATE(:), REACTION
+    DOUBLE PRECISION, INTENT(IN), OPTIONAL :: PARAMETERS(:)
+    INTEGER :: S, R
+    S = (REACTION + 1) / 2                          ! the species reaction 2S-1 makes and 2S removes
+    R = MOD(S, 3) + 1                               ! its repressor: 2, 3, 1
+    IF (MOD(REACTION, 2) == 1) THEN
+       REPRESSILATOR_EXAMPLE_PROP = PARAMETERS(1) / (1D0 + PARAMETERS(2) * STATE(R)**6.0D0)
+    ELSE
+       REPRESSILATOR_EXAMPLE_PROP = PARAMETERS(3) * STATE(S)
+    ENDIF
+  END FUNCTION REPRESSILATOR_EXAMPLE_PROP
+
+  DOUBLE PRECISION FUNCTION GOUTSIAS_EXAMPLE_PROP(STATE, REACTION, PARAMETERS)
+    ! the propensities of examples/transcr6d.f90:63-90, restated; species M, D, RNA, DNA, DNA.D, DNA.2D = 1..6
+    INTEGER, INTENT(IN) :: STATE(:), REACTION
+    DOUBLE PRECISION, INTENT(IN), OPTIONAL :: PARAMETERS(:)
+    INTEGER, PARAMETER :: FIRST(10) = [3, 1, 5, 3, 4, 5, 5, 6, 1, 2]
+    SELECT CASE (REACTION)
+    CASE (5, 7)
+       GOUTSIAS_EXAMPLE_PROP = PARAMETERS(REACTION) * STATE(FIRST(REACTION)) * STATE(2)
+    CASE (9)
+       GOUTSIAS_EXAMPLE_PROP = PARAMETERS(9) * (STATE(1) * (STATE(1) - 1) / 2)
+    CASE DEFAULT
+       GOUTSIAS_EXAMPLE_PROP = PARAMETERS(REACTION) * STATE(FIRST(REACTION))
+    END SELECT
+  END FUNCTION GOUTSIAS_EXAMPLE_PROP
+
   SUBROUTINE LOAD_INPUT_MODEL(NAME, MODEL, X0)
     ! the three complete models/*.input files (keywords upper-cased by the
     ! Makefile: ModelModule.f90:95-140 matches upper case only) with the
@@ -178,6 +207,33 @@ CONTAINS
        ! models/goutsias_model.input with the tolerances of examples/transcr6d.f90:16
        CALL LOAD_INPUT_MODEL('goutsias', MODEL, X0)
        T = 300.0D0; FSPTOL = 1.0D-6; KRYTOL = 1.0D-8
+       CALL SEED_POINT(MODEL, FSP_IN, FSP, X0)
+    CASE ('repressilator_example')
+       ! examples/repressilator.f90:14-42 (compiled-in propensities; stoichiometry :24, parameters :26, seed :36)
+       CALL MODEL%CREATE(3, 6, 3)
+       MODEL%STOICHIOMETRY = RESHAPE((/1, 0, 0, -1, 0, 0, 0, 1, 0, 0, -1, 0, 0, 0, 1, 0, 0, -1/), (/3, 6/))
+       MODEL%CUSTOMPROP => REPRESSILATOR_EXAMPLE_PROP
+       CALL MODEL%RESET_PARAMETERS([100.0D0, 25.0D0, 1.0D0])
+       MODEL%LOADED = .TRUE.
+       T = 10.0D0; FSPTOL = 1.0D-4; KRYTOL = 1.0D-14
+       X0 = [22, 0, 0]
+       CALL SEED_POINT(MODEL, FSP_IN, FSP, X0)
+    CASE ('goutsias_example')
+       ! examples/transcr6d.f90:14-56 (compiled-in propensities :63-90, stoichiometry :92-131, parameters :23-32)
+       CALL MODEL%CREATE(6, 10, 10)
+       MODEL%STOICHIOMETRY = 0
+       MODEL%STOICHIOMETRY(1, 1) = 1;   MODEL%STOICHIOMETRY(1, 2) = -1
+       MODEL%STOICHIOMETRY(3, 3) = 1;   MODEL%STOICHIOMETRY(3, 4) = -1
+       MODEL%STOICHIOMETRY([4, 2, 5], 5) = [-1, -1, 1];  MODEL%STOICHIOMETRY([4, 2, 5], 6) = [1, 1, -1]
+       MODEL%STOICHIOMETRY([5, 2, 6], 7) = [-1, -1, 1];  MODEL%STOICHIOMETRY([5, 2, 6], 8) = [1, 1, -1]
+       MODEL%STOICHIOMETRY([1, 2], 9) = [-2, 1];         MODEL%STOICHIOMETRY([1, 2], 10) = [2, -1]
+       MODEL%CUSTOMPROP => GOUTSIAS_EXAMPLE_PROP
+       CALL MODEL%RESET_PARAMETERS([0.043D0, 0.0007D0, 0.0715D0, 0.0039D0, &
+            0.0199264663575241D0, 0.4791D0, 0.000199264663575241D0, &
+            0.8765D0 * 1.0D-11, 0.0830269431563506104D0, 0.5D0])
+       MODEL%LOADED = .TRUE.
+       T = 300.0D0; FSPTOL = 1.0D-6; KRYTOL = 1.0D-8
+       X0 = [2, 6, 0, 2, 0, 0]
        CALL SEED_POINT(MODEL, FSP_IN, FSP, X0)
     CASE ('ring6')
        ! closed 6-species ring, 8 molecules: every state is seeded, nothing

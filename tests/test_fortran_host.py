@@ -451,34 +451,77 @@ def test_compute_rkey_returns_the_reference_key_changes(tmp_path):
         assert key([a + b for a, b in zip(x, v)]) == key(x) + sgn * rk
 
 
-@pytest.mark.gpu
-def test_goutsias_full_horizon_agrees_with_the_reference(dump, tmp_path):
-    """models/goutsias_model.input over the horizon of the reference's own example (examples/transcr6d.f90:16:
-    T = 300, FSPTOL 1e-6, KRYTOL 1e-8; the FSP grows to ~10^6 states; ~40 min on one CPU core for the
-    reference, ~30 s here).  Over 300+ steps the two runs take different - equally valid - step and
-    expansion decisions, so the result is compared as a distribution: every species'
-    marginal and the 4000 most probable states, against the digest of the reference's result
-    (oracle/make_golden.py goutsias300), within the solver's own error budget
-    FSPTOL + 2 * DELTA * KRYTOL * T = 1e-6 + 7.2e-6."""
-    g = np.load(os.path.join(GOLDEN, "digest_goutsias_input_T300.npz"))
-    p = str(tmp_path / "g.bin")
-    text = _run(dump, ["solve", "goutsias_input", p, "300"], tmp_path, env={"KFSP_CASE_CAPACITY": "2097169"})
-    d = MG.read_fsp(p)
-    log = MG.parse_log(text)
+def _against_digest(d, log, g, text=""):
+    """A whole adaptive run against the digest of the reference's result at the same horizon (oracle/make_golden.py
+    fsp_digest: size, mass, every species' marginal, the 4000 most probable states).  Over hundreds of steps any two
+    implementations take different - equally valid - step, drop and expansion decisions, so the result
+    is compared as a distribution, within the solver's own error budget FSPTOL + 2 * DELTA * KRYTOL * T
+    (KrylovSolver.f90:314,375: the local error is held below DELTA * KRYTOL per unit time, on either side)."""
     budget = float(g["fsptol"]) + 2 * 1.2 * float(g["krytol"]) * float(g["T"])
     w = d["vector"]
     assert np.all(w >= 0) and 1.0 - w.sum() < float(g["fsptol"])
-    print(f"N={d['n']} (ref {int(g['n'])}) steps={len(log['step_no'])} (ref {int(g['steps'])}) mass={w.sum():.12f} (ref {float(g['mass']):.12f})")
-    assert 0.8 * int(g["n"]) < d["n"] < 1.25 * int(g["n"])
+    assert 0.8 * int(g["n"]) < d["n"] < 1.25 * int(g["n"]), (d["n"], int(g["n"]))
     worst = 0.0
     for s in range(int(g["ns"])):
         ref = g[f"marginal_{s}"]
         got = np.bincount(d["state"][:, s], weights=w)
         k = max(len(ref), len(got))
-        diff = np.abs(np.pad(ref, (0, k - len(ref))) - np.pad(got, (0, k - len(got)))).sum()
-        worst = max(worst, diff)
+        worst = max(worst, np.abs(np.pad(ref, (0, k - len(ref))) - np.pad(got, (0, k - len(got)))).sum())
     index = {tuple(x): i for i, x in enumerate(d["state"].tolist())}
     top = sum(abs(float(pr) - (w[index[tuple(x)]] if tuple(x) in index else 0.0))
               for x, pr in zip(g["top_state"].tolist(), g["top_prob"].tolist()))
-    print(f"worst marginal l1 {worst:.3e}, l1 over the reference's 4000 most probable states {top:.3e} (budget {budget:.1e})")
+    print(f"N={d['n']} (ref {int(g['n'])}) steps={len(log['step_no'])} (ref {int(g['steps'])}) mass={w.sum():.12f} "
+          f"(ref {float(g['mass']):.12f}) worst marginal l1 {worst:.3e}, l1 over the reference's {len(g['top_prob'])} most "
+          f"probable states {top:.3e} (budget {budget:.1e})")
     assert worst < budget and top < budget
+
+
+@pytest.mark.gpu
+def test_goutsias_full_horizon_agrees_with_the_reference(dump, tmp_path):
+    """models/goutsias_model.input over the horizon of the reference's own example (examples/transcr6d.f90:16:
+    T = 300, FSPTOL 1e-6, KRYTOL 1e-8; the FSP grows to ~10^6 states; ~40 min on one CPU core for the
+    reference, ~30 s here), in the DEFAULT mode (the reference's sampling order), against the digest of the reference's
+    result (oracle/make_golden.py goutsias300), budget 1e-6 + 7.2e-6."""
+    g = np.load(os.path.join(GOLDEN, "digest_goutsias_input_T300.npz"))
+    p = str(tmp_path / "g.bin")
+    text = _run(dump, ["solve", "goutsias_input", p, "300"], tmp_path, env={"KFSP_CASE_CAPACITY": "2097169"})
+    assert "LISTS = HOST" in text and "SSA = REFERENCE" in text
+    _against_digest(MG.read_fsp(p), MG.parse_log(text), g)
+
+
+# (digest, ref_dump case, T): BASELINE config 1 (test/TestSolverFromFile.f90:35), the repressilator .input model over the
+# horizon of examples/repressilator.f90:14, the Goutsias .input model over that of examples/transcr6d.f90:16
+HORIZONS = [("toggle_input_T1000", "toggle_input", 1000.0), ("repressilator_input_T10", "repressilator_input", 10.0),
+            ("goutsias_input_T300", "goutsias_input", 300.0)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks", [1, 2])
+@pytest.mark.parametrize("digest,case,T", HORIZONS)
+def test_resident_mode_agrees_with_the_reference_at_full_horizon(dump, tmp_path, digest, case, T, ranks):
+    """The mode the end-to-end times are quoted in (KFSP_SSA_STREAMS=1: independent-stream SSA paths, and with them the
+    RESIDENT loop - drop, walk, one-step sweep and generator rebuild on the device's own lists) samples
+    OTHER states than the reference's single stream does (StateSpace.f90:577-578); what it must reproduce is the
+    reference's RESULT.  Whole runs at the horizons of the reference's own drivers against digests of the unmodified
+    reference's output (oracle/make_golden.py digest), with one context and over a 2-rank row partition (KFSP_NRANKS=2,
+    loop-back group on the one GPU)."""
+    g = np.load(os.path.join(GOLDEN, f"digest_{digest}.npz"))
+    p = str(tmp_path / "g.bin")
+    env = {"KFSP_CASE_CAPACITY": "2097169", "KFSP_SSA_STREAMS": "1"}
+    if ranks > 1:
+        env["KFSP_NRANKS"] = str(ranks)
+    text = _run(dump, ["solve", case, p, repr(T)], tmp_path, env=env)
+    assert "LISTS = RESIDENT" in text and "PROPENSITIES = DEVICE" in text and "SSA = STREAMS" in text
+    _against_digest(MG.read_fsp(p), MG.parse_log(text), g)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("digest,case,T", HORIZONS[:2])
+def test_default_mode_agrees_with_the_reference_at_full_horizon(dump, tmp_path, digest, case, T):
+    """The same horizons in the DEFAULT mode (the reference's sampling order, lists on the host); Goutsias T = 300 is
+    test_goutsias_full_horizon_agrees_with_the_reference."""
+    g = np.load(os.path.join(GOLDEN, f"digest_{digest}.npz"))
+    p = str(tmp_path / "g.bin")
+    text = _run(dump, ["solve", case, p, repr(T)], tmp_path, env={"KFSP_CASE_CAPACITY": "2097169"})
+    assert "LISTS = HOST" in text and "SSA = REFERENCE" in text
+    _against_digest(MG.read_fsp(p), MG.parse_log(text), g)

@@ -51,6 +51,38 @@ def test_bad_arguments_return_status_codes(ctx):
     assert ctx.begin_step() == pytest.approx(0.1)
 
 
+def test_raised_m_max_applies_from_the_next_generator(oracle):
+    """Option m_max sizes the basis when a generator is set.  Raising it afterwards must not let kfsp_arnoldi (or the
+    scratch column of kfsp_spmv_w) run past the columns that ARE allocated: the larger m is refused (-2) until the next
+    generator re-lays the basis, then it works and agrees with the oracle."""
+    from krylovfspssa_amd import KfspContext, KfspError
+    rng = np.random.default_rng(3)
+    adj, off, diag = _random_generator(500, 4, rng)
+    A = oracle.EllMatrix(adj, off, diag)
+    p0 = rng.random(500)
+    p0 /= p0.sum()
+    with KfspContext(0) as c:
+        c.set_option("m_max", 8)
+        c.set_matrix_ell(adj, off, diag)
+        c.set_vector(p0)
+        c.begin_step()
+        c.arnoldi(8)
+        c.set_option("m_max", 100)                    # the basis still has 8 + 3 columns
+        with pytest.raises(KfspError, match="-2"):
+            c.arnoldi(20)
+        with pytest.raises(KfspError, match="-2"):
+            c.get_basis(20)
+        y = c.spmv_w()                               # scratch column = the last ALLOCATED one
+        assert np.abs(y - oracle.spmv_ell(A, p0)).max() <= 1e-13 * np.abs(off).max()
+        c.arnoldi(8)                                 # ... and what fits still runs
+        c.set_matrix_ell(adj, off, diag)              # re-lays the basis for 100 + 3 columns
+        c.set_vector(p0)
+        c.begin_step()
+        H, mb, k1, av = c.arnoldi(20)
+        V, Href, mbr, k1r, avr = oracle.arnoldi(A, p0 / np.sqrt((p0 * p0).sum()), 20)
+        assert mb == mbr and np.abs(H[:22, :21] - Href[:22, :21]).max() <= 1e-9 * np.abs(Href).max()
+
+
 @pytest.mark.parametrize("n,bw", [(2, 1), (3, 2), (65, 20), (1000, 33), (4097, 64)])
 def test_unstructured_generators_any_width(ctx, oracle, n, bw):
     """rows with up to 64 incoming links, nothing banded: SELL path, device build"""

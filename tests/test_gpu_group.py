@@ -100,3 +100,34 @@ def test_ranks_that_disagree_are_reported():
             c._chk(c._lib.kfsp_set_vector(c._h, mdl.n - 1, None), "kfsp_set_vector")
         c.set_vector(np.ones(mdl.n) / mdl.n)
         assert c.begin_step() == pytest.approx(1.0 / np.sqrt(mdl.n), rel=1e-13)
+
+
+def test_a_failing_rank_is_reported_and_does_not_hang():
+    """Rank 1 of a 3-rank loop-back group fails (injected: option group_inject_failure) at the start of set_matrix_ell while
+    ranks 0 and 2 run into the collectives of the generator build, which rank 1 never enters.  The head's watchdog (Group::run)
+    releases them after the grace period by aborting the transport, reports 'rank 1: ...' with rank 1's code, and the group
+    is broken: the next call returns 2999 at once, destruction still works, and a new group on the same device is fine."""
+    import time
+    from krylovfspssa_amd import KfspContext, KfspError
+    adj, off, diag, state = _fsp("goutsias", 16)
+    n = adj.shape[0]
+    c = KfspContext(0, group=3)
+    try:
+        c.set_option("group_grace_ms", 500)
+        c.set_matrix_ell(adj, off, diag)                 # a healthy call first
+        c.set_option("group_inject_failure", 1)
+        t0 = time.time()
+        with pytest.raises(KfspError, match=r"-77.*rank 1: injected failure"):
+            c.set_matrix_ell(adj, off, diag)
+        assert time.time() - t0 < 20.0                   # the grace period, not the 120 s guard of the loop-back barrier
+        t0 = time.time()
+        with pytest.raises(KfspError, match="2999"):
+            c.set_vector(np.ones(n) / n)
+        assert time.time() - t0 < 1.0
+    finally:
+        c.close()
+    x = np.random.default_rng(5).random(n)
+    with KfspContext(0, group=3) as g, KfspContext(0) as one:
+        g.set_matrix_ell(adj, off, diag)
+        one.set_matrix_ell(adj, off, diag)
+        assert np.array_equal(g.spmv(x), one.spmv(x))
