@@ -303,6 +303,20 @@ int kfsp_onestep(kfsp_ctx *ctx, int32_t ns, int32_t nr, const int32_t *stoich, i
 int kfsp_set_propensity_program(kfsp_ctx *ctx, int32_t ns, int32_t nr, int32_t nparams, const double *params,
                                 const int32_t *code_off, const int32_t *code, const int32_t *imm_off, const double *imm,
                                 const int32_t *tab_species, int32_t tab_len, const double *tab);
+/* Tables over TWO species, for the program just set - how a COMPILED-IN propensity function (MODEL%CUSTOMPROP,
+ * ModelModule.f90:163-199, examples/transcr6d.f90:63-90) reaches the device: there is no code to hand over, so the host
+ * tabulates the user's own function (exact by construction).  Reaction k with s1[k] >= 0 depends on species s1[k] and s2[k]
+ * (0-based) and reads tab2[off[k] + x[s2] * n1[k] + x[s1]] for populations x[s1] < n1[k], x[s2] < n2[k]; s1[k] < 0: no such
+ * table (code / product chain / one-species table of kfsp_set_propensity_program apply).  len = doubles in tab2.
+ * A population BEYOND a table cannot be served: the operation that met it - kfsp_propensities, kfsp_onestep_columns,
+ * kfsp_ssa_streams, kfsp_expand_resident - returns -16 and has changed nothing the caller can see (host outputs are to be
+ * discarded; the resident lists still describe the FSP as it was); kfsp_propensity_overflow says which species went how
+ * far; the caller sets larger tables (kfsp_set_propensity_program + this call) and repeats the operation - deterministic,
+ * so the repeat is what a larger table would have given at once. */
+int kfsp_set_propensity_tables2(kfsp_ctx *ctx, int32_t nr, const int32_t *s1, const int32_t *s2, const int32_t *n1, const int32_t *n2,
+                                const int64_t *off, int64_t len, const double *tab2);
+/* after a -16: max_missed[s] = the largest population of species s that lay beyond a table (0: none) */
+int kfsp_propensity_overflow(kfsp_ctx *ctx, int32_t ns, int32_t *max_missed);
 /* OFFDIAG(1:nr, i) = a_k(x_i) and DIAG(i) = their sum in reaction order (ADD_STATE, StateSpace.f90:207-212) for the
  * n states state[ld_state][n] (host arrays in and out) */
 int kfsp_propensities(kfsp_ctx *ctx, int32_t n, const int32_t *state, int32_t ld_state, double *offdiag, int32_t ld_off,

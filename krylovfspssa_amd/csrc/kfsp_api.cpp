@@ -1875,6 +1875,29 @@ int kfsp_set_propensity_program(kfsp_ctx *ctx, int32_t ns, int32_t nr, int32_t n
     });
 }
 
+int kfsp_set_propensity_tables2(kfsp_ctx *ctx, int32_t nr, const int32_t *s1, const int32_t *s2, const int32_t *n1, const int32_t *n2,
+                                const int64_t *off, int64_t len, const double *tab2)
+{
+    return no_throw(ctx, [&]() -> int {
+        if (!ctx) return -1;
+        if (nr < 1 || nr > 64) return fail(ctx, -2, "1 <= nr <= 64");
+        if (!s1 || !s2 || !n1 || !n2 || !off) return fail(ctx, -3, "null table description");
+        if (len < 0 || (len > 0 && !tab2)) return fail(ctx, -8, "bad tables");
+        if (ctx->group) return kfsp::group_set_propensity_tables2(ctx, nr, s1, s2, n1, n2, off, len, tab2);
+        HIP_TRY(hipSetDevice(ctx->device));
+        return kfsp::prop_set_tables2(ctx, nr, s1, s2, n1, n2, off, len, tab2);
+    });
+}
+
+int kfsp_propensity_overflow(kfsp_ctx *ctx, int32_t ns, int32_t *max_missed)
+{
+    if (!ctx) return -1;
+    if (ns < 1 || ns > 16 || !max_missed) return fail(ctx, -2, "1 <= ns <= 16, non-null max_missed");
+    const kfsp_ctx *c = ctx->group ? kfsp::group_rank0(ctx) : ctx;     // (every rank works on the whole lists: same misses)
+    for (int s = 0; s < ns; ++s) max_missed[s] = c->prop_missed[s];
+    return 0;
+}
+
 int kfsp_ssa_streams(kfsp_ctx *ctx, double timestep, int64_t seedmix, int32_t ns, int32_t nr, const int32_t *stoich, int32_t n,
                      const int32_t *state, int32_t ld_state, const int32_t *adj, const double *offdiag, int32_t ld_adj,
                      const double *diag, int32_t max_count, int32_t capacity_new, int32_t *n_found, int32_t *state_new,

@@ -259,6 +259,14 @@ struct kfsp_ctx {
     int prop_ncode = 0, prop_nimm = 0;
     size_t prop_mono_off = 0, prop_monoc_off = 0;      // where the product-chain tables sit in d_prop_i / d_prop_d
     int prop_ns = 0, prop_nr = 0, prop_np = 0, prop_np_pad = 1, prop_nimm_pad = 1, prop_tab_len = 0;
+    // tables over TWO species (kfsp_set_propensity_tables2: a compiled-in CUSTOMPROP tabulated by the host): per reaction
+    // [s1, s2, n1, n2] in d_prop_t2i (s1 < 0: none) and the offset of its n1 x n2 block in d_prop_t2d (d_prop_t2o); a
+    // population beyond a table raises d_prop_oob[0] and leaves the largest population per species in d_prop_oob[1 + s]
+    bool prop_has_tab2 = false;
+    DevBuf<int32_t> d_prop_t2i, d_prop_oob;
+    DevBuf<long long> d_prop_t2o;
+    DevBuf<double> d_prop_t2d;
+    int32_t prop_missed[16] = {0};                      // what the last overflow left in d_prop_oob[1 ..] (kfsp_propensity_overflow)
 
     // vectors
     DevBuf<double> d_V;    // (kMMax+2) columns, stride ldv, unnormalised basis
@@ -357,6 +365,8 @@ int group_layout_info(const kfsp_ctx *h, int64_t *v);
 int group_drop_rebuild(kfsp_ctx *h);
 int group_expand_resident(kfsp_ctx *h, double t_ssa, int64_t seedmix, int32_t ns, int32_t nr, const int32_t *stoich, int32_t max_count,
                           int32_t capacity, int64_t *n_new, int64_t *n_from_ssa);
+int group_set_propensity_tables2(kfsp_ctx *h, int32_t nr, const int32_t *s1, const int32_t *s2, const int32_t *n1, const int32_t *n2,
+                                 const int64_t *off, int64_t len, const double *tab2);
 int group_update_state_coords(kfsp_ctx *h, int32_t n, int32_t ns, int32_t ld, const int32_t *state, int32_t n_unchanged);
 int group_set_propensity_program(kfsp_ctx *h, int32_t ns, int32_t nr, int32_t np, const double *params, const int32_t *code_off,
                                  const int32_t *code, const int32_t *imm_off, const double *imm, const int32_t *tab_species,
@@ -398,6 +408,11 @@ int prop_set_program(kfsp_ctx *ctx, int32_t ns, int32_t nr, int32_t np, const do
                      const int32_t *code, const int32_t *imm_off, const double *imm, const int32_t *tab_species, int32_t tab_len,
                      const double *tab);
 int prop_eval_device(kfsp_ctx *ctx, int64_t n, const int32_t *d_state, int lds, double *d_off, int ldo, double *d_diag);
+int prop_set_tables2(kfsp_ctx *ctx, int32_t nr, const int32_t *s1, const int32_t *s2, const int32_t *n1, const int32_t *n2,
+                     const int64_t *off, int64_t len, const double *tab2);
+// after an operation that evaluated propensities (and a stream synchronisation): -16 if a population missed a two-species
+// table (the flag is cleared, prop_missed filled), else 0.  No-op for programs without such tables.
+int prop_check_overflow(kfsp_ctx *ctx);
 // SSA paths on independent streams (kfsp_ssa.hip); all arrays are host memory
 int ssa_streams_device(kfsp_ctx *ctx, double tstep, int64_t seedmix, int32_t ns, int32_t nr, const int32_t *stoich, int32_t n,
                        const int32_t *state, int32_t lds, const int32_t *adj, const double *offdiag, int32_t lda, const double *diag,

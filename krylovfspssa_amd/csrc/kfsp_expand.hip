@@ -344,14 +344,18 @@ int sweep_count(kfsp_ctx *ctx, XDev &A, int **cnt_out, int **off_out, int *nu_ou
     return 0;
 }
 
-// step 5 (A.state_new / A.adj_new have room for nu states)
-void sweep_append(kfsp_ctx *ctx, const XDev &A, const int *cnt, const int *off, int nu)
+// step 5 (A.state_new / A.adj_new have room for nu states), in two halves: the appended states' coordinates first - nothing
+// of the listed states changes, so their propensity columns can be made and checked before the sweep commits -, then the links
+void sweep_new_states(kfsp_ctx *ctx, const XDev &A, const int *cnt, const int *off, int nu)
+{
+    if (nu <= 0) return;
+    hipLaunchKernelGGL(k_x_new, dim3(blocks((int64_t)A.n * A.lda)), dim3(kBlock), 0, ctx->stream, A, cnt, off);
+}
+void sweep_link(kfsp_ctx *ctx, const XDev &A, int nu)
 {
     if (nu <= 0) return;
     hipStream_t st = ctx->stream;
-    const int64_t nent = (int64_t)A.n * A.lda;
-    hipLaunchKernelGGL(k_x_new, dim3(blocks(nent)), dim3(kBlock), 0, st, A, cnt, off);
-    hipLaunchKernelGGL(k_x_link, dim3(blocks(nent)), dim3(kBlock), 0, st, A);
+    hipLaunchKernelGGL(k_x_link, dim3(blocks((int64_t)A.n * A.lda)), dim3(kBlock), 0, st, A);
     hipLaunchKernelGGL(k_x_newcols, dim3(blocks((int64_t)nu * A.lda)), dim3(kBlock), 0, st, A, nu);
 }
 
@@ -384,13 +388,20 @@ int onestep_device(kfsp_ctx *ctx, int32_t ns, int32_t nr, const int32_t *stoich,
         Arena a4{ctx->d_os4.p};
         A.state_new = a4.take<int32_t>((size_t)nu * lds);
         A.adj_new = a4.take<int32_t>((size_t)nu * lda);
-        sweep_append(ctx, A, d_cnt, d_off, nu);
+        sweep_new_states(ctx, A, d_cnt, d_off, nu);
+        double *d_on = nullptr, *d_dn = nullptr;
+        if (off_new) {
+            // the propensity columns of the appended states, made where their coordinates already are (kfsp_prop.hip) - and
+            // BEFORE anything is written to the caller's arrays: a state beyond a two-species table ends the call with -16
+            d_on = a4.take<double>((size_t)nu * ldo);
+            d_dn = a4.take<double>((size_t)nu);
+            if (int rc = prop_eval_device(ctx, nu, A.state_new, lds, d_on, ldo, d_dn)) return rc;
+            if (int rc = prop_check_overflow(ctx)) return rc;
+        }
+        sweep_link(ctx, A, nu);
         X_TRY(hipMemcpyAsync(state_new, A.state_new, (size_t)nu * lds * 4, hipMemcpyDeviceToHost, st));
         X_TRY(hipMemcpyAsync(adj_out + (size_t)n * lda, A.adj_new, (size_t)nu * lda * 4, hipMemcpyDeviceToHost, st));
         if (off_new) {
-            // the propensity columns of the appended states, made where their coordinates already are (kfsp_prop.hip)
-            double *d_on = a4.take<double>((size_t)nu * ldo), *d_dn = a4.take<double>((size_t)nu);
-            if (int rc = prop_eval_device(ctx, nu, A.state_new, lds, d_on, ldo, d_dn)) return rc;
             X_TRY(hipMemcpyAsync(off_new, d_on, ob, hipMemcpyDeviceToHost, st));
             X_TRY(hipMemcpyAsync(diag_new, d_dn, (size_t)nu * 8, hipMemcpyDeviceToHost, st));
         }
@@ -457,8 +468,16 @@ int expand_resident_lists(kfsp_ctx *ctx, double tstep, int64_t seedmix, int32_t 
         A.adj = ctx->d_ell_adj.p;
         A.state_new = ctx->d_coords.p + (size_t)n1 * lds;
         A.adj_new = ctx->d_ell_adj.p + (size_t)n1 * lda;
-        sweep_append(ctx, A, d_cnt, d_off, nu);
+        sweep_new_states(ctx, A, d_cnt, d_off, nu);
         if (int rc = prop_eval_device(ctx, nu, A.state_new, lds, ctx->d_ell_off.p + (size_t)n1 * lda, lda, ctx->d_ell_diag.p + n1)) return rc;
+        if (int rc = prop_check_overflow(ctx)) {
+            // an appended state lies beyond a two-species table: the sweep is taken back (as for -11) - the first n columns are
+            // what they were, the caller enlarges the table and repeats the whole step
+            hipLaunchKernelGGL(k_x_unmark, dim3(blocks((int64_t)n * lda)), dim3(kBlock), 0, st, A, (int)n);
+            X_TRY(hipStreamSynchronize(st));
+            return rc;
+        }
+        sweep_link(ctx, A, nu);
     }
     X_TRY(hipStreamSynchronize(st));
     *n_out = (int64_t)n1 + nu;

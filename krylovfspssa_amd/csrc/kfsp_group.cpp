@@ -574,6 +574,12 @@ int group_set_propensity_program(kfsp_ctx *h, int32_t ns, int32_t nr, int32_t np
     });
 }
 
+int group_set_propensity_tables2(kfsp_ctx *h, int32_t nr, const int32_t *s1, const int32_t *s2, const int32_t *n1, const int32_t *n2,
+                                 const int64_t *off, int64_t len, const double *tab2)
+{
+    return gall(h, [&](kfsp_ctx *c, int) { return kfsp_set_propensity_tables2(c, nr, s1, s2, n1, n2, off, len, tab2); });
+}
+
 kfsp_ctx *group_rank0(const kfsp_ctx *h) { return h->group->sub[0]; }
 
 int group_layout_info(const kfsp_ctx *h, int64_t *v)

@@ -60,6 +60,7 @@ int prop_set_program(kfsp_ctx *ctx, int32_t ns, int32_t nr, int32_t np, const do
                      const double *tab)
 {
     ctx->prop_ready = false;
+    ctx->prop_has_tab2 = false;           // (two-species tables belong to one program: kfsp_set_propensity_tables2 follows this call)
     // the code is checked once, here: every operand exists, the stack never exceeds the kernel's, variables are in range
     const int ncode = code_off[nr], nimm = imm_off[nr];
     bool light = true, light_tab = true;         // (+ - * / NEG only, shallow: prop_eval_light may run it / all but tabulated reactions)
@@ -171,6 +172,62 @@ int prop_set_program(kfsp_ctx *ctx, int32_t ns, int32_t nr, int32_t np, const do
     return 0;
 }
 
+// Two-species tables of the program just set (a compiled-in CUSTOMPROP the host tabulated, include/kfsp.h)
+int prop_set_tables2(kfsp_ctx *ctx, int32_t nr, const int32_t *s1, const int32_t *s2, const int32_t *n1, const int32_t *n2,
+                     const int64_t *off, int64_t len, const double *tab2)
+{
+    if (!ctx->prop_ready || nr != ctx->prop_nr) {
+        ctx->err = "two-species tables: no propensity program with this many reactions";
+        return -2;
+    }
+    std::vector<int32_t> ti((size_t)nr * 4);
+    std::vector<long long> to((size_t)nr, 0);
+    bool any = false;
+    for (int k = 0; k < nr; ++k) {
+        ti[4 * k] = ti[4 * k + 1] = -1;
+        ti[4 * k + 2] = ti[4 * k + 3] = 0;
+        if (s1[k] < 0) continue;
+        if (s1[k] >= ctx->prop_ns || s2[k] < 0 || s2[k] >= ctx->prop_ns || s1[k] == s2[k] || n1[k] < 1 || n2[k] < 1 || off[k] < 0 ||
+            off[k] + (int64_t)n1[k] * n2[k] > len) {
+            ctx->err = "two-species tables: species / extent / offset out of range";
+            return -3;
+        }
+        ti[4 * k] = s1[k];
+        ti[4 * k + 1] = s2[k];
+        ti[4 * k + 2] = n1[k];
+        ti[4 * k + 3] = n2[k];
+        to[(size_t)k] = off[k];
+        any = true;
+    }
+    if (!any) return 0;
+    hipStream_t st = ctx->stream;
+    HIP_TRY_P(ctx->d_prop_t2i.reserve(ti.size(), false));
+    HIP_TRY_P(ctx->d_prop_t2o.reserve(to.size(), false));
+    HIP_TRY_P(ctx->d_prop_t2d.reserve((size_t)std::max<int64_t>(len, 1), false));
+    HIP_TRY_P(ctx->d_prop_oob.reserve(32, false));
+    HIP_TRY_P(hipMemcpyAsync(ctx->d_prop_t2i.p, ti.data(), ti.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY_P(hipMemcpyAsync(ctx->d_prop_t2o.p, to.data(), to.size() * sizeof(long long), hipMemcpyHostToDevice, st));
+    HIP_TRY_P(hipMemcpyAsync(ctx->d_prop_t2d.p, tab2, (size_t)len * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY_P(hipMemsetAsync(ctx->d_prop_oob.p, 0, 32 * sizeof(int32_t), st));
+    HIP_TRY_P(hipStreamSynchronize(st));
+    ctx->prop_has_tab2 = true;
+    return 0;
+}
+
+int prop_check_overflow(kfsp_ctx *ctx)
+{
+    if (!ctx->prop_has_tab2) return 0;
+    int32_t h[17];
+    hipStream_t st = ctx->stream;
+    HIP_TRY_P(hipMemcpyAsync(h, ctx->d_prop_oob.p, sizeof(h), hipMemcpyDeviceToHost, st));
+    HIP_TRY_P(hipStreamSynchronize(st));
+    if (!h[0]) return 0;
+    std::memcpy(ctx->prop_missed, h + 1, sizeof(ctx->prop_missed));
+    HIP_TRY_P(hipMemsetAsync(ctx->d_prop_oob.p, 0, 32 * sizeof(int32_t), st));
+    ctx->err = "a population lies beyond a two-species propensity table (kfsp_propensity_overflow says which; enlarge and repeat)";
+    return -16;
+}
+
 // states already on the device (n x lds int32) -> columns on the device
 int prop_eval_device(kfsp_ctx *ctx, int64_t n, const int32_t *d_state, int lds, double *d_off, int ldo, double *d_diag)
 {
@@ -195,7 +252,7 @@ int prop_eval_host(kfsp_ctx *ctx, int32_t n, const int32_t *state, int32_t lds, 
     HIP_TRY_P(hipMemcpyAsync(offdiag, d_off, no_b, hipMemcpyDeviceToHost, st));
     HIP_TRY_P(hipMemcpyAsync(diag, d_diag, nd_b, hipMemcpyDeviceToHost, st));
     HIP_TRY_P(hipStreamSynchronize(st));
-    return 0;
+    return prop_check_overflow(ctx);
 }
 
 }  // namespace kfsp

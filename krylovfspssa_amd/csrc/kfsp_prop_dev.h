@@ -21,7 +21,25 @@ struct PropDev {
     // mono[k][i] = species of operand i or -1 for a constant, whose value is mono_c[k][i - 1]
     const int32_t *mono;                // [nr][1 + kPropMonoOps]
     const double *mono_c;               // [nr][kPropMonoOps]
+    // two-species tables (null: none): reaction k reads t2d[t2o[k] + x[s2] * n1 + x[s1]] with (s1, s2, n1, n2) = t2i[4k ..]
+    const int32_t *t2i;
+    const long long *t2o;
+    const double *t2d;
+    int32_t *oob;                       // [0] raised by a population beyond a table, [1 + s] largest such population of species s
 };
+
+// a_k(x) from the two-species table of reaction k (the caller saw t2i[4k] >= 0); a miss is recorded and gives 0 - the host
+// discards whatever the operation produced, enlarges the table and repeats it (include/kfsp.h kfsp_set_propensity_tables2)
+__device__ __forceinline__ double prop_tab2(const PropDev &P, int k, const int32_t *__restrict__ x)
+{
+    const int32_t *t = P.t2i + 4 * k;
+    const int v1 = x[t[0]], v2 = x[t[1]];
+    if (v1 >= 0 && v2 >= 0 && v1 < t[2] && v2 < t[3]) return P.t2d[P.t2o[k] + (long long)v2 * t[2] + v1];
+    if (v1 >= t[2]) atomicMax(&P.oob[1 + t[0]], v1);
+    if (v2 >= t[3]) atomicMax(&P.oob[1 + t[1]], v2);
+    P.oob[0] = 1;
+    return 0.0;
+}
 
 // ((o_1 * o_2) * o_3) ... : the multiplications of the postfix code  o_1 o_2 MUL o_3 MUL ...  in its order - same bits
 __device__ __forceinline__ double prop_mono(const PropDev &P, int k, int n, const int32_t *__restrict__ x)
@@ -41,6 +59,7 @@ __device__ inline double prop_eval(const PropDev &P, int k, const int32_t *__res
         const int n = P.mono[k * (1 + kPropMonoOps)];
         if (n > 0) return prop_mono(P, k, n, x);
     }
+    if (P.t2i && P.t2i[4 * k] >= 0) return prop_tab2(P, k, x);
     const int ts = P.tab_species[k];
     if (ts >= 0) {
         const int v = x[ts];
@@ -113,6 +132,7 @@ __device__ inline double prop_eval_light(const PropDev &P, int k, const int32_t 
         const int n = P.mono[k * (1 + kPropMonoOps)];
         if (n > 0) return prop_mono(P, k, n, x);
     }
+    if (P.t2i && P.t2i[4 * k] >= 0) return prop_tab2(P, k, x);
     const int ts = P.tab_species[k];
     if (ts >= 0) {
         const int v = x[ts];
@@ -161,6 +181,10 @@ inline PropDev prop_dev(const kfsp_ctx *ctx)
     P.tab = db + ctx->prop_np_pad + ctx->prop_nimm_pad;
     P.mono = ib + ctx->prop_mono_off;
     P.mono_c = db + ctx->prop_monoc_off;
+    P.t2i = ctx->prop_has_tab2 ? ctx->d_prop_t2i.p : nullptr;
+    P.t2o = ctx->d_prop_t2o.p;
+    P.t2d = ctx->d_prop_t2d.p;
+    P.oob = ctx->d_prop_oob.p;
     return P;
 }
 

@@ -650,6 +650,7 @@ int ssa_streams_core(kfsp_ctx *ctx, double tstep, int64_t seedmix, int32_t ns, i
         unsigned long long got[2] = {0, 0};
         SSA_TRY(hipMemcpyAsync(got, d_total, sizeof(got), hipMemcpyDeviceToHost, st));
         SSA_TRY(hipStreamSynchronize(st));
+        if (int rc = prop_check_overflow(ctx)) return rc;           // (a path left a two-species table: nothing was changed)
         nrec = (long long)got[0];                                   // slots taken (empty ones included)
         nvalid = (long long)got[1];                                 // records
         if (nrec <= cap) break;
@@ -701,6 +702,7 @@ int ssa_streams_core(kfsp_ctx *ctx, double tstep, int64_t seedmix, int32_t ns, i
     int32_t *d_sn = reinterpret_cast<int32_t *>(d_dn + nnew);
     hipLaunchKernelGGL(k_rec_gather, dim3(blocks(nnew)), dim3(kBlock), 0, st, nnew, ns, lds, d_sel, d_perm, d_rec, d_sn);
     if (int rc = prop_eval_device(ctx, nnew, d_sn, lds, d_on, ldo, d_dn)) return rc;
+    if (int rc = prop_check_overflow(ctx)) return rc;
     *n_found = nnew;
     *sn = d_sn;
     *on = d_on;

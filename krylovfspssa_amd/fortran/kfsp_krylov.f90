@@ -16,6 +16,7 @@
 MODULE KRYLOVSOLVER
   USE, INTRINSIC :: ISO_C_BINDING
   USE STATESPACE
+  USE KFSP_CUSTOMPROP
   USE KFSP_C
   IMPLICIT NONE
 
@@ -60,12 +61,19 @@ MODULE KRYLOVSOLVER
   ! (kfsp_drop_rebuild / kfsp_expand_resident); this side keeps the size only and fetches the lists when the solve is over.
   LOGICAL, SAVE, PRIVATE :: RESIDENT_WANTED = .TRUE., RESIDENT = .FALSE., SSA_ON_DEVICE = .TRUE.
   LOGICAL, SAVE, PRIVATE :: DEVICE_REBUILD = .TRUE.   ! KFSP_DEVICE_REBUILD=0: the compacted generator is uploaded after every drop
+  ! A compiled-in CUSTOMPROP on the device (module KFSP_CUSTOMPROP): the plan the probe made, whether the program on the
+  ! device IS that plan (then the solve is speculative: every propensity of the final lists is checked against the function,
+  ! and the solve is repeated with host propensities if one differs), whether the tables could not follow the FSP
+  ! (CUSTOM_FAILED: same repeat), and how often they grew.  KFSP_DEVICE_CUSTOMPROP=0: never probe.
+  TYPE(CUSTOM_PLAN), SAVE, PRIVATE :: CPLAN
+  LOGICAL, SAVE, PRIVATE :: CUSTOM_WANTED = .TRUE., CUSTOM_ACTIVE = .FALSE., CUSTOM_FAILED = .FALSE.
+  INTEGER, SAVE, PRIVATE :: CUSTOM_GROWTHS = 0
   ! wall seconds spent in the host state-space code of the current solve:
   ! (1) DROP_STATES decision + compaction, (2) SSA_EXTENDER, (3) ONESTEP_EXTENDER,
   ! (4) uploads of the changed FSP
   DOUBLE PRECISION, SAVE, PRIVATE :: HOST_SEC(4) = 0.0D0
 
-  PRIVATE :: ENSURE_CONTEXT, UPLOAD_FSP, CHECK, CB_DROP, CB_EXPAND, CB_LOG, WALL, DEVICE_ONESTEP, DEVICE_SSA
+  PRIVATE :: ENSURE_CONTEXT, UPLOAD_FSP, CHECK, CB_DROP, CB_EXPAND, CB_LOG, WALL, DEVICE_ONESTEP, DEVICE_SSA, SEND_CUSTOM, GROW_CUSTOM
   PUBLIC :: KFSP_UPLOAD_PROGRAM, KFSP_DEVICE_PROPENSITIES
 
 CONTAINS
@@ -104,19 +112,26 @@ CONTAINS
     TYPE(KFSP_REPLAY) :: RP
     DOUBLE PRECISION, ALLOCATABLE :: P0(:)
     REAL(C_DOUBLE) :: TMS(7)
-    INTEGER :: I, N0, RC
+    INTEGER, ALLOCATABLE :: SEED(:, :)
+    INTEGER :: I, N0, RC, NFIN, NBAD
     INTEGER(8) :: C0, C1, CRATE
     LOGICAL :: WAS_RESIDENT
+    DOUBLE PRECISION :: T0V
 
     IFLAG = 0
     ! the device context comes first: the threads its runtime starts must not
     ! inherit the one-core affinity the host sweeps give the calling thread
     CALL ENSURE_CONTEXT()
-    CALL KFSP_UPLOAD_PROGRAM(MODEL)
     N0 = FSP%SIZE
-    ALLOCATE(P0(N0))
+    ALLOCATE(P0(N0), SEED(SIZE(FSP%STATE, 1), N0))
     P0 = V(1:N0)                       ! DCOPY(FSP%SIZE, V, 1, W, 1)  :176
+    SEED = FSP%STATE(:, 1:N0)
+    CALL KFSP_UPLOAD_PROGRAM(MODEL, SEEDS=SEED)
+    CALL SYSTEM_CLOCK(C0, CRATE)
+    RC = KFSP_GET_TIMERS(CTX, TMS, 1_C_INT)
+    HOST_SEC = 0.0D0
 
+    ATTEMPT: DO
     ! the FSP the first step runs on (:130-134)
     CALL MATRIX_STARTER(FSP, MODEL)
     DO I = 1, 5
@@ -125,12 +140,10 @@ CONTAINS
     FSP%VECTOR(1:N0) = P0
     IF (FSP%SIZE > N0) FSP%VECTOR(N0 + 1:FSP%SIZE) = 0.0D0
 
-    CALL SYSTEM_CLOCK(C0, CRATE)
-    RC = KFSP_GET_TIMERS(CTX, TMS, 1_C_INT)
-    HOST_SEC = 0.0D0
     CUR_FSP => FSP
     CUR_MODEL => MODEL
     CUR_TRACE = ITRACE
+    CUSTOM_FAILED = .FALSE.
     RESIDENT = RESIDENT_WANTED .AND. PROGRAM_READY .AND. SSA_ON_DEVICE .AND. SSA_STREAMS_REQUESTED() &
          .AND. .NOT. HOST_DROP .AND. DEVICE_REBUILD .AND. .NOT. ASSOCIATED(KFSP_STEP_OBSERVER) &
          .AND. .NOT. ASSOCIATED(KFSP_REPLAY_SCRIPT)
@@ -154,22 +167,45 @@ CONTAINS
        KFSP_REPLAY_EXTENSIONS = RP%N_SAFE_EXTENSIONS
        KFSP_REPLAY_RC = RC
        IF (RC == 20 .OR. RC == 21) RC = 0
-       CALL CHECK(RC, 'kfsp_dgexpv_replay')
+       IF (.NOT. (CUSTOM_ACTIVE .AND. CUSTOM_FAILED)) CALL CHECK(RC, 'kfsp_dgexpv_replay')
     ELSE
        RC = KFSP_DGEXPV(CTX, T, FSPTOL, KRYTOL, INT(MODEL%NREACTIONS, C_INT), OPS, LAST_SOLVE_STATS)
-       CALL CHECK(RC, 'kfsp_dgexpv')
+       IF (.NOT. (CUSTOM_ACTIVE .AND. CUSTOM_FAILED)) CALL CHECK(RC, 'kfsp_dgexpv')
     ENDIF
 
     WAS_RESIDENT = RESIDENT
-    IF (RESIDENT) THEN
+    IF (RESIDENT .AND. .NOT. CUSTOM_FAILED) THEN
        ! the lists as the device left them; keys and look-up table of this side follow
-       N0 = FSP%SIZE
+       NFIN = FSP%SIZE
        RC = KFSP_DOWNLOAD_FSP(CTX, INT(FSP%SIZE, C_INT32_T), FSP%STATE, INT(SIZE(FSP%STATE, 1), C_INT32_T), FSP%MATRIX%ADJ, &
             FSP%MATRIX%OFFDIAG, INT(SIZE(FSP%MATRIX%ADJ, 1), C_INT32_T), FSP%MATRIX%DIAG)
        CALL CHECK(RC, 'kfsp_download_fsp')
-       CALL ADOPT_LISTS(FSP, MODEL, N0)
-       RESIDENT = .FALSE.
+       CALL ADOPT_LISTS(FSP, MODEL, NFIN)
     ENDIF
+    RESIDENT = .FALSE.
+    IF (.NOT. CUSTOM_ACTIVE) EXIT ATTEMPT
+    ! The program on the device was made by PROBING a compiled-in function: the result stands only if every propensity
+    ! of the final lists is the function's own value, bit for bit.  Otherwise (or when the tables could not follow the
+    ! FSP) the solve is repeated from the seed with the propensities - and with them the lists - on the host.
+    NBAD = 0
+    IF (.NOT. CUSTOM_FAILED) THEN
+       T0V = WALL()
+       NBAD = CUSTOM_VERIFY(MODEL, FSP)
+       IF (ITRACE /= 0) PRINT '(A,I10,A,I4,A,F9.1,A,I8)', ' KFSP CUSTOMPROP ON THE DEVICE: ', FSP%SIZE * (MODEL%NREACTIONS + 1), &
+            ' PROPENSITIES VERIFIED AGAINST THE FUNCTION, TABLE GROWTHS =', CUSTOM_GROWTHS, ', MS =', 1.0D3 * (WALL() - T0V), &
+            ', MISMATCHES =', NBAD
+    ENDIF
+    IF (NBAD == 0 .AND. .NOT. CUSTOM_FAILED) EXIT ATTEMPT
+    PRINT *, 'KFSP: THE DEVICE TABLES OF CUSTOMPROP DID NOT HOLD (MISMATCHES =', NBAD, ', TABLE LIMIT =', CUSTOM_FAILED, &
+         '); REPEATING THE SOLVE WITH HOST PROPENSITIES'
+    PROGRAM_READY = .FALSE.
+    CUSTOM_ACTIVE = .FALSE.
+    NULLIFY(SSA_DEVICE)
+    FSP%SIZE = N0
+    FSP%MATRIX%SIZE = N0
+    FSP%STATE(:, 1:N0) = SEED
+    ENDDO ATTEMPT
+
     RC = KFSP_GET_VECTOR(CTX, INT(FSP%SIZE, C_INT64_T), FSP%VECTOR)
     CALL CHECK(RC, 'kfsp_get_vector')
     ! W is FSP%VECTOR itself when called through CME_SOLVE; a distinct W gets a copy
@@ -187,8 +223,9 @@ CONTAINS
             'HOST_PADE', TMS(5), 'UPLOAD', TMS(6), 'DEVICE_ONESTEP', TMS(7)
        ! which side kept the lists (RESIDENT: the device, DESIGN.md 10.6), whether the model's propensities were there, and
        ! how the SSA paths were sampled (REFERENCE: one stream, the reference's order; STREAMS: one stream per path)
-       PRINT '(A,A,A,A,A,A)', ' KFSP MODE: LISTS = ', TRIM(MERGE('RESIDENT', 'HOST    ', WAS_RESIDENT)), ' PROPENSITIES = ', &
-            TRIM(MERGE('DEVICE', 'HOST  ', PROGRAM_READY)), ' SSA = ', TRIM(MERGE('STREAMS  ', 'REFERENCE', SSA_STREAMS_REQUESTED()))
+       PRINT '(A,A,A,A,A,A,A,A)', ' KFSP MODE: LISTS = ', TRIM(MERGE('RESIDENT', 'HOST    ', WAS_RESIDENT)), ' PROPENSITIES = ', &
+            TRIM(MERGE('DEVICE', 'HOST  ', PROGRAM_READY)), ' SSA = ', TRIM(MERGE('STREAMS  ', 'REFERENCE', SSA_STREAMS_REQUESTED())), &
+            ' MODEL = ', TRIM(MERGE('CUSTOMPROP ', 'EXPRESSIONS', ASSOCIATED(MODEL%CUSTOMPROP)))
        PRINT '(A,I8,A,I8,A,I8,A,I6,A,I6)', ' KFSP STATS: NMULT =', LAST_SOLVE_STATS%NMULT, ' NEXPH =', &
             LAST_SOLVE_STATS%NEXPH, ' WSUM_EVALS =', LAST_SOLVE_STATS%N_WSUM, ' EXPANSIONS =', &
             LAST_SOLVE_STATS%N_EXPAND, ' DROP_CALLS =', LAST_SOLVE_STATS%N_DROP_CALLS
@@ -272,7 +309,9 @@ CONTAINS
     CALL GET_ENVIRONMENT_VARIABLE('KFSP_DEVICE_REBUILD', ENV, L, STAT)
     IF (STAT == 0 .AND. L > 0) DEVICE_REBUILD = ENV(1:1) /= '0'
     CALL GET_ENVIRONMENT_VARIABLE('KFSP_DEVICE_PROPENSITY', ENV, L, STAT)
-    IF (STAT == 0 .AND. L > 0) PROGRAM_WANTED = ENV(1:1) /= '0' 
+    IF (STAT == 0 .AND. L > 0) PROGRAM_WANTED = ENV(1:1) /= '0'
+    CALL GET_ENVIRONMENT_VARIABLE('KFSP_DEVICE_CUSTOMPROP', ENV, L, STAT)
+    IF (STAT == 0 .AND. L > 0) CUSTOM_WANTED = ENV(1:1) /= '0' 
     ! any other library option (kfsp_set_option, include/kfsp.h): KFSP_OPTIONS="name=value,name=value"
     CALL GET_ENVIRONMENT_VARIABLE('KFSP_OPTIONS', OPTS, L, STAT)
     IF (STAT == 0 .AND. L > 0) THEN
@@ -319,9 +358,15 @@ CONTAINS
     COLUMNS = PROGRAM_READY
     IF (COLUMNS) THEN
        ! the propensity program of the model is on the device: complete columns come back
-       DEVICE_ONESTEP = KFSP_ONESTEP_COLUMNS(CTX, INT(NS, C_INT32_T), INT(NR, C_INT32_T), STOICH, INT(N, C_INT32_T), STATE, &
-            INT(NS, C_INT32_T), ADJ, INT(NR, C_INT32_T), INT(MAXCOUNT, C_INT32_T), INT(CAP, C_INT32_T), NN, &
-            STATE(1:NS, N + 1:CAP), ADJ, OFFDIAG(1:NR, N + 1:CAP), INT(NR, C_INT32_T), DIAG(N + 1:CAP))
+       DO
+          DEVICE_ONESTEP = KFSP_ONESTEP_COLUMNS(CTX, INT(NS, C_INT32_T), INT(NR, C_INT32_T), STOICH, INT(N, C_INT32_T), STATE, &
+               INT(NS, C_INT32_T), ADJ, INT(NR, C_INT32_T), INT(MAXCOUNT, C_INT32_T), INT(CAP, C_INT32_T), NN, &
+               STATE(1:NS, N + 1:CAP), ADJ, OFFDIAG(1:NR, N + 1:CAP), INT(NR, C_INT32_T), DIAG(N + 1:CAP))
+          ! (-16: a new state lies beyond a two-species table of a probed CUSTOMPROP - nothing was written; larger tables,
+          ! again; when they cannot grow the host sweep takes over, here and from now on)
+          IF (DEVICE_ONESTEP /= -16) EXIT
+          IF (.NOT. GROW_CUSTOM()) EXIT
+       ENDDO
     ELSE
        DEVICE_ONESTEP = KFSP_ONESTEP(CTX, INT(NS, C_INT32_T), INT(NR, C_INT32_T), STOICH, INT(N, C_INT32_T), STATE, &
             INT(NS, C_INT32_T), ADJ, INT(NR, C_INT32_T), INT(MAXCOUNT, C_INT32_T), INT(CAP, C_INT32_T), NN, &
@@ -345,10 +390,14 @@ CONTAINS
     NFOUND = 0
     DEVICE_SSA = -1
     IF (.NOT. PROGRAM_READY .OR. CAPNEW < 1) RETURN
-    DEVICE_SSA = KFSP_SSA_STREAMS(CTX, TIMESTEP, INT(SEEDMIX, C_INT64_T), INT(NS, C_INT32_T), INT(NR, C_INT32_T), STOICH, &
-         INT(N, C_INT32_T), STATE, INT(NS, C_INT32_T), ADJ, OFFDIAG, INT(NR, C_INT32_T), DIAG, INT(MAXCOUNT, C_INT32_T), &
-         INT(CAPNEW, C_INT32_T), NF, STATE(1:NS, N + 1:N + CAPNEW), OFFDIAG(1:NR, N + 1:N + CAPNEW), INT(NR, C_INT32_T), &
-         DIAG(N + 1:N + CAPNEW))
+    DO
+       DEVICE_SSA = KFSP_SSA_STREAMS(CTX, TIMESTEP, INT(SEEDMIX, C_INT64_T), INT(NS, C_INT32_T), INT(NR, C_INT32_T), STOICH, &
+            INT(N, C_INT32_T), STATE, INT(NS, C_INT32_T), ADJ, OFFDIAG, INT(NR, C_INT32_T), DIAG, INT(MAXCOUNT, C_INT32_T), &
+            INT(CAPNEW, C_INT32_T), NF, STATE(1:NS, N + 1:N + CAPNEW), OFFDIAG(1:NR, N + 1:N + CAPNEW), INT(NR, C_INT32_T), &
+            DIAG(N + 1:N + CAPNEW))
+       IF (DEVICE_SSA /= -16) EXIT               ! (-16: a path left a two-species table - larger tables, the same walk again)
+       IF (.NOT. GROW_CUSTOM()) EXIT
+    ENDDO
     NFOUND = NF
   END FUNCTION DEVICE_SSA
 
@@ -356,9 +405,10 @@ CONTAINS
   ! Hill function and x (x - 1) / 2 of the shipped models) travel as tables made HERE with MODEL%PROPENSITY at every
   ! population count 0..MAXNUMBERMOLECULES, so the device returns the host's own bits for them; the others as postfix
   ! code (exact for + - * /).  Nothing happens for a compiled-in CUSTOMPROP (no code to hand over).
-  SUBROUTINE KFSP_UPLOAD_PROGRAM(MODEL, NO_TABLES)
+  SUBROUTINE KFSP_UPLOAD_PROGRAM(MODEL, NO_TABLES, SEEDS)
     TYPE(CME_MODEL), INTENT(IN) :: MODEL
     LOGICAL, INTENT(IN), OPTIONAL :: NO_TABLES         ! (tests: everything through the device's interpreter)
+    INTEGER, INTENT(IN), OPTIONAL :: SEEDS(:, :)       ! the seed states: where a compiled-in CUSTOMPROP is probed (KFSP_CUSTOMPROP)
     INTEGER, ALLOCATABLE :: CODE_OFF(:), CODE(:), IMM_OFF(:), DEP(:), X(:)
     DOUBLE PRECISION, ALLOCATABLE :: IMM(:), TAB(:, :)
     DOUBLE PRECISION :: PDUMMY(1)
@@ -366,11 +416,25 @@ CONTAINS
     INTEGER :: K, V, TL
     INTEGER(C_INT) :: RC
     PROGRAM_READY = .FALSE.
+    CUSTOM_ACTIVE = .FALSE.
+    CUSTOM_GROWTHS = 0
     NULLIFY(SSA_DEVICE)
     CALL ENSURE_CONTEXT()
     IF (.NOT. PROGRAM_WANTED) RETURN
     CALL MODEL%EXPORT_PROGRAM(OK, CODE_OFF, CODE, IMM_OFF, IMM, DEP)
-    IF (.NOT. OK) RETURN
+    IF (.NOT. OK) THEN
+       ! a compiled-in function: no code to hand over - probe it and tabulate it with the function itself (speculative:
+       ! DGEXPV_FSP verifies the final lists and falls back to host propensities)
+       IF (ASSOCIATED(MODEL%CUSTOMPROP) .AND. CUSTOM_WANTED .AND. PRESENT(SEEDS)) THEN
+          IF (MODEL%NSPECIES > 16 .OR. MODEL%NREACTIONS > 64 .OR. SIZE(SEEDS, 2) < 1) RETURN
+          CALL CUSTOM_PROBE(MODEL, SEEDS, SIZE(SEEDS, 2), CPLAN)
+          IF (.NOT. CPLAN%OK) RETURN
+          PROGRAM_READY = SEND_CUSTOM(MODEL) == 0
+          CUSTOM_ACTIVE = PROGRAM_READY
+          IF (PROGRAM_READY) SSA_DEVICE => DEVICE_SSA
+       ENDIF
+       RETURN
+    ENDIF
     IF (MODEL%NSPECIES > 16 .OR. MODEL%NREACTIONS > 64) RETURN
     TABLES = .TRUE.
     IF (PRESENT(NO_TABLES)) TABLES = .NOT. NO_TABLES
@@ -407,6 +471,45 @@ CONTAINS
     ENDIF
   END SUBROUTINE KFSP_UPLOAD_PROGRAM
 
+  ! the plan of a probed CUSTOMPROP -> kfsp_set_propensity_program + kfsp_set_propensity_tables2
+  INTEGER FUNCTION SEND_CUSTOM(MODEL) RESULT(RC)
+    TYPE(CME_MODEL), INTENT(IN) :: MODEL
+    INTEGER, ALLOCATABLE :: CODE_OFF(:), CODE(:), IMM_OFF(:), TS(:), T2S1(:), T2S2(:), T2N1(:), T2N2(:)
+    INTEGER(8), ALLOCATABLE :: T2OFF(:)
+    INTEGER(8) :: T2LEN
+    INTEGER :: TL
+    DOUBLE PRECISION, ALLOCATABLE :: IMM(:), TAB(:, :), TAB2(:)
+    DOUBLE PRECISION :: PDUMMY(1)
+    CALL CUSTOM_ARRAYS(MODEL, CPLAN, CODE_OFF, CODE, IMM_OFF, IMM, TS, TL, TAB, T2S1, T2S2, T2N1, T2N2, T2OFF, T2LEN, TAB2)
+    PDUMMY = 0.0D0
+    ! (the parameter values are inside the tables and the chains' constants: the program itself has no parameters)
+    RC = KFSP_SET_PROPENSITY_PROGRAM(CTX, INT(MODEL%NSPECIES, C_INT32_T), INT(MODEL%NREACTIONS, C_INT32_T), 0_C_INT32_T, PDUMMY, &
+         CODE_OFF, CODE, IMM_OFF, IMM, TS, INT(TL, C_INT32_T), TAB)
+    IF (RC /= 0 .OR. T2LEN == 0) RETURN
+    RC = KFSP_SET_PROPENSITY_TABLES2(CTX, INT(MODEL%NREACTIONS, C_INT32_T), T2S1, T2S2, T2N1, T2N2, T2OFF, INT(T2LEN, C_INT64_T), TAB2)
+  END FUNCTION SEND_CUSTOM
+
+  ! after a -16: the two-species tables grow past the population that missed them and go to the device again.
+  ! .FALSE.: they cannot (size limit) - the device no longer serves this model's propensities
+  LOGICAL FUNCTION GROW_CUSTOM() RESULT(GREW)
+    INTEGER(C_INT32_T) :: MISSED(16)
+    INTEGER(C_INT) :: RC
+    GREW = .FALSE.
+    IF (.NOT. CUSTOM_ACTIVE .OR. .NOT. ASSOCIATED(CUR_MODEL)) RETURN
+    MISSED = 0
+    RC = KFSP_PROPENSITY_OVERFLOW(CTX, INT(CUR_MODEL%NSPECIES, C_INT32_T), MISSED)
+    IF (RC == 0) THEN
+       IF (CUSTOM_GROW(CPLAN, INT(MISSED(1:CUR_MODEL%NSPECIES)))) GREW = SEND_CUSTOM(CUR_MODEL) == 0
+    ENDIF
+    IF (GREW) THEN
+       CUSTOM_GROWTHS = CUSTOM_GROWTHS + 1
+    ELSE
+       CUSTOM_FAILED = .TRUE.
+       PROGRAM_READY = .FALSE.
+       NULLIFY(SSA_DEVICE)
+    ENDIF
+  END FUNCTION GROW_CUSTOM
+
   ! OFFDIAG / DIAG columns of N states through the resident program (kfsp_propensities); .FALSE. without one
   LOGICAL FUNCTION KFSP_DEVICE_PROPENSITIES(N, STATE, OFFDIAG, DIAG) RESULT(DONE)
     INTEGER, INTENT(IN) :: N
@@ -415,8 +518,12 @@ CONTAINS
     INTEGER(C_INT) :: RC
     DONE = .FALSE.
     IF (.NOT. PROGRAM_READY) RETURN
-    RC = KFSP_PROPENSITIES(CTX, INT(N, C_INT32_T), STATE, INT(SIZE(STATE, 1), C_INT32_T), OFFDIAG, &
-         INT(SIZE(OFFDIAG, 1), C_INT32_T), DIAG)
+    DO
+       RC = KFSP_PROPENSITIES(CTX, INT(N, C_INT32_T), STATE, INT(SIZE(STATE, 1), C_INT32_T), OFFDIAG, &
+            INT(SIZE(OFFDIAG, 1), C_INT32_T), DIAG)
+       IF (RC /= -16) EXIT
+       IF (.NOT. GROW_CUSTOM()) RETURN
+    ENDDO
     CALL CHECK(RC, 'kfsp_propensities')
     DONE = .TRUE.
   END FUNCTION KFSP_DEVICE_PROPENSITIES
@@ -547,9 +654,18 @@ CONTAINS
        ! the paths' streams is drawn here, as SSA_EXTENDER_STREAMS draws it
        T0 = WALL()
        CALL RANDOM_NUMBER(BASE)
-       RC = KFSP_EXPAND_RESIDENT(CTX, T_SSA, INT(BASE * 2147483647.0D0, C_INT64_T), INT(CUR_MODEL%NSPECIES, C_INT32_T), &
-            INT(CUR_MODEL%NREACTIONS, C_INT32_T), CUR_MODEL%STOICHIOMETRY(1:CUR_MODEL%NSPECIES, 1:CUR_MODEL%NREACTIONS), &
-            INT(MAXNUMBERMOLECULES, C_INT32_T), INT(CUR_FSP%MAX_SIZE - 1, C_INT32_T), NN, NSSA)
+       DO
+          RC = KFSP_EXPAND_RESIDENT(CTX, T_SSA, INT(BASE * 2147483647.0D0, C_INT64_T), INT(CUR_MODEL%NSPECIES, C_INT32_T), &
+               INT(CUR_MODEL%NREACTIONS, C_INT32_T), CUR_MODEL%STOICHIOMETRY(1:CUR_MODEL%NSPECIES, 1:CUR_MODEL%NREACTIONS), &
+               INT(MAXNUMBERMOLECULES, C_INT32_T), INT(CUR_FSP%MAX_SIZE - 1, C_INT32_T), NN, NSSA)
+          ! (-16: a path or an appended state left a two-species table of a probed CUSTOMPROP; the lists are untouched -
+          ! larger tables, the same step again)
+          IF (RC /= -16) EXIT
+          IF (.NOT. GROW_CUSTOM()) THEN
+             RC = 4016                          ! (ends kfsp_dgexpv; DGEXPV_FSP repeats the solve with host propensities)
+             RETURN
+          ENDIF
+       ENDDO
        IF (RC == -11) STOP 'OVERFLOW ERROR: FSP SIZE EXCEEDS MEMORY LIMIT.'
        CALL CHECK(RC, 'kfsp_expand_resident')
        CUR_FSP%SIZE = INT(NN)

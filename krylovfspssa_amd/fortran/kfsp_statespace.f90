@@ -65,7 +65,7 @@ MODULE STATESPACE
      PROCEDURE :: INDEX => INDEX_STATE
   END TYPE FINITE_STATE_PROJECTION
 
-  PRIVATE :: ONESTEP_ON_DEVICE, SSA_STREAMS_ON_DEVICE, KFSP_PLOG, SSA_EXTENDER_STREAMS, STREAM_PATH, TICK, STATE_HASH, LOOKUP, PROBE, INSERT_RANGE, APPEND_CANDIDATES, CUSTOMPROP_IS_PURE, TABLE_INSERT, REBUILD_TABLE, LEGAL, RESERVE_TABLE, APPEND_STATE, &
+  PRIVATE :: ONESTEP_ON_DEVICE, SSA_STREAMS_ON_DEVICE, KFSP_PLOG, SSA_EXTENDER_STREAMS, STREAM_PATH, TICK, STATE_HASH, LOOKUP, PROBE, INSERT_RANGE, APPEND_CANDIDATES, TABLE_INSERT, REBUILD_TABLE, LEGAL, RESERVE_TABLE, APPEND_STATE, &
        LINK_ONE, LINK_NEW, HOST_THREADS
 
   INTEGER(8), PARAMETER, PRIVATE :: LOW32 = 4294967295_8

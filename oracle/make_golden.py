@@ -103,6 +103,14 @@ SOLVE_CASES = {
     "goutsias_input_T4": ("goutsias_input", 4.0, 1e-6, 1e-8),
     "goutsias_input_T15": ("goutsias_input", 15.0, 1e-6, 1e-8),
     "goutsias_input_T40": ("goutsias_input", 40.0, 1e-6, 1e-8),
+    # compiled-in propensity functions (MODEL%CUSTOMPROP, oracle/ref_cases.f90): the reference's repressilator example over
+    # a short horizon, and three variants of OURS whose production law depends on two species (not a product), on three, and
+    # on a plane no probe visits - how the Fortran host's probing of such functions (KFSP_CUSTOMPROP) is tested
+    "repressilator_example_T1": ("repressilator_example", 1.0, 1e-4, 1e-14),
+    "goutsias_example_T15": ("goutsias_example", 15.0, 1e-6, 1e-8),
+    "repressilator_pair_T2": ("repressilator_pair", 2.0, 1e-4, 1e-10),
+    "repressilator_triple_T1": ("repressilator_triple", 1.0, 1e-4, 1e-10),
+    "repressilator_trap_T2": ("repressilator_trap", 2.0, 1e-4, 1e-10),
 }
 
 ASSEMBLY_CASES = [("toggle", 5), ("toggle", 10), ("toggle", 20),

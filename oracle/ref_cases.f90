@@ -52,6 +52,34 @@ CONTAINS
     ENDIF
   END FUNCTION REPRESSILATOR_EXAMPLE_PROP
 
+  DOUBLE PRECISION FUNCTION REPRESSILATOR_VARIANT_PROP(STATE, REACTION, PARAMETERS)
+    ! Repressilator-shaped networks of OUR OWN that exercise how a compiled-in function is probed (KFSP_CUSTOMPROP of the
+    ! Fortran host; for the reference these are just three more CUSTOMPROP models).  PARAMETERS(4) selects the production law:
+    !   1  "pair":   repressed by one species, damped by the other - depends on TWO species, not a product
+    !   2  "triple": depends on all three species, not a product   (no device plan: the host keeps the propensities)
+    !   3  "trap":   as examples/repressilator.f90 except on the plane X3 = 30, which no probe visits - a plan the probe
+    !                accepts and the final verification must reject
+    INTEGER, INTENT(IN) :: STATE(:), REACTION
+    DOUBLE PRECISION, INTENT(IN), OPTIONAL :: PARAMETERS(:)
+    INTEGER :: S, R, Q
+    S = (REACTION + 1) / 2
+    R = MOD(S, 3) + 1
+    Q = MOD(R, 3) + 1
+    IF (MOD(REACTION, 2) == 0) THEN
+       REPRESSILATOR_VARIANT_PROP = PARAMETERS(3) * STATE(S)
+       RETURN
+    ENDIF
+    SELECT CASE (NINT(PARAMETERS(4)))
+    CASE (1)
+       REPRESSILATOR_VARIANT_PROP = PARAMETERS(1) / (1D0 + PARAMETERS(2) * STATE(R)**2.0D0 + 0.5D0 * STATE(Q))
+    CASE (2)
+       REPRESSILATOR_VARIANT_PROP = PARAMETERS(1) / (1D0 + PARAMETERS(2) * STATE(R)**2.0D0 + 0.5D0 * STATE(Q) + 0.01D0 * STATE(S))
+    CASE DEFAULT
+       REPRESSILATOR_VARIANT_PROP = PARAMETERS(1) / (1D0 + PARAMETERS(2) * STATE(R)**6.0D0)
+       IF (STATE(3) == 30 .AND. S == 1) REPRESSILATOR_VARIANT_PROP = REPRESSILATOR_VARIANT_PROP + 1.0D-3
+    END SELECT
+  END FUNCTION REPRESSILATOR_VARIANT_PROP
+
   DOUBLE PRECISION FUNCTION GOUTSIAS_EXAMPLE_PROP(STATE, REACTION, PARAMETERS)
     ! the propensities of examples/transcr6d.f90:63-90, restated; species M, D, RNA, DNA, DNA.D, DNA.2D = 1..6
     INTEGER, INTENT(IN) :: STATE(:), REACTION
@@ -216,6 +244,17 @@ CONTAINS
        CALL MODEL%RESET_PARAMETERS([100.0D0, 25.0D0, 1.0D0])
        MODEL%LOADED = .TRUE.
        T = 10.0D0; FSPTOL = 1.0D-4; KRYTOL = 1.0D-14
+       X0 = [22, 0, 0]
+       CALL SEED_POINT(MODEL, FSP_IN, FSP, X0)
+    CASE ('repressilator_pair', 'repressilator_triple', 'repressilator_trap')
+       CALL MODEL%CREATE(3, 6, 4)
+       MODEL%STOICHIOMETRY = RESHAPE((/1, 0, 0, -1, 0, 0, 0, 1, 0, 0, -1, 0, 0, 0, 1, 0, 0, -1/), (/3, 6/))
+       MODEL%CUSTOMPROP => REPRESSILATOR_VARIANT_PROP
+       CALL MODEL%RESET_PARAMETERS([100.0D0, 25.0D0, 1.0D0, 1.0D0])
+       IF (CASENAME == 'repressilator_triple') MODEL%PARAMETER_VAL(4) = 2.0D0
+       IF (CASENAME == 'repressilator_trap') MODEL%PARAMETER_VAL(4) = 3.0D0
+       MODEL%LOADED = .TRUE.
+       T = 2.0D0; FSPTOL = 1.0D-4; KRYTOL = 1.0D-10
        X0 = [22, 0, 0]
        CALL SEED_POINT(MODEL, FSP_IN, FSP, X0)
     CASE ('goutsias_example')

@@ -525,3 +525,142 @@ def test_default_mode_agrees_with_the_reference_at_full_horizon(dump, tmp_path, 
     text = _run(dump, ["solve", case, p, repr(T)], tmp_path, env={"KFSP_CASE_CAPACITY": "2097169"})
     assert "LISTS = HOST" in text and "SSA = REFERENCE" in text
     _against_digest(MG.read_fsp(p), MG.parse_log(text), g)
+
+
+# ---- compiled-in propensity functions (MODEL%CUSTOMPROP) on the device: probed, tabulated with the function itself, verified
+
+def _solve_text(dump, tmp_path, fixture, case, env=None):
+    g = np.load(os.path.join(GOLDEN, f"solve_{fixture}.npz"))
+    p = str(tmp_path / "s.bin")
+    text = _run(dump, ["solve", case, p, repr(float(g["T"]))], tmp_path, env=env)
+    return g, MG.read_fsp(p), MG.parse_log(text), text
+
+
+def _same_run(a, b):
+    (da, la), (db, lb) = a, b
+    assert np.array_equal(la["step_n"], lb["step_n"]) and np.array_equal(la["step_tau"], lb["step_tau"])
+    assert np.array_equal(la["step_m"], lb["step_m"]) and np.array_equal(la["wsum"], lb["wsum"])
+    for key in ("state", "adj", "offdiag", "diag", "vector"):
+        assert np.array_equal(da[key], db[key]), key
+
+
+# (fixture, case, where the propensities end up, two-species tables expected)
+CUSTOM = [("toggle_example_T05", "toggle_example", "DEVICE", False),              # examples/toggle.f90: one species each
+          ("repressilator_example_T1", "repressilator_example", "DEVICE", False),  # examples/repressilator.f90: one species each
+          ("goutsias_example_T15", "goutsias_example", "DEVICE", False),           # examples/transcr6d.f90: c X Y chains, x (x - 1) / 2
+          ("repressilator_pair_T2", "repressilator_pair", "DEVICE", True),         # two species, not a product: 2-D tables
+          ("repressilator_triple_T1", "repressilator_triple", "HOST", False)]      # three species: no plan, host
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fixture,case,where,tab2", CUSTOM)
+def test_customprop_models_reach_the_device(dump, tmp_path, fixture, case, where, tab2):
+    """The reference's own drivers attach COMPILED-IN propensity functions (MODEL%CUSTOMPROP: examples/toggle.f90:23-27,
+    repressilator.f90:23-27, transcr6d.f90:36-40; ModelModule.f90:163-199).  The Fortran host probes such a function
+    (module KFSP_CUSTOMPROP: which species each reaction depends on; one species -> a table made with the function itself;
+    c X Y -> the same multiplications; two species -> a 2-D table that grows with the FSP; else the host keeps it) and
+    verifies every propensity of the final lists against the function.  Default mode (the reference's sampling order),
+    every one-step sweep on the device with complete columns: the run reproduces the reference's fixture exactly - step
+    log, state list, links, and OFFDIAG / DIAG bit for bit - and is byte-identical to the run that never probes
+    (KFSP_DEVICE_CUSTOMPROP=0)."""
+    base = {"KFSP_DEVICE_ONESTEP_MIN": "1", "KFSP_CUSTOM_TABLE2_START": "8"}
+    g, d, log, text = _solve_text(dump, tmp_path, fixture, case, env=base)
+    assert f"PROPENSITIES = {where}" in text and "MODEL = CUSTOMPROP" in text and "LISTS = HOST" in text
+    assert ("REPEATING THE SOLVE" not in text)
+    if where == "DEVICE":
+        assert "MISMATCHES =       0" in text
+        grew = int(text.split("TABLE GROWTHS =")[1].split(",")[0])
+        assert (grew >= 1) == tab2, text[-600:]
+    g, dh, logh, texth = _solve_text(dump, tmp_path, fixture, case, env=dict(base, KFSP_DEVICE_CUSTOMPROP="0"))
+    assert "PROPENSITIES = HOST" in texth
+    _same_run((d, log), (dh, logh))
+    assert np.array_equal(log["step_n"], g["step_n"]) and np.array_equal(log["step_tau"], g["step_tau"])
+    assert np.array_equal(log["step_m"], g["step_m"]) and int(log["n_ssa"]) == int(g["n_ssa"])
+    assert np.array_equal(d["state"], g["state"]) and np.array_equal(d["adj"], g["adj"])
+    assert np.array_equal(d["offdiag"], g["offdiag"]) and np.array_equal(d["diag"], g["diag"])
+    assert np.abs(log["wsum"] - g["wsum"]).max() < 1e-10 and np.abs(d["vector"] - g["vector"]).sum() < 1e-10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks", [1, 2])
+@pytest.mark.parametrize("fixture,case,where,tab2", CUSTOM[:4])
+def test_customprop_models_in_the_resident_mode(dump, tmp_path, fixture, case, where, tab2, ranks):
+    """KFSP_SSA_STREAMS=1 with a compiled-in function: the RESIDENT loop (walk through unlisted states, one-step sweep,
+    columns of the appended states - all on the device's tables of the probed function; a population beyond a 2-D table
+    makes the step return -16 untouched, the tables grow, the step is repeated) against the same mode with the walk and the
+    propensities on the host (KFSP_DEVICE_CUSTOMPROP=0: the thread team calls the function): identical step logs, state
+    lists, links, columns and probabilities, bit for bit; with one context and over 2 loop-back ranks (there: lists and
+    columns bit for bit, probabilities to 1e-10)."""
+    base = {"KFSP_SSA_STREAMS": "1", "KFSP_HOST_THREADS": "4", "KFSP_HOST_PARALLEL_MIN": "1", "KFSP_HOST_PARALLEL_PROPENSITY": "1",
+            "KFSP_CUSTOM_TABLE2_START": "8"}
+    g, dh, logh, texth = _solve_text(dump, tmp_path, fixture, case, env=dict(base, KFSP_DEVICE_CUSTOMPROP="0"))
+    assert "PROPENSITIES = HOST" in texth and "LISTS = HOST" in texth and "SSA = STREAMS" in texth
+    env = dict(base, KFSP_NRANKS=str(ranks)) if ranks > 1 else base
+    g, d, log, text = _solve_text(dump, tmp_path, fixture, case, env=env)
+    assert "LISTS = RESIDENT" in text and "PROPENSITIES = DEVICE" in text and "MISMATCHES =       0" in text
+    assert "REPEATING THE SOLVE" not in text
+    grew = int(text.split("TABLE GROWTHS =")[1].split(",")[0])
+    assert (grew >= 1) == tab2
+    assert int(log["n_ssa"]) >= 1
+    if ranks == 1:
+        _same_run((d, log), (dh, logh))
+    else:
+        assert np.array_equal(log["step_n"], logh["step_n"]) and np.array_equal(log["step_tau"], logh["step_tau"])
+        for key in ("state", "adj", "offdiag", "diag"):
+            assert np.array_equal(d[key], dh[key]), key
+        assert np.abs(d["vector"] - dh["vector"]).sum() < 1e-10
+    ref = {tuple(s): v for s, v in zip(g["state"].tolist(), g["vector"].tolist())}
+    got = {tuple(s): v for s, v in zip(d["state"].tolist(), d["vector"].tolist())}
+    assert sum(abs(ref.get(k, 0.0) - got.get(k, 0.0)) for k in set(ref) | set(got)) < 2.0 * float(g["fsptol"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["default", "resident"])
+def test_a_customprop_plan_that_does_not_hold_is_caught(dump, tmp_path, mode):
+    """repressilator_trap (oracle/ref_cases.f90): the examples' repressilator except on the plane X3 = 30, where reaction 1
+    gets 1e-3 more - a dependence on a second species no probe sees, so the probe accepts one-species tables.  The final
+    verification (every OFFDIAG / DIAG of the final lists against the function) must find the wrong entries and the solve
+    must be repeated with host propensities; the result is then the reference's within the FSP tolerance."""
+    env = {"KFSP_DEVICE_ONESTEP_MIN": "1"} if mode == "default" else {"KFSP_SSA_STREAMS": "1"}
+    g, d, log, text = _solve_text(dump, tmp_path, "repressilator_trap_T2", "repressilator_trap", env=env)
+    assert "REPEATING THE SOLVE WITH HOST PROPENSITIES" in text
+    bad = int(text.split("MISMATCHES =")[1].split()[0])
+    assert bad > 0
+    assert "PROPENSITIES = HOST" in text.split("REPEATING THE SOLVE")[1]
+    assert np.any(d["state"][:, 2] == 30)
+    ref = {tuple(s): v for s, v in zip(g["state"].tolist(), g["vector"].tolist())}
+    got = {tuple(s): v for s, v in zip(d["state"].tolist(), d["vector"].tolist())}
+    l1 = sum(abs(ref.get(k, 0.0) - got.get(k, 0.0)) for k in set(ref) | set(got))
+    assert l1 < 2.0 * float(g["fsptol"]) and 1.0 - d["vector"].sum() < float(g["fsptol"])
+    # and the columns that came back are the function's (the reference's, where the lists overlap)
+    idx = {tuple(s): i for i, s in enumerate(g["state"].tolist())}
+    both = [(i, idx[tuple(s)]) for i, s in enumerate(d["state"].tolist()) if tuple(s) in idx]
+    a, b = np.array(both).T
+    assert len(both) > 1000 and np.array_equal(d["offdiag"][a], g["offdiag"][b])
+
+
+# the reference's three example drivers at their own horizons (examples/toggle.f90:14, repressilator.f90:14, transcr6d.f90:16)
+EXAMPLES = [("toggle_example_T100", "toggle_example", 100.0), ("repressilator_example_T10", "repressilator_example", 10.0),
+            ("goutsias_example_T300", "goutsias_example", 300.0)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["default", "resident"])
+@pytest.mark.parametrize("digest,case,T", EXAMPLES)
+def test_example_drivers_workloads_agree_with_the_reference_at_full_horizon(dump, tmp_path, digest, case, T, mode):
+    """The workloads of the reference's example PROGRAMs - compiled-in propensities, their seeds, horizons and tolerances
+    (oracle/ref_cases.f90 restates the set-up) - against digests of the unmodified reference's results: in the default mode
+    (reference sampling order; the probed tables serve the device's one-step sweeps) and in the resident mode
+    (KFSP_SSA_STREAMS=1), where examples/transcr6d's workload takes seconds instead of the reference's 36 minutes."""
+    path = os.path.join(GOLDEN, f"digest_{digest}.npz")
+    if mode == "default" and case == "goutsias_example":
+        pytest.skip("30 s of sequential host walk: covered by test_goutsias_full_horizon_agrees_with_the_reference")
+    g = np.load(path)
+    p = str(tmp_path / "g.bin")
+    env = {"KFSP_CASE_CAPACITY": "2097169"}
+    if mode == "resident":
+        env["KFSP_SSA_STREAMS"] = "1"
+    text = _run(dump, ["solve", case, p, repr(T)], tmp_path, env=env)
+    assert "MODEL = CUSTOMPROP" in text and "PROPENSITIES = DEVICE" in text and "MISMATCHES =       0" in text
+    assert ("LISTS = RESIDENT" in text) == (mode == "resident")
+    _against_digest(MG.read_fsp(p), MG.parse_log(text), g)
