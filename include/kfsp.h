@@ -83,7 +83,8 @@ int kfsp_partition(int64_t n, int nranks, int rank, int64_t *row0, int64_t *nrow
  * entered; the call returns the failing rank's code with "rank p: ..." as the error text (2999 when no rank failed and only
  * the deadline expired), and the group is BROKEN: every later call returns 2999 at once - destroy it and create a new one.
  * 2998: ranks did not come back even after the abort ("group_settle_ms", default 30 s); their threads are abandoned, the
- * caller still gets control back.  The process is never ended.  (KFSP_NRANKS with distinct KFSP_DEVICES - RCCL between real
+ * caller still gets control back.  The process is never ended.  ("group_inject_failure" = p is a test hook: rank p fails the
+ * next fan-out with -77 before doing anything.)  (KFSP_NRANKS with distinct KFSP_DEVICES - RCCL between real
  * devices - has not run on hardware yet: no multi-GPU box was available to the builder; tests/test_gpu_two_ranks.py is the
  * first thing to run on one.) */
 int kfsp_create_group(int nranks, const int *devices, kfsp_ctx **out);
@@ -541,7 +542,9 @@ int kfsp_add_timer(kfsp_ctx *ctx, int phase, double ms);
  * vector; 1, default: a SELL generator whose reach max |col - row| is at most one block - bounded under the internal state order -
  * exchanges halo strips like a banded one), "overlap", "small_kernel", "small_lds", "dia_mask", "box_lds" (1: the single-factor matrix-free product stages the part of x within "box_reach" rows - default
  * 512 - of a workgroup's rows in LDS and serves the near entries from there, kernel format 6; 0, default: every entry gathers from
- * global memory, format 4, which measured faster on every box; bit-identical products), "ssa_general" (1: kfsp_ssa_streams / kfsp_expand_resident walk with the general kernel even for models of <= 8 species and
+ * global memory, format 4, which measured faster on every box; bit-identical products), "ssa_partition" (1, default: kfsp_expand_resident under a communicator has every rank walk
+ * only ITS share of the SSA seeds and all-gathers the paths' records - the same states in the same order as the unpartitioned walk;
+ * 0: every rank walks all seeds), "ssa_general" (1: kfsp_ssa_streams / kfsp_expand_resident walk with the general kernel even for models of <= 8 species and
  * <= 16 reactions, which otherwise take the register-resident one; same paths; default 0), "keep_coords" (1: the coordinates of kfsp_set_state_coords / kfsp_update_state_coords stay on the device
  * even when no state order is derived from them - kfsp_expand_resident needs them; default 0), "ssa_resident" (1: the caller vouches that the FSP arrays handed to kfsp_ssa_streams are the ones of its last
  * kfsp_update_matrix_ell / kfsp_set_state_coords: they are taken from the device's copies instead of being uploaded again; default 0),

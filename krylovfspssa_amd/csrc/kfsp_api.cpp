@@ -226,6 +226,10 @@ int comm_allgather_bytes(kfsp_ctx *ctx, const void *send, void *recv, size_t byt
 }  // namespace
 
 namespace kfsp {
+// the collectives for the translation units of the expansion step (the walk's records of a partitioned expansion)
+int comm_gather_doubles(kfsp_ctx *ctx, const double *send, double *recv, size_t count, hipStream_t st) { return comm_allgather(ctx, send, recv, count, st); }
+int comm_gather_bytes(kfsp_ctx *ctx, const void *send, void *recv, size_t bytes, hipStream_t st) { return comm_allgather_bytes(ctx, send, recv, bytes, st); }
+
 // Called from ANOTHER thread than the one that drives ctx (the watchdog of a group context, kfsp_group.cpp) when a peer
 // failed or a deadline expired: the rank may sit in hipStreamSynchronize behind a collective its peers never entered.
 // ncclCommAbort makes the collective's kernel give up; the loop-back transport releases its barriers.  The rank's
@@ -850,7 +854,8 @@ int kfsp_destroy(kfsp_ctx *ctx)
     ctx->d_ell_adj.release(); ctx->d_ell_off.release(); ctx->d_ell_diag.release(); ctx->d_cnt.release();
     ctx->d_ticket.release(); ctx->d_slot.release(); ctx->d_scan.release(); ctx->d_strip.release();
     ctx->d_dropflag.release(); ctx->d_dropcnt.release(); ctx->d_box.release(); ctx->d_os1.release(); ctx->d_os2.release();
-    ctx->d_os3.release(); ctx->d_prop_i.release(); ctx->d_prop_d.release();
+    ctx->d_os3.release(); ctx->d_os4.release(); ctx->d_os5.release(); ctx->d_prop_i.release(); ctx->d_prop_d.release();
+    ctx->d_prop_t2i.release(); ctx->d_prop_t2o.release(); ctx->d_prop_t2d.release(); ctx->d_prop_oob.release();
     ctx->d_perm.release(); ctx->d_iperm.release(); ctx->d_coords.release(); ctx->d_coords2.release(); ctx->d_ell_adj2.release();
     ctx->d_ell_off2.release(); ctx->d_ell_diag2.release(); ctx->d_pstage.release(); ctx->d_keys.release();
     ctx->d_sortidx.release(); ctx->d_sorttmp.release(); ctx->d_gmask.release(); ctx->d_zero.release();
@@ -2400,6 +2405,7 @@ int kfsp_set_option(kfsp_ctx *ctx, const char *name, int64_t value)
     else if (k == "ssa_resident") ctx->opt_ssa_resident = value;
     else if (k == "keep_coords") ctx->opt_keep_coords = value;
     else if (k == "ssa_general") ctx->opt_ssa_general = value;
+    else if (k == "ssa_partition") ctx->opt_ssa_partition = value;
     else if (k == "small_lds") ctx->opt_small_lds = value;
     else if (k == "state_order") ctx->opt_state_order = value;
     else if (k == "state_order_min") ctx->opt_state_order_min = value;

@@ -248,7 +248,7 @@ struct kfsp_ctx {
     int64_t w_pending_n = 0;
 
     // ONESTEP_EXTENDER on the device (kfsp_onestep.hip): two scratch arenas (+ one for the columns of the new states)
-    DevBuf<char> d_os1, d_os2, d_os3, d_os4;
+    DevBuf<char> d_os1, d_os2, d_os3, d_os4, d_os5;
     // the model's propensity program (kfsp_prop.hip): [code_off | imm_off | tab_species | code] and [params | imm | tables]
     DevBuf<int32_t> d_prop_i;
     DevBuf<double> d_prop_d;
@@ -312,6 +312,7 @@ struct kfsp_ctx {
                                           // measured slower than format 4 on every box: DESIGN.md 4.1b - off by default)
     int64_t opt_box_reach = 512;          // largest shift (rows) served from that window
     int64_t opt_box_generic = 0;          // 1: matrix-free boxes always take the run-time interpreted kernel
+    int64_t opt_ssa_partition = 1;         // the resident expansion under a communicator: each rank walks its share of the seeds (0: all of them)
     int64_t opt_mmax = kfsp::kMMax;        // largest Krylov dimension the NEXT basis is allocated for (m_max + 3 columns)
     int64_t v_mmax = 0;                    // ... and the one the basis in d_V WAS allocated for (resize); 0: no basis yet
     int64_t opt_ssa_resident = 0;          // 1: the caller vouches that the arrays given to kfsp_ssa_streams are the ones last uploaded
@@ -419,10 +420,15 @@ int ssa_streams_device(kfsp_ctx *ctx, double tstep, int64_t seedmix, int32_t ns,
                        int32_t max_count, int32_t cap_new, int32_t *n_found, int32_t *state_new, double *off_new, int32_t ldo,
                        double *diag_new);
 int prop_eval_host(kfsp_ctx *ctx, int32_t n, const int32_t *state, int32_t lds, double *offdiag, int32_t ldo, double *diag);
-// the same walk on lists that are on the device; the states met and their columns stay there (d_pstage)
+// the same walk on lists that are on the device; the states met and their columns stay there (d_pstage).  partitioned: called
+// by EVERY rank of a communicator on identical lists - each rank walks the paths of its share of the seeds only and the
+// records are all-gathered (same result on every rank as the unpartitioned walk, bit for bit)
 int ssa_streams_core(kfsp_ctx *ctx, double tstep, int64_t seedmix, int32_t ns, int32_t nr, const int32_t *stoich, int32_t n,
                      const int32_t *d_state, int32_t lds, const int32_t *d_adj, const double *d_off, int32_t lda, const double *d_diag,
-                     int32_t max_count, int32_t cap_new, int32_t ldo, int32_t *n_found, int32_t **sn, double **on, double **dn);
+                     int32_t max_count, int32_t cap_new, int32_t ldo, int32_t *n_found, int32_t **sn, double **on, double **dn,
+                     bool partitioned = false);
+int comm_gather_doubles(kfsp_ctx *ctx, const double *send, double *recv, size_t count, hipStream_t st);
+int comm_gather_bytes(kfsp_ctx *ctx, const void *send, void *recv, size_t bytes, hipStream_t st);
 // SSA walk + one-step sweep on the resident lists (kfsp_expand.hip)
 int expand_resident_lists(kfsp_ctx *ctx, double tstep, int64_t seedmix, int32_t ns, int32_t nr, const int32_t *stoich,
                           int32_t max_count, int32_t cap, int64_t *n_out, int64_t *n_ssa);

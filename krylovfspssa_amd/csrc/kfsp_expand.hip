@@ -429,7 +429,7 @@ int expand_resident_lists(kfsp_ctx *ctx, double tstep, int64_t seedmix, int32_t 
         int32_t nnew = 0, *d_sn = nullptr;
         double *d_on = nullptr, *d_dn = nullptr;
         if (int rc = ssa_streams_core(ctx, tstep, seedmix, ns, nr, stoich, n, ctx->d_coords.p, lds, ctx->d_ell_adj.p, ctx->d_ell_off.p,
-                                      lda, ctx->d_ell_diag.p, max_count, cap - n, lda, &nnew, &d_sn, &d_on, &d_dn))
+                                      lda, ctx->d_ell_diag.p, max_count, cap - n, lda, &nnew, &d_sn, &d_on, &d_dn, true))
             return rc;
         if (nnew > 0) {
             n1 = n + nnew;

@@ -45,6 +45,9 @@ struct SsaDev {
     const int32_t *nu;         // [nr][ns]
     const int32_t *tab;        // hash table of the listed states: index + 1, 0 = empty
     unsigned tmask;
+    // the wavefronts of this launch are wavefronts [wave0, wave1) of the walk (a partitioned expansion: this rank's share;
+    // else all of them, [0, nwaves))
+    long long wave0, wave1;
     PropDev P;
 };
 
@@ -131,14 +134,14 @@ __global__ __launch_bounds__(kBlock) void k_ssa_walk_any(SsaDev A, unsigned long
                                                      unsigned long long *__restrict__ keys, int32_t *__restrict__ rec)
 {
     const int lane = threadIdx.x & 63;
-    const long long wave = ((long long)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const long long wave = A.wave0 + (((long long)blockIdx.x * kBlock + threadIdx.x) >> 6);
     // kSsaSeedsPerWave seeds per wavefront, dealt in blocks of 64 consecutive seed states ROUND ROBIN over the wavefronts:
     // the long paths start from neighbouring states (measured: the LAST states of the list, the FSP's rim - they step
     // outside and walk through unlisted states to the horizon, hundreds of jumps, while a path from an inner state falls
     // back onto an earlier seed after a handful), and a wavefront that owned 256 consecutive ones of them walked four
     // long paths per lane, one after the other
     const long long nwaves = ((long long)A.n0 + kSsaSeedsPerWave - 1) / kSsaSeedsPerWave;
-    if (wave >= nwaves) return;
+    if (wave >= A.wave1) return;
     int next = 0;                                                  // wave-uniform: seeds handed out so far
     bool active = false;
     int j0 = 0, j = 0, npos = 0;
@@ -337,14 +340,14 @@ __global__ __launch_bounds__(kBlock) void k_ssa_walk(SsaDev A, unsigned long lon
     }
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    const long long wave = ((long long)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const long long wave = A.wave0 + (((long long)blockIdx.x * kBlock + threadIdx.x) >> 6);
     // kSsaSeedsPerWave seeds per wavefront, dealt in blocks of 64 consecutive seed states ROUND ROBIN over the wavefronts:
     // the long paths start from neighbouring states (measured: the LAST states of the list, the FSP's rim - they step
     // outside and walk through unlisted states to the horizon, hundreds of jumps, while a path from an inner state falls
     // back onto an earlier seed after a handful), and a wavefront that owned 256 consecutive ones of them walked four
     // long paths per lane, one after the other
     const long long nwaves = ((long long)A.n0 + kSsaSeedsPerWave - 1) / kSsaSeedsPerWave;
-    if (wave >= nwaves) return;
+    if (wave >= A.wave1) return;
     int next = 0;                                                  // wave-uniform: seeds handed out so far
     unsigned long long cbase = 0;                                  // wave-uniform: the wavefront's chunk of the record list
     int cleft = 0, nvalid = 0;
@@ -583,7 +586,8 @@ void launch_table_build(int n, int ns, int lds, const int32_t *state, int32_t *t
 // *sn (nnew x lds), *on (nnew x ldo), *dn (nnew) point into ctx->d_pstage until that buffer is used again.
 int ssa_streams_core(kfsp_ctx *ctx, double tstep, int64_t seedmix, int32_t ns, int32_t nr, const int32_t *stoich, int32_t n,
                      const int32_t *d_state, int32_t lds, const int32_t *d_adj, const double *d_off, int32_t lda, const double *d_diag,
-                     int32_t max_count, int32_t cap_new, int32_t ldo, int32_t *n_found, int32_t **sn, double **on, double **dn)
+                     int32_t max_count, int32_t cap_new, int32_t ldo, int32_t *n_found, int32_t **sn, double **on, double **dn,
+                     bool partitioned)
 {
     hipStream_t st = ctx->stream;
     const auto blocks = [](long long k) { return (int)std::max<long long>(1, (k + kBlock - 1) / kBlock); };
@@ -621,7 +625,16 @@ int ssa_streams_core(kfsp_ctx *ctx, double tstep, int64_t seedmix, int32_t ns, i
         if (stoich[i] < -128 || stoich[i] > 127) fast = false;
     // one wavefront per kSsaSeedsPerWave seed states (4 wavefronts per workgroup); the record list is sized by a guess
     // and, should the paths meet more unlisted states than that, by the count the first attempt returns
-    const int wgrid = (int)(((long long)n + 4 * kSsaSeedsPerWave - 1) / (4 * kSsaSeedsPerWave));
+    // Under a row partition (partitioned: every rank is here, with the same lists) rank p walks wavefronts
+    // [nwaves p / P, nwaves (p + 1) / P) of the walk only - a wavefront's seeds are blocks of 64 dealt round robin over ALL
+    // wavefronts, so every share holds rim and inner seeds alike - and the records are all-gathered below: keys are
+    // (seed state, position), the union is the unpartitioned walk's record set, and everything after it (sort, first
+    // occurrences, columns) runs on every rank on identical input.
+    const long long nwaves = ((long long)n + kSsaSeedsPerWave - 1) / kSsaSeedsPerWave;
+    const bool share = partitioned && ctx->use_comm && ctx->nranks > 1 && ctx->opt_ssa_partition != 0;
+    A.wave0 = share ? nwaves * ctx->rank / ctx->nranks : 0;
+    A.wave1 = share ? nwaves * (ctx->rank + 1) / ctx->nranks : nwaves;
+    const int wgrid = (int)std::max<long long>(1, (A.wave1 - A.wave0 + 3) / 4);
     // (the register-resident kernel leaves up to kSsaChunk - 1 slots empty per wavefront and chunk change)
     long long cap = std::max<long long>((long long)1 << 18, (long long)n), nrec = 0, nvalid = 0;
     unsigned long long *d_keys = nullptr;
@@ -650,9 +663,65 @@ int ssa_streams_core(kfsp_ctx *ctx, double tstep, int64_t seedmix, int32_t ns, i
         unsigned long long got[2] = {0, 0};
         SSA_TRY(hipMemcpyAsync(got, d_total, sizeof(got), hipMemcpyDeviceToHost, st));
         SSA_TRY(hipStreamSynchronize(st));
-        if (int rc = prop_check_overflow(ctx)) return rc;           // (a path left a two-species table: nothing was changed)
+        int over = prop_check_overflow(ctx);                        // (a path left a two-species table: nothing was changed)
+        if (over && over != -16) return over;
         nrec = (long long)got[0];                                   // slots taken (empty ones included)
         nvalid = (long long)got[1];                                 // records
+        if (share) {
+            // what every rank must agree on before the next collective: the largest slot count (the list's size, and the
+            // length of the pieces gathered below), the records in all, and whether ANY rank's paths left a table
+            const int P = ctx->nranks;
+            SSA_TRY(ctx->d_os1.reserve((size_t)(P + 1) * 20 * sizeof(double) + 256, false));
+            double *d_s = reinterpret_cast<double *>(ctx->d_os1.p), *d_r = d_s + 20, hs[20], hr[64 * 20];
+            hs[0] = (double)nrec;
+            hs[1] = (double)nvalid;
+            hs[2] = over ? 1.0 : 0.0;
+            for (int s_ = 0; s_ < 16; ++s_) hs[3 + s_] = over ? (double)ctx->prop_missed[s_] : 0.0;
+            SSA_TRY(hipMemcpyAsync(d_s, hs, sizeof(hs), hipMemcpyHostToDevice, st));
+            if (int rc = comm_gather_doubles(ctx, d_s, d_r, 20, st)) return rc;
+            SSA_TRY(hipMemcpyAsync(hr, d_r, (size_t)P * 20 * sizeof(double), hipMemcpyDeviceToHost, st));
+            SSA_TRY(hipStreamSynchronize(st));
+            long long maxrec = 0, sumvalid = 0;
+            bool any_over = false;
+            for (int p = 0; p < P; ++p) {
+                maxrec = std::max<long long>(maxrec, (long long)hr[20 * p]);
+                sumvalid += (long long)hr[20 * p + 1];
+                any_over = any_over || hr[20 * p + 2] != 0.0;
+            }
+            if (any_over) {
+                for (int s_ = 0; s_ < 16; ++s_) {
+                    int32_t m_ = 0;
+                    for (int p = 0; p < P; ++p) m_ = std::max<int32_t>(m_, (int32_t)hr[20 * p + 3 + s_]);
+                    ctx->prop_missed[s_] = m_;
+                }
+                ctx->err = "a population lies beyond a two-species propensity table (kfsp_propensity_overflow says which; enlarge and repeat)";
+                return -16;
+            }
+            if (maxrec > cap) {                                      // some rank's list was too short: all repeat with the same size
+                if (attempt == 1 || maxrec > 2000000000LL / P) {
+                    ctx->err = "SSA paths met more unlisted states than the record list holds";
+                    return -11;
+                }
+                cap = maxrec + 1024;
+                continue;
+            }
+            // the pieces: maxrec slots of every rank (slots a rank did not take keep the empty key), rank after rank
+            const long long tot = maxrec * P;
+            SSA_TRY(ctx->d_os5.reserve((size_t)tot * 8 + (size_t)tot * ns * 4 + 1024, false));
+            Arena a5{ctx->d_os5.p};
+            unsigned long long *d_keys_all = a5.take<unsigned long long>((size_t)tot);
+            int32_t *d_rec_all = a5.take<int32_t>((size_t)tot * ns);
+            if (maxrec > 0) {
+                if (int rc = comm_gather_bytes(ctx, d_keys, d_keys_all, (size_t)maxrec * 8, st)) return rc;
+                if (int rc = comm_gather_bytes(ctx, d_rec, d_rec_all, (size_t)maxrec * ns * 4, st)) return rc;
+            }
+            d_keys = d_keys_all;
+            d_rec = d_rec_all;
+            nrec = tot;
+            nvalid = sumvalid;
+            break;
+        }
+        if (over) return over;
         if (nrec <= cap) break;
         if (attempt == 1 || nrec > 2000000000LL) {
             ctx->err = "SSA paths met more unlisted states than the record list holds";

@@ -68,6 +68,7 @@ MODULE KRYLOVSOLVER
   TYPE(CUSTOM_PLAN), SAVE, PRIVATE :: CPLAN
   LOGICAL, SAVE, PRIVATE :: CUSTOM_WANTED = .TRUE., CUSTOM_ACTIVE = .FALSE., CUSTOM_FAILED = .FALSE.
   INTEGER, SAVE, PRIVATE :: CUSTOM_GROWTHS = 0
+  LOGICAL, SAVE, PRIVATE :: DEBUG_LINKS = .FALSE.    ! KFSP_DEBUG_LINKS=1: size and largest link after every host-side expansion sweep
   ! wall seconds spent in the host state-space code of the current solve:
   ! (1) DROP_STATES decision + compaction, (2) SSA_EXTENDER, (3) ONESTEP_EXTENDER,
   ! (4) uploads of the changed FSP
@@ -310,6 +311,8 @@ CONTAINS
     IF (STAT == 0 .AND. L > 0) DEVICE_REBUILD = ENV(1:1) /= '0'
     CALL GET_ENVIRONMENT_VARIABLE('KFSP_DEVICE_PROPENSITY', ENV, L, STAT)
     IF (STAT == 0 .AND. L > 0) PROGRAM_WANTED = ENV(1:1) /= '0'
+    CALL GET_ENVIRONMENT_VARIABLE('KFSP_DEBUG_LINKS', ENV, L, STAT)
+    DEBUG_LINKS = (STAT == 0 .AND. L > 0 .AND. ENV(1:1) /= '0')
     CALL GET_ENVIRONMENT_VARIABLE('KFSP_DEVICE_CUSTOMPROP', ENV, L, STAT)
     IF (STAT == 0 .AND. L > 0) CUSTOM_WANTED = ENV(1:1) /= '0' 
     ! any other library option (kfsp_set_option, include/kfsp.h): KFSP_OPTIONS="name=value,name=value"
@@ -501,6 +504,8 @@ CONTAINS
     IF (RC == 0) THEN
        IF (CUSTOM_GROW(CPLAN, INT(MISSED(1:CUR_MODEL%NSPECIES)))) GREW = SEND_CUSTOM(CUR_MODEL) == 0
     ENDIF
+    IF (CUR_TRACE /= 0) PRINT '(A,16I6)', ' KFSP CUSTOMPROP: A POPULATION LEFT A TWO-SPECIES TABLE; LARGEST MISSES PER SPECIES =', &
+         MISSED(1:CUR_MODEL%NSPECIES)
     IF (GREW) THEN
        CUSTOM_GROWTHS = CUSTOM_GROWTHS + 1
     ELSE
@@ -684,8 +689,12 @@ CONTAINS
     RC = KFSP_SET_OPTION(CTX, 'ssa_resident' // C_NULL_CHAR, 1_C_INT64_T)
     CALL SSA_EXTENDER(TS, CUR_FSP, CUR_MODEL)
     RC = KFSP_SET_OPTION(CTX, 'ssa_resident' // C_NULL_CHAR, 0_C_INT64_T)
+    IF (DEBUG_LINKS) PRINT *, 'KFSP DEBUG: AFTER SSA_EXTENDER SIZE =', CUR_FSP%SIZE, ' MAX LINK =', &
+         MAXVAL(CUR_FSP%MATRIX%ADJ(:, 1:CUR_FSP%SIZE))
     T1 = WALL()
     CALL ONESTEP_EXTENDER(CUR_FSP, CUR_MODEL)
+    IF (DEBUG_LINKS) PRINT *, 'KFSP DEBUG: AFTER ONESTEP_EXTENDER SIZE =', CUR_FSP%SIZE, ' MAX LINK =', &
+         MAXVAL(CUR_FSP%MATRIX%ADJ(:, 1:CUR_FSP%SIZE)), ' N_BEFORE =', N_BEFORE
     T2 = WALL()
     ! states only get appended here: the propensity columns of the first N_BEFORE are on the device already
     CALL UPLOAD_FSP(CUR_FSP, CUR_MODEL, N_UNCHANGED=N_BEFORE)

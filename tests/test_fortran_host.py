@@ -451,7 +451,7 @@ def test_compute_rkey_returns_the_reference_key_changes(tmp_path):
         assert key([a + b for a, b in zip(x, v)]) == key(x) + sgn * rk
 
 
-def _against_digest(d, log, g, text=""):
+def _against_digest(d, log, g, size_band=(0.5, 2.0)):
     """A whole adaptive run against the digest of the reference's result at the same horizon (oracle/make_golden.py
     fsp_digest: size, mass, every species' marginal, the 4000 most probable states).  Over hundreds of steps any two
     implementations take different - equally valid - step, drop and expansion decisions, so the result
@@ -460,7 +460,6 @@ def _against_digest(d, log, g, text=""):
     budget = float(g["fsptol"]) + 2 * 1.2 * float(g["krytol"]) * float(g["T"])
     w = d["vector"]
     assert np.all(w >= 0) and 1.0 - w.sum() < float(g["fsptol"])
-    assert 0.8 * int(g["n"]) < d["n"] < 1.25 * int(g["n"]), (d["n"], int(g["n"]))
     worst = 0.0
     for s in range(int(g["ns"])):
         ref = g[f"marginal_{s}"]
@@ -474,6 +473,12 @@ def _against_digest(d, log, g, text=""):
           f"(ref {float(g['mass']):.12f}) worst marginal l1 {worst:.3e}, l1 over the reference's {len(g['top_prob'])} most "
           f"probable states {top:.3e} (budget {budget:.1e})")
     assert worst < budget and top < budget
+    # The SIZE of the final FSP is not a property of the solution: it depends on where in its grow / drop cycle a run ends
+    # (DROP_STATES only compacts when more than 10 % of the states go, StateSpace.f90:497), and two valid runs end in
+    # different phases - the reference's own repressilator example ends at 36 541 states, this one (same sampling order) at
+    # 62 473 with the same marginals.  Bounded loosely; 0.8 .. 1.25 holds where the reference's horizon ends in a quiet phase.
+    lo, hi = size_band
+    assert lo * int(g["n"]) < d["n"] < hi * int(g["n"]), (d["n"], int(g["n"]))
 
 
 @pytest.mark.gpu
@@ -486,7 +491,7 @@ def test_goutsias_full_horizon_agrees_with_the_reference(dump, tmp_path):
     p = str(tmp_path / "g.bin")
     text = _run(dump, ["solve", "goutsias_input", p, "300"], tmp_path, env={"KFSP_CASE_CAPACITY": "2097169"})
     assert "LISTS = HOST" in text and "SSA = REFERENCE" in text
-    _against_digest(MG.read_fsp(p), MG.parse_log(text), g)
+    _against_digest(MG.read_fsp(p), MG.parse_log(text), g, size_band=(0.8, 1.25))
 
 
 # (digest, ref_dump case, T): BASELINE config 1 (test/TestSolverFromFile.f90:35), the repressilator .input model over the
@@ -512,7 +517,7 @@ def test_resident_mode_agrees_with_the_reference_at_full_horizon(dump, tmp_path,
         env["KFSP_NRANKS"] = str(ranks)
     text = _run(dump, ["solve", case, p, repr(T)], tmp_path, env=env)
     assert "LISTS = RESIDENT" in text and "PROPENSITIES = DEVICE" in text and "SSA = STREAMS" in text
-    _against_digest(MG.read_fsp(p), MG.parse_log(text), g)
+    _against_digest(MG.read_fsp(p), MG.parse_log(text), g, size_band=(0.8, 1.25))
 
 
 @pytest.mark.gpu

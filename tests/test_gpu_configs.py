@@ -2,8 +2,8 @@
 6-species network small enough for the oracle.
 
   config 4  goutsias_model.input propensities on M, D, RNA in [0,150)^3 x the 6 conserved DNA
-            configurations: N = 2.025e7 states, nnz = 1.81e8 (the row block of ONE GPU; its
-            2- and 4-rank partitions run in tests/test_gpu_loopback.py on a reduced box)
+            configurations: N = 2.025e7 states, nnz = 1.81e8, on one context and row-partitioned over
+            2 and 4 loop-back ranks at the full size
   config 5  synthetic 6-species birth-death network, the per-GPU slab 22^5 x 3 of the 22^6 box:
             N = 1.55e7 states, 12 reactions
 
@@ -69,6 +69,63 @@ def test_config4_at_full_size():
         w = c.get_vector()
         assert np.all(w >= 0) and 0.999 < ws[-1] <= 1.0 + 1e-12
         assert ws[-1] == pytest.approx(w.sum(), rel=1e-13)
+
+
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_config4_at_full_size_row_partitioned(ranks):
+    """BASELINE config 4 as it is stated: "row-partitioned across 2 and 4 GPUs" - here the 2 / 4 contexts of a loop-back
+    group on the one GPU, at the FULL size (2.025e7 states, 1.81e8 nonzeros).  Every rank builds only its block of gather
+    rows (numpy) and uploads it; the partitioned product (banded rows with group masks, halo strips: the configuration
+    shift is 3.4e6 rows, within one block) against the single-context product, an Arnoldi pass with bit-identical scalars
+    on all ranks, and two fixed-(m, tau) steps from the reference's initial state against the single-context steps."""
+    from krylovfspssa_amd import KfspContext, host, synth
+    mdl = synth.GoutsiasConserved(150, 150, 150)
+    rng = np.random.default_rng(44)
+    x = rng.random(mdl.n)
+    p0 = np.zeros(mdl.n)
+    p0[2 + 150 * (6 + 150 * 0)] = 1.0
+    m = 8
+    rowptr, col, val = mdl.csr_rows()
+    with KfspContext(0) as c:
+        c.set_option("m_max", 12)
+        c.set_matrix_csr(mdl.n, rowptr, col, val)
+        c.set_vector(x)
+        y1 = c.spmv_w()
+        beta1 = c.begin_step()
+        H1, mb1, k11, av1 = c.arnoldi(m)
+        c.set_vector(p0)
+        ws1 = c.expv_fixed(m, 0.05, 2)
+        w1 = c.get_vector()
+    del rowptr, col, val
+    mag = np.abs(y1).max()
+
+    def body(ctx, rank):
+        ctx.set_option("m_max", 12)
+        r0, nr = ctx.row_block(mdl.n)
+        rp, cc, vv = mdl.csr_rows(r0, nr)
+        nnz = int(rp[-1])
+        ctx.set_matrix_csr(mdl.n, rp, cc, vv)
+        del rp, cc, vv
+        info = ctx.layout_info()
+        ctx.set_vector(x[r0:r0 + nr])
+        y = ctx.spmv_w()
+        err = float(np.abs(y - y1[r0:r0 + nr]).max()) if nr else 0.0
+        beta = ctx.begin_step()
+        H, mb, k1, av = ctx.arnoldi(m)
+        ctx.set_vector(p0[r0:r0 + nr])
+        ws = ctx.expv_fixed(m, 0.05, 2)
+        l1 = float(np.abs(ctx.get_vector() - w1[r0:r0 + nr]).sum())
+        return err, beta, H.copy(), mb, k1, av, nnz, nr, ws, l1, info["exchange"], info["format"]
+
+    res = host.run_loopback_ranks(ranks, body)
+    assert sum(r[7] for r in res) == mdl.n and sum(r[6] for r in res) == mdl.nnz()
+    assert max(r[0] for r in res) <= 1e-12 * mag
+    for r in res[1:]:
+        assert r[1] == res[0][1] and np.array_equal(r[2], res[0][2]) and r[3:6] == res[0][3:6] and np.array_equal(r[8], res[0][8])
+    assert all(r[10] == 1 and r[11] in (1, 2) for r in res)              # halo strips, banded rows
+    assert abs(res[0][1] - beta1) <= 1e-13 * beta1 and (res[0][3], res[0][4]) == (mb1, k11)
+    assert np.abs(res[0][2] - H1).max() <= 1e-10 * np.abs(H1).max() and abs(res[0][5] - av1) <= 1e-10 * av1
+    assert np.abs(res[0][8] - ws1).max() < 1e-12 and sum(r[9] for r in res) < 1e-10
 
 
 def test_config5_slab_at_full_size():
