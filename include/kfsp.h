@@ -382,6 +382,9 @@ int kfsp_get_basis(kfsp_ctx *ctx, int j, int64_t nlocal, double *v);
  * (src/expokit/dgpadm.f:2-169, :171-339).  E: m*m column-major (ld m). */
 int kfsp_padm(int ideg, int m, double t, const double *H, int ldh, double *E,
               int *ns, double *hnorm);
+/* diagnostic: seconds spent so far inside kfsp_padm in {its dense products (the squaring phase; dealt to KFSP_PADE_THREADS
+ * threads), its banded products, the LU solve, whole calls}; reset != 0 clears the counters */
+void kfsp_padm_profile(double *seconds4, int reset);
 
 /* ---- the adaptive solver ---------------------------------------------- */
 /* Seams of DGEXPV_FSP through which the host's state-space code is reached.
@@ -552,7 +555,10 @@ int kfsp_add_timer(kfsp_ctx *ctx, int phase, double ms);
  * 0 never, 1 always try), "m_max" (largest Krylov dimension the basis is allocated for, default and maximum 100 = M_MAX of
  * KrylovSolver.f90:47; a smaller value saves 8 * rows bytes per column - 90 GB at 10^8 states - and makes kfsp_arnoldi refuse
  * a larger m; it takes effect when the NEXT generator is set - until then every bound follows the basis that is allocated, so
- * raising it and calling kfsp_arnoldi with the larger m before a new generator returns -2; kfsp_dgexpv needs the default), "box_store" (1: kfsp_set_matrix_box stores the generator as diagonals), "box_generic" (1: matrix-free boxes take
+ * raising it and calling kfsp_arnoldi with the larger m before a new generator returns -2; kfsp_dgexpv needs the default), "box_store" (1: kfsp_set_matrix_box stores the generator as diagonals), "box_tile" (the order in which
+ * products over a box take their 128-row trips: -1, default: tiled - blocks of 1024 rows below a stride of at most 16 K rows, per
+ * block every slower line back to back - when neither the vector nor the windows of its far strides fit the 256 MiB Infinity
+ * Cache (22^6: 14 % faster), ascending otherwise; 0 always ascending; 1 always tiled; same bits either way), "box_generic" (1: matrix-free boxes take
  * the run-time interpreted kernel even when the single-factor fast path applies), "state_order" (1: use
  * kfsp_set_state_coords, the default; 0: never), "state_order_min" (smallest generator that is
  * reordered, default 32768), "state_order_products" (products the previous

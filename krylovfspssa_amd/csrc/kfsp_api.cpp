@@ -782,6 +782,46 @@ int init_context(kfsp_ctx *ctx)
 
 }  // namespace
 
+namespace {
+// The order in which a product over a lexicographic box takes its 128-row trips when the box is too large for the caches
+// (option "box_tile": -1 auto, 0 never, 1 always): rows are cut below the slowest stride that is still at most 16 K rows
+// (cut), r = hi * S_cut + lo; blocks of B = 1024 rows of lo; per block ALL lines hi back to back.  A row's +-S neighbours
+// for the strides above the cut are then whole lines away - one line = B rows = 8 KB of x - instead of whole strides:
+// 22^6 with the cut below species 4: the +-22^3 / 22^4 / 22^5 neighbours sit 1 / 22 / 484 lines = 8 KB / 180 KB / 4 MB
+// from the row in the order of the sweep.  Empty: keep the ascending order.
+std::vector<int32_t> box_tile_order(int ns, const int32_t *dims, int64_t n, bool force)
+{
+    std::vector<int32_t> out;
+    const int64_t trips = (n + 127) / 128;
+    if (ns < 3 || trips < 2 || trips > INT32_MAX) return out;
+    int64_t stride = 1, smax = 1;
+    int cut = -1;
+    int64_t scut = 1;
+    for (int s = 0; s < ns; ++s) {
+        if (stride <= 16384 && s > 0) {
+            cut = s;
+            scut = stride;
+        }
+        smax = stride;
+        stride *= dims[s];
+    }
+    const double mall = 256.0 * 1024 * 1024;
+    const bool large = (double)n * 8.0 > mall && 8.0 * 2.0 * (double)smax * 8.0 > mall;
+    if (cut < 1 || scut < 2048 || !(force || large)) return out;
+    const int64_t B = 1024, nhi = (n + scut - 1) / scut;
+    std::vector<std::pair<int64_t, int32_t>> key((size_t)trips);
+    for (int64_t c = 0; c < trips; ++c) {
+        const int64_t r = c * 128, lo = r % scut, hi = r / scut;
+        key[(size_t)c] = {((lo / B) * nhi + hi) * scut + lo, (int32_t)c};
+    }
+    std::sort(key.begin(), key.end());
+    out.resize((size_t)trips);
+    for (int64_t c = 0; c < trips; ++c) out[(size_t)c] = key[(size_t)c].second;
+    return out;
+}
+
+}  // namespace
+
 extern "C" {
 
 int kfsp_abi_version(void) { return kAbiVersion; }
@@ -2401,6 +2441,7 @@ int kfsp_set_option(kfsp_ctx *ctx, const char *name, int64_t value)
     else if (k == "box_lds") ctx->opt_box_lds = value;
     else if (k == "box_reach") ctx->opt_box_reach = value;
     else if (k == "box_store") ctx->opt_box_store = value;
+    else if (k == "box_tile") ctx->opt_box_tile = value;
     else if (k == "sell_code") ctx->opt_sell_code = value;
     else if (k == "ssa_resident") ctx->opt_ssa_resident = value;
     else if (k == "keep_coords") ctx->opt_keep_coords = value;

@@ -7,19 +7,50 @@
 #include <xmmintrin.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
+#include <condition_variable>
+#include <cstdint>
+#include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 namespace {
 
+// An m x m column-major matrix over storage the caller of kfsp_padm keeps between calls (Workspace below): five fresh
+// 83 KB vectors per exponential cost more than its arithmetic - glibc hands blocks of that size back to the system on
+// free, so every call paid ~100 page faults again (137 us of a 980 us call in the build container, 420 of 690 us on the
+// MI355X boxes' host; found with kfsp_padm_profile in round 4).
+struct Span {
+    double *p = nullptr;
+    size_t n = 0;
+    double *data() { return p; }
+    const double *data() const { return p; }
+    size_t size() const { return n; }
+    double &operator[](size_t i) { return p[i]; }
+    double operator[](size_t i) const { return p[i]; }
+    double *begin() { return p; }
+    double *end() { return p + n; }
+    const double *begin() const { return p; }
+    const double *end() const { return p + n; }
+};
 struct Dense {
     int m;
-    std::vector<double> a;
-    explicit Dense(int m_) : m(m_), a((size_t)m_ * m_, 0.0) {}
+    Span a;
+    Dense(int m_, double *store, bool zero) : m(m_)
+    {
+        a.p = store;
+        a.n = (size_t)m_ * m_;
+        if (zero) std::memset(store, 0, a.n * sizeof(double));
+    }
     double &operator()(int i, int j) { return a[(size_t)j * m + i]; }
     double operator()(int i, int j) const { return a[(size_t)j * m + i]; }
 };
+inline void swap_storage(Dense &x, Dense &y) { std::swap(x.a.p, y.a.p); }
 
 // C = alpha * A * B, column major.  Column j of C is a linear combination of
 // the columns of A; four of them are folded per sweep over the column and zero
@@ -80,10 +111,10 @@ __attribute__((target("avx512f,avx512vl,fma"))) void matmul_avx512(double alpha,
     const double *a = A.a.data();                                                             \
     const double *b = B.a.data();                                                             \
     double *c = C.a.data();                                                                   \
-    int j = 0;                                                                                \
+    int j = jbeg;                                                                             \
     /* four output columns share every load of A (8 loads + 8 column accesses per 32 FMAs); every element is still */ \
     /* the same expression as in the two-column sweep below, so the bits do not depend on which sweep made it */      \
-    for (; j + 4 <= m; j += 4) {                                                              \
+    for (; j + 4 <= jend; j += 4) {                                                           \
         double *__restrict__ c0 = c + (size_t)j * m;                                          \
         double *__restrict__ c1 = c0 + m;                                                     \
         double *__restrict__ c2 = c1 + m;                                                     \
@@ -125,6 +156,7 @@ __attribute__((target("avx512f,avx512vl,fma"))) void matmul_avx512(double alpha,
             }                                                                                 \
         }                                                                                     \
     }                                                                                         \
+    if (jend != m) return; /* (a range that ends inside the matrix is whole groups of four) */ \
     for (; j + 2 <= m; j += 2) {                                                              \
         double *__restrict__ c0 = c + (size_t)j * m;                                          \
         double *__restrict__ c1 = c0 + m;                                                     \
@@ -167,8 +199,9 @@ __attribute__((target("avx512f,avx512vl,fma"))) void matmul_avx512(double alpha,
         }                                                                                     \
     }
 
-void matmul_dense_base(double alpha, const Dense &A, const Dense &B, Dense &C) { KFSP_MATMUL_DENSE_BODY }
-__attribute__((target("avx2,fma"))) void matmul_dense_avx2(double alpha, const Dense &A, const Dense &B, Dense &C)
+// (output columns [jbeg, jend): jbeg a multiple of 4, jend a multiple of 4 or m - the ranges the worker threads take)
+void matmul_dense_base(double alpha, const Dense &A, const Dense &B, Dense &C, int jbeg, int jend) { KFSP_MATMUL_DENSE_BODY }
+__attribute__((target("avx2,fma"))) void matmul_dense_avx2(double alpha, const Dense &A, const Dense &B, Dense &C, int jbeg, int jend)
 {
     KFSP_MATMUL_DENSE_BODY
 }
@@ -177,11 +210,106 @@ __attribute__((target("avx2,fma"))) void matmul_dense_avx2(double alpha, const D
 // the previous library on 400 random matrices on both an AVX-512 Xeon and the EPYC (the check is how any change to these
 // bodies has to be accepted: which product of "a b + c d" the compiler fuses is its choice, and a restructured
 // body - a template over the column count was tried - can come out with other bits).
-__attribute__((target("avx512f,avx512vl,fma"))) void matmul_dense_avx512(double alpha, const Dense &A, const Dense &B, Dense &C)
+__attribute__((target("avx512f,avx512vl,fma"))) void matmul_dense_avx512(double alpha, const Dense &A, const Dense &B, Dense &C, int jbeg,
+                                                                         int jend)
 {
     KFSP_MATMUL_DENSE_BODY
 }
 #undef KFSP_MATMUL_DENSE_BODY
+
+// The dense products of the squaring phase (13 or so per exponential, 2 m^3 flops each, m <= 102) are the host's share of a
+// step - 19 % of the resident Goutsias run in round 3.  Output columns are independent and every element is the same
+// expression whichever thread makes it, so the columns are dealt to a few threads in groups of four: the bits cannot change
+// (tests/test_padm_bits.py pins them).  The workers spin for a moment after a product (the next one follows at once inside a
+// call), then sleep until the next call.  KFSP_PADE_THREADS sets their number.  DEFAULT 1 (no workers): measured on the
+// MI355X boxes' host at order 102 (profiles/r04_padm_profile.txt) the dense products go 126 -> 81 us with 4 threads, 45 us of a
+// 300 us call, but 516 us with 2 (a worker on a busy core stalls every product) - worth it only on a host with idle cores.
+class PadePool {
+public:
+    static PadePool &get()
+    {
+        static PadePool *p = new PadePool;      // (never destroyed: its threads are detached and may sleep past exit)
+        return *p;
+    }
+    int threads() const { return nthreads_; }
+    // fn(t) for t = 0 .. threads() - 1, t = 0 on the caller
+    template <class F>
+    void run(const F &fn)
+    {
+        if (nthreads_ <= 1) {
+            fn(0);
+            return;
+        }
+        // (the caller runs with subnormals flushed - kfsp_padm sets FTZ / DAZ for its duration; a worker must round the same way)
+        const unsigned csr = _mm_getcsr();
+        job_ = [&fn, csr](int t) {
+            const unsigned saved = _mm_getcsr();
+            _mm_setcsr(csr);
+            fn(t);
+            _mm_setcsr(saved);
+        };
+        remaining_.store(nthreads_ - 1, std::memory_order_relaxed);
+        gen_.fetch_add(1, std::memory_order_release);
+        if (sleepers_.load(std::memory_order_acquire) > 0) {
+            std::lock_guard<std::mutex> lk(mu_);
+            cv_.notify_all();
+        }
+        fn(0);
+        while (remaining_.load(std::memory_order_acquire) != 0) _mm_pause();
+    }
+
+private:
+    PadePool()
+    {
+        int want = 1;                                    // (opt-in: see the comment above the class)
+        if (const char *e = std::getenv("KFSP_PADE_THREADS")) want = std::atoi(e);
+        const int hw = (int)std::thread::hardware_concurrency();
+        if (hw > 0) want = std::min(want, std::max(1, hw / 2));
+        nthreads_ = std::max(1, std::min(want, 16));
+        for (int t = 1; t < nthreads_; ++t) {
+            try {
+                std::thread(&PadePool::worker, this, t).detach();
+            } catch (...) {
+                nthreads_ = t;
+                break;
+            }
+        }
+    }
+    void worker(int t)
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            int spins = 0;
+            while (gen_.load(std::memory_order_acquire) == seen) {
+                if (++spins < 20000) {
+                    _mm_pause();
+                    continue;
+                }
+                std::unique_lock<std::mutex> lk(mu_);
+                sleepers_.fetch_add(1, std::memory_order_acq_rel);
+                cv_.wait(lk, [&] { return gen_.load(std::memory_order_acquire) != seen; });
+                sleepers_.fetch_sub(1, std::memory_order_acq_rel);
+            }
+            seen = gen_.load(std::memory_order_acquire);
+            job_(t);
+            remaining_.fetch_sub(1, std::memory_order_release);
+        }
+    }
+    int nthreads_ = 1;
+    std::function<void(int)> job_;
+    std::atomic<uint64_t> gen_{0};
+    std::atomic<int> remaining_{0}, sleepers_{0};
+    std::mutex mu_;
+    std::condition_variable cv_;
+};
+
+double g_prof[4] = {0, 0, 0, 0};   // seconds: dense products, banded products, solve, whole calls (kfsp_padm_profile)
+struct ProfTimer {
+    double &acc;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    explicit ProfTimer(double &a) : acc(a) {}
+    ~ProfTimer() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
 
 void matmul(double alpha, const Dense &A, const Dense &B, Dense &C)
 {
@@ -190,11 +318,28 @@ void matmul(double alpha, const Dense &A, const Dense &B, Dense &C)
     size_t nz = 0;
     for (double v : B.a) nz += v != 0.0;
     if (2 * nz > B.a.size()) {                            // mostly non-zero: no point in skipping
-        if (wider) matmul_dense_avx512(alpha, A, B, C);
-        else if (wide) matmul_dense_avx2(alpha, A, B, C);
-        else matmul_dense_base(alpha, A, B, C);
+        ProfTimer pt(g_prof[0]);
+        const int m = A.m;
+        auto part = [&](int jbeg, int jend) {
+            if (wider) matmul_dense_avx512(alpha, A, B, C, jbeg, jend);
+            else if (wide) matmul_dense_avx2(alpha, A, B, C, jbeg, jend);
+            else matmul_dense_base(alpha, A, B, C, jbeg, jend);
+        };
+        PadePool &pool = PadePool::get();
+        const int T = m >= 48 ? pool.threads() : 1;      // (a small product is over before a second thread has heard of it)
+        if (T <= 1) {
+            part(0, m);
+            return;
+        }
+        const int groups = m / 4;                         // whole groups of four columns; the last range also takes the tail
+        pool.run([&](int t) {
+            const int g0 = (int)((long long)groups * t / T), g1 = (int)((long long)groups * (t + 1) / T);
+            const int jb = 4 * g0, je = t == T - 1 ? m : 4 * g1;
+            if (je > jb) part(jb, je);
+        });
         return;
     }
+    ProfTimer pt(g_prof[1]);
     if (wider) matmul_avx512(alpha, A, B, C);
     else if (wide) matmul_avx2(alpha, A, B, C);
     else matmul_base(alpha, A, B, C);
@@ -263,11 +408,21 @@ bool solve_in_place(Dense &Q, Dense &X)
 
 }  // namespace
 
+// where the host's share of a step goes: seconds spent so far in {dense products, banded products, the solve, whole calls}
+extern "C" void kfsp_padm_profile(double *seconds4, int reset)
+{
+    for (int i = 0; i < 4; ++i) {
+        if (seconds4) seconds4[i] = g_prof[i];
+        if (reset) g_prof[i] = 0.0;
+    }
+}
+
 extern "C" int kfsp_padm(int ideg, int m, double t, const double *H, int ldh, double *E, int *ns_out, double *hnorm_out)
 try {
     if (ideg < 1 || ideg > 20) return -1;
     if (m < 1) return -2;
     if (!H) return -4;
+    ProfTimer whole(g_prof[3]);
     if (ldh < m) return -5;
     if (!E) return -6;
     // Entries of exp(tH) far from the band underflow during the squaring phase;
@@ -278,7 +433,11 @@ try {
         FlushSubnormals() { _mm_setcsr(saved | 0x8040u); }
         ~FlushSubnormals() { _mm_setcsr(saved); }
     } flush_guard;
-    Dense A(m);
+    static thread_local std::vector<double> workspace;
+    if (workspace.size() < 5 * (size_t)m * m) workspace.resize(5 * (size_t)m * m);
+    double *ws = workspace.data();
+    const size_t mm = (size_t)m * m;
+    Dense A(m, ws, false);                               // (every element is assigned below)
     double hnorm = 0.0;
     for (int i = 0; i < m; ++i) {
         double rs = 0.0;
@@ -300,7 +459,7 @@ try {
     for (int k = 1; k <= ideg; ++k)
         c[(size_t)k] = c[(size_t)k - 1] * (double)(ideg + 1 - k) / (double)(k * (2 * ideg + 1 - k));
 
-    Dense H2(m), P(m), Q(m), T(m);
+    Dense H2(m, ws + mm, false), P(m, ws + 2 * mm, true), Q(m, ws + 3 * mm, true), T(m, ws + 4 * mm, false);   // (products write every element of their result)
     matmul(scale * scale, A, A, H2);
     for (int i = 0; i < m; ++i) {
         P(i, i) = c[(size_t)ideg - 1];
@@ -312,16 +471,19 @@ try {
         Dense &U = odd ? Q : P;
         matmul(1.0, U, H2, T);
         for (int i = 0; i < m; ++i) T(i, i) += c[(size_t)k - 1];
-        std::swap(U.a, T.a);
+        swap_storage(U, T);
         odd = !odd;
     }
     {
         Dense &U = odd ? Q : P;
         matmul(scale, U, A, T);
-        std::swap(U.a, T.a);
+        swap_storage(U, T);
     }
     for (size_t i = 0; i < Q.a.size(); ++i) Q.a[i] -= P.a[i];
-    if (!solve_in_place(Q, P)) return -7;
+    {
+        ProfTimer pt(g_prof[2]);
+        if (!solve_in_place(Q, P)) return -7;
+    }
     for (double &x : P.a) x *= 2.0;
     for (int i = 0; i < m; ++i) P(i, i) += 1.0;
     if (ns == 0 && odd) {
@@ -329,7 +491,7 @@ try {
     } else {
         for (int k = 0; k < ns; ++k) {
             matmul(1.0, P, P, T);
-            std::swap(P.a, T.a);
+            swap_storage(P, T);
         }
     }
     std::memcpy(E, P.a.data(), P.a.size() * sizeof(double));

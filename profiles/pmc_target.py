@@ -43,8 +43,21 @@ def box(workload):
     raise ValueError(workload)
 
 
+def tiled_order(mdl, cut, B):
+    """profiles/trip_order_sweep_r04.py: blocks of B rows of the index below strides[cut], per block every slower line back to back"""
+    trips = (mdl.n + 127) // 128
+    Sc = int(mdl.strides[cut])
+    r = np.arange(trips, dtype=np.int64) * 128
+    lo, hi = r % Sc, r // Sc
+    return np.argsort(((lo // B) * (hi.max() + 1) + hi) * Sc + lo, kind="stable").astype(np.int32)
+
+
 for case in cases:
     workload, form = case.split(":")
+    tile = None
+    if "@" in form:                                 # form@cut,B : a tiled trip order (round 4), e.g. c5:mf@3,1024
+        form, t = form.split("@")
+        tile = tuple(int(v) for v in t.split(","))
     ctx.set_option("m_max", 8)                      # the product needs two basis columns
     ctx.set_option("format", 0)
     ctx.set_option("sell_code", -1)
@@ -86,6 +99,8 @@ for case in cases:
             ctx.set_matrix_csr(mdl.n, *mdl.csr_rows())
     ctx.set_vector(np.random.default_rng(12345).random(n))
     ctx.begin_step()
+    if tile is not None:
+        ctx.set_trip_order(tiled_order(mdl, *tile))
     ms = float("nan")
     if timed:
         ctx.spmv_bench(20, variant)
