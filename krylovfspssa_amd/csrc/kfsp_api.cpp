@@ -331,6 +331,15 @@ int run_product(kfsp_ctx *ctx, int mode, SpmvArgs a, const double *src, bool src
         a.trip_jump = 0;
         a.trip_order = (ctx->trip_order_n == trips && !force_sell) ? ctx->d_trip_order.p : nullptr;
         const int g = trips_grid(trips, cap);
+        if (fmt == 4 && ctx->box_pencil && ctx->opt_box_pencil != 0 && !ctx->use_comm && ctx->opt_box_lds == 0) {
+            // format 7: one wavefront per pencil of 128 rows x all planes of the slowest species
+            const int gp = trips_grid(ctx->pencil_trips, cap);
+            launch_spmv_pencil(mode, gp, a, st, ctx->box_lds_bytes, ctx->pencil_plane_rows, ctx->pencil_planes, ctx->pencil_trips,
+                               ctx->pencil_order_n == ctx->pencil_trips ? ctx->d_pencil_order.p : nullptr, ctx->pencil_simple);
+            if (p1) *p1 = Pending{P1, gp};
+            if (p2) *p2 = Pending{P2, gp};
+            return 0;
+        }
         if (fmt == 4 && ctx->box_reach > 0 && ctx->opt_box_lds != 0 && !ctx->use_comm && a.trip_order == nullptr) {
             // format 6: near entries from an LDS window of x (single rank: x is readable exactly on [0, n))
             const size_t img = (ctx->box_lds_bytes + 15) & ~(size_t)15;
@@ -894,7 +903,7 @@ int kfsp_destroy(kfsp_ctx *ctx)
     ctx->d_ell_adj.release(); ctx->d_ell_off.release(); ctx->d_ell_diag.release(); ctx->d_cnt.release();
     ctx->d_ticket.release(); ctx->d_slot.release(); ctx->d_scan.release(); ctx->d_strip.release();
     ctx->d_dropflag.release(); ctx->d_dropcnt.release(); ctx->d_box.release(); ctx->d_os1.release(); ctx->d_os2.release();
-    ctx->d_os3.release(); ctx->d_os4.release(); ctx->d_os5.release(); ctx->d_prop_i.release(); ctx->d_prop_d.release();
+    ctx->d_pencil_order.release(); ctx->d_os3.release(); ctx->d_os4.release(); ctx->d_os5.release(); ctx->d_prop_i.release(); ctx->d_prop_d.release();
     ctx->d_prop_t2i.release(); ctx->d_prop_t2o.release(); ctx->d_prop_t2d.release(); ctx->d_prop_oob.release();
     ctx->d_perm.release(); ctx->d_iperm.release(); ctx->d_coords.release(); ctx->d_coords2.release(); ctx->d_ell_adj2.release();
     ctx->d_ell_off2.release(); ctx->d_ell_diag2.release(); ctx->d_pstage.release(); ctx->d_keys.release();
@@ -1340,6 +1349,37 @@ int kfsp_set_matrix_box(kfsp_ctx *ctx, int32_t ns, const int32_t *dims, int32_t 
         HIP_TRY(hipMemcpy(ctx->d_box.p, image.data(), image.size() * sizeof(double), hipMemcpyHostToDevice));
         ctx->box = B;
         ctx->box_fast = fast;
+        // Format 7 (pencils, kfsp_kernels.hip): the instantiation's species are the model's (no padding species), the slowest
+        // species' own entries reach exactly one plane (or are unused slots), no other entry moves the slowest species, planes
+        // have an even number of rows (16-byte pairs), one rank, and there are enough base trips to fill the chip.
+        ctx->box_pencil = false;
+        ctx->pencil_order_n = 0;
+        if (fast && ns >= 3 && ns == ns_inst && ctx->nranks == 1 && !ctx->use_comm) {
+            const int Ls = ns - 1;
+            int64_t plane = 1;
+            for (int s = 0; s < Ls; ++s) plane *= dims[s];
+            // (1: also small boxes - tests.  Nothing else is required of the reactions: an entry that does not fit the register
+            // scheme - it depends on the slowest species but moves another, or moves the slowest by two - is gathered from
+            // memory as in format 4; entries of other species that move the slowest one get that species' valid bit per step)
+            const bool ok = (plane % 2 == 0) && dims[Ls] >= 2 && ((plane + 127) / 128 >= 4096 || ctx->opt_box_pencil > 0);
+            bool simple = true;
+            for (int k = 0; k < nr; ++k)
+                if (dep_species[(size_t)k * kfsp::kBoxMaxDep] != Ls && stoich[(size_t)k * ns + Ls] != 0) simple = false;
+            ctx->pencil_simple = simple;
+            if (ok) {
+                ctx->box_pencil = true;
+                ctx->pencil_plane_rows = plane;
+                ctx->pencil_planes = dims[Ls];
+                ctx->pencil_trips = (plane + 127) / 128;
+                // the base trips in small tiles of the plane (the same rule as box_tile_order, one species fewer)
+                const std::vector<int32_t> po = box_tile_order(Ls, dims, plane, plane * 8 > (int64_t)(4 << 20));
+                if (!po.empty()) {
+                    HIP_TRY(ctx->d_pencil_order.reserve(po.size(), false));
+                    HIP_TRY(hipMemcpy(ctx->d_pencil_order.p, po.data(), po.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+                    ctx->pencil_order_n = (int64_t)po.size();
+                }
+            }
+        }
         // format 6: the largest shift within opt_box_reach rows decides how much of x a workgroup stages in LDS;
         // the windows must fit beside the table image in the 64 KB a workgroup gets without asking for more
         ctx->box_reach = 0;
@@ -1477,7 +1517,8 @@ int kfsp_layout_info(const kfsp_ctx *ctx, int64_t *v)
     if (!ctx) return -1;
     if (!v) return -2;
     if (ctx->group) return kfsp::group_layout_info(ctx, v);
-    v[0] = ctx->use_box ? (ctx->box_fast && !ctx->opt_box_generic ? (ctx->box_reach > 0 && ctx->opt_box_lds && !ctx->use_comm ? 6 : 4) : 3) : ctx->use_dia ? (ctx->dia_masked ? 2 : 1) : (ctx->sell_coded ? 5 : 0);
+    v[0] = ctx->use_box ? (ctx->box_fast && !ctx->opt_box_generic ? (ctx->box_reach > 0 && ctx->opt_box_lds && !ctx->use_comm ? 6 :
+                           (ctx->box_pencil && ctx->opt_box_pencil != 0 && !ctx->use_comm ? 7 : 4)) : 3) : ctx->use_dia ? (ctx->dia_masked ? 2 : 1) : (ctx->sell_coded ? 5 : 0);
     v[1] = !ctx->use_comm ? 0 : (ctx->use_halo ? 1 : 2);
     v[2] = ctx->halo;
     v[3] = ctx->use_dia ? -1 : ctx->sell_reach;
@@ -2442,6 +2483,7 @@ int kfsp_set_option(kfsp_ctx *ctx, const char *name, int64_t value)
     else if (k == "box_reach") ctx->opt_box_reach = value;
     else if (k == "box_store") ctx->opt_box_store = value;
     else if (k == "box_tile") ctx->opt_box_tile = value;
+    else if (k == "box_pencil") ctx->opt_box_pencil = value;
     else if (k == "sell_code") ctx->opt_sell_code = value;
     else if (k == "ssa_resident") ctx->opt_ssa_resident = value;
     else if (k == "keep_coords") ctx->opt_keep_coords = value;

@@ -234,6 +234,9 @@ void launch_spmv(int mode, int grid, const SpmvArgs &a, bool nontemporal, int fm
 // format 6: the single-factor matrix-free product with the near part of x staged in LDS (reach rows on either side of a
 // workgroup's 512; lds_bytes = table image + two windows)
 void launch_spmv_boxlds(int mode, int grid, const SpmvArgs &a, hipStream_t s, size_t lds_bytes, int reach);
+// format 7: a wavefront walks the planes of the slowest species (kfsp_kernels.hip, k_spmv_pencil)
+void launch_spmv_pencil(int mode, int grid, const SpmvArgs &a, hipStream_t s, size_t lds_bytes, int64_t plane_rows, int planes,
+                        int64_t base_trips, const int32_t *order, bool simple);
 void launch_ortho2(int grid, const Ortho2Args &a, hipStream_t s);
 void launch_ortho(int grid, const OrthoArgs &a, hipStream_t s);
 void launch_combine(int grid, const CombineArgs &a, hipStream_t s);

@@ -1117,6 +1117,280 @@ void launch_ortho2(int grid, const Ortho2Args &a, hipStream_t st)
     hipLaunchKernelGGL(k_ortho2, dim3(grid), dim3(kBlock), 0, st, a);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Format 7 (round 4): the PENCIL product of a matrix-free box (single-factor fast form, one rank).
+//
+// Format 4 takes the rows 128 at a time in (some) order of the row index and gathers every entry's source element of x from
+// memory.  On the 6-species boxes (BASELINE config 5: 22^6) that is where the time goes: the two entries of the SLOWEST species
+// reach +-22^5 rows = 41 MB, no cache holds anything that far, and x crosses the fabric ~6 times per product
+// (profiles/r04_pmc_trip_order_tiles.txt: 5.2-5.6 GB read for a 0.9 GB vector, at 0.73-0.80 of the HBM peak - the kernel is bound
+// by that traffic; ordering the trips in small tiles moves it by 7 %).
+// Here a wavefront owns the 128 rows of a "base trip" of ONE plane of the slowest species and walks the planes: rows
+// lo + p * plane_rows, p = 0 .. planes - 1.  Along that walk
+//   * the coordinates of the other species, their shares of DIAG, every entry's table value a_k(x - nu) and its validity do not
+//     change: they are worked out once per pencil (coordinate decoding, 10 table look-ups) instead of once per 128 rows;
+//   * the source elements of the slowest species' own entries are the lane's OWN rows of the previous / next plane: the pair
+//     the lane loaded one step ago and the pair it loads one step ahead - registers, no memory access at all;
+//   * the slowest species' coordinate is the step number: its table values and valid bits are wave-uniform.
+// Per step and lane: 10 gathers + 1 streaming pair load and ~40 vector instructions, against 13 gathers and ~300; and what
+// crosses the fabric is x once plus whatever the second-slowest stride misses in the L2 (the base trips are taken in small tiles,
+// box_tile_order, so that those neighbours are in flight on the same XCD at the same step).
+// Every row is the same sequence of fused multiply-adds over the same operands as in format 4: products are bit-identical
+// (tests/test_gpu_box.py, tests/test_gpu_configs.py).  Eligibility (kfsp_set_matrix_box): the slowest species' entries reach
+// exactly one plane, no other entry moves that species, planes have an even number of rows, enough base trips to fill the chip.
+// SIMPLE: no entry of another species moves the slowest one (every birth-death / mass-action box whose reactions change one
+// species each): the entries served from memory keep their validity along the pencil.  Otherwise their valid bit of the
+// slowest species (wave-uniform, from its table at the step's population) is applied step by step.
+template <int MODE, int NS, int PER, bool SIMPLE>
+__global__ __launch_bounds__(kBlock) void k_spmv_pencil(SpmvArgs a, int64_t plane_rows, int planes, int64_t base_trips,
+                                                        const int32_t *__restrict__ order)
+{
+    constexpr int L = NS - 1;                       // the slowest species
+    constexpr int NE = L * PER;                     // entries whose source comes from memory
+    __shared__ double red[12];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (MODE != 0) {
+        if (*a.brk_flag) return;
+    }
+    for (int i = threadIdx.x; i < a.B.ntab; i += kBlock) box_lds[i] = a.box_tab[i];
+    __syncthreads();
+    BoxRegs<NS, PER> R;
+    box_load(a.box_fast, R);
+    double s = 1.0;
+    if (MODE != 0) {
+        const double S = finish_sum(a.sq, red);
+        const double nrm = sqrt(S);
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            if (a.sq_final) *a.sq_final = S;
+            if (a.h_sub) *a.h_sub = nrm;
+        }
+        if (a.break_tol >= 0.0 && !(nrm > a.break_tol)) {   // happy breakdown :249
+            if (blockIdx.x == 0 && threadIdx.x == 0) *a.brk_flag = 1;
+            return;
+        }
+        s = 1.0 / nrm;
+    }
+    const int xcd = blockIdx.x & 7;
+    const int slot = blockIdx.x >> 3;
+    const int bx = gridDim.x >> 3;
+    const int64_t cpx = (base_trips + 7) >> 3;
+    const int64_t cbeg = (int64_t)xcd * cpx;
+    const int64_t cend = (cbeg + cpx < base_trips) ? cbeg + cpx : base_trips;
+    const int64_t cstep = (int64_t)bx * 4;
+    const lds_bytes_t lds = (lds_bytes_t)box_lds;
+    const unsigned lds0 = (unsigned)(size_t)lds;
+    const int64_t plane_bytes = plane_rows * 8;
+    double acc = 0.0, acc2 = 0.0;
+    for (int64_t c = cbeg + (int64_t)slot * 4 + wave; c < cend; c += cstep) {
+        const int64_t ct = order ? (int64_t)__builtin_amdgcn_readfirstlane(order[c]) : c;
+        const int64_t r0 = (ct << 7) + 2 * lane;                  // the lane's rows r0, r0 + 1 of every plane
+        if (r0 < plane_rows) {                                     // (plane_rows is even: both rows or neither)
+            // ---- what does not change along the pencil
+            int c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
+            uint32_t q = (uint32_t)r0;
+#define KFSP_PEN_DEC(S, VAR)                                             \
+    if (L > S + 1) {                                                     \
+        const int d = R.dims[L > S ? S : 0];                             \
+        uint32_t t = (uint32_t)((double)q * R.inv_dim[L > S ? S : 0]);   \
+        int r = (int)(q - t * (uint32_t)d);                              \
+        const int lo_ = r < 0, hi_ = r >= d;                             \
+        t = t - lo_ + hi_;                                               \
+        r = r + (lo_ ? d : 0) - (hi_ ? d : 0);                           \
+        VAR = r;                                                         \
+        q = t;                                                           \
+    } else if (L == S + 1) {                                             \
+        VAR = (int)q;                                                    \
+    }
+            KFSP_PEN_DEC(0, c0)
+            KFSP_PEN_DEC(1, c1)
+            KFSP_PEN_DEC(2, c2)
+            KFSP_PEN_DEC(3, c3)
+            KFSP_PEN_DEC(4, c4)
+#undef KFSP_PEN_DEC
+            int b0 = c0, b1 = c1, b2 = c2, b3 = c3, b4 = c4, carry = 1;
+#define KFSP_PEN_INC(S, VAR)                                             \
+    if (L > S) {                                                         \
+        const int v = VAR + carry;                                       \
+        const int wrap = (L > S + 1) && v >= R.dims[L > S ? S : 0];      \
+        VAR = wrap ? 0 : v;                                              \
+        carry = wrap;                                                    \
+    }
+            KFSP_PEN_INC(0, b0)
+            KFSP_PEN_INC(1, b1)
+            KFSP_PEN_INC(2, b2)
+            KFSP_PEN_INC(3, b3)
+            KFSP_PEN_INC(4, b4)
+#undef KFSP_PEN_INC
+            // shares of DIAG and valid bits of the species below the slowest, in species order (the order format 4 adds them in)
+            double dsa0, dsb0;
+            unsigned va0, vb0;
+            {
+                const lds_bytes_t fa = lds + R.df8[0] + 16 * c0, fb = lds + R.df8[0] + 16 * b0;
+                dsa0 = *(const __attribute__((address_space(3))) double *)fa;
+                va0 = *(const __attribute__((address_space(3))) unsigned *)(fa + 8);
+                dsb0 = *(const __attribute__((address_space(3))) double *)fb;
+                vb0 = *(const __attribute__((address_space(3))) unsigned *)(fb + 8);
+            }
+#define KFSP_PEN_DF(S, CA, CB)                                                                       \
+    if (L > S) {                                                                                     \
+        const lds_bytes_t fa = lds + R.df8[L > S ? S : 0] + 16 * CA, fb = lds + R.df8[L > S ? S : 0] + 16 * CB; \
+        dsa0 += *(const __attribute__((address_space(3))) double *)fa;                               \
+        va0 &= *(const __attribute__((address_space(3))) unsigned *)(fa + 8);                        \
+        dsb0 += *(const __attribute__((address_space(3))) double *)fb;                               \
+        vb0 &= *(const __attribute__((address_space(3))) unsigned *)(fb + 8);                        \
+    }
+            KFSP_PEN_DF(1, c1, b1)
+            KFSP_PEN_DF(2, c2, b2)
+            KFSP_PEN_DF(3, c3, b3)
+            KFSP_PEN_DF(4, c4, b4)
+#undef KFSP_PEN_DF
+            // table values of the entries served from memory (0.0 where the source state lies outside the box) and where their
+            // source pair sits relative to the lane's own pair
+            double ta[NE > 0 ? NE : 1], tb[NE > 0 ? NE : 1];
+            unsigned off[NE > 0 ? NE : 1];
+            const unsigned voff = (unsigned)(16 * lane + R.bias8);
+#define KFSP_PEN_ENT(S, CA, CB)                                                                      \
+    if (L > S) {                                                                                     \
+        _Pragma("unroll") for (int j = 0; j < PER; ++j) {                                            \
+            constexpr int e = (L > S ? S : 0) * PER;                                                 \
+            const int ma = __builtin_amdgcn_sbfe(va0, e + j, 1), mb = __builtin_amdgcn_sbfe(vb0, e + j, 1); \
+            const unsigned ata = lds0 + (unsigned)(8 * CA + R.koff8[L > S ? S : 0][j]);              \
+            const unsigned atb = lds0 + (unsigned)(8 * CB + R.koff8[L > S ? S : 0][j]);              \
+            ta[e + j] = *(const __attribute__((address_space(3))) double *)(size_t)((ma & ata) | (~ma & lds0)); \
+            tb[e + j] = *(const __attribute__((address_space(3))) double *)(size_t)((mb & atb) | (~mb & lds0)); \
+            off[e + j] = (ma | mb) ? voff + (unsigned)R.delta8[L > S ? S : 0][j] : voff;             \
+        }                                                                                            \
+    }
+            KFSP_PEN_ENT(0, c0, b0)
+            KFSP_PEN_ENT(1, c1, b1)
+            KFSP_PEN_ENT(2, c2, b2)
+            KFSP_PEN_ENT(3, c3, b3)
+            KFSP_PEN_ENT(4, c4, b4)
+#undef KFSP_PEN_ENT
+            // ---- the walk over the planes
+            uint64_t xb = reinterpret_cast<uint64_t>(a.xg + (ct << 7)) - (uint64_t)(int64_t)R.bias8;
+            box_pair_t xprev = {0.0, 0.0}, xcur, xnext = {0.0, 0.0};
+            {
+                const global_bytes_t xw = (global_bytes_t)((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)xb) |
+                                                           (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(xb >> 32)) << 32);
+                xcur = *(const __attribute__((address_space(1), aligned(8))) box_pair_t *)(xw + voff);
+            }
+            int64_t row = r0;
+            for (int p = 0; p < planes; ++p) {
+                const global_bytes_t xw = (global_bytes_t)((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)xb) |
+                                                           (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(xb >> 32)) << 32);
+                if (p + 1 < planes) xnext = *(const __attribute__((address_space(1), aligned(8))) box_pair_t *)(xw + plane_bytes + voff);
+                // the slowest species at population p: its share of DIAG and its valid bits are the same for every lane
+                const lds_bytes_t fl = lds + R.df8[L] + 16 * p;
+                const double dsl = *(const __attribute__((address_space(3))) double *)fl;
+                const unsigned vl = *(const __attribute__((address_space(3))) unsigned *)(fl + 8);
+                double acca = 0.0, accb = 0.0;
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    if (SIMPLE) {
+                        const box_pair_t xv = *(const __attribute__((address_space(1), aligned(8))) box_pair_t *)(xw + off[e]);
+                        acca += ta[e] * xv.x;
+                        accb += tb[e] * xv.y;
+                    } else {
+                        // (the entry moves the slowest species too: whether its source plane exists is this step's bit)
+                        const bool here = (vl >> e) & 1u;
+                        const box_pair_t xv = *(const __attribute__((address_space(1), aligned(8))) box_pair_t *)(xw + (here ? off[e] : voff));
+                        acca += (here ? ta[e] : 0.0) * xv.x;
+                        accb += (here ? tb[e] : 0.0) * xv.y;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < PER; ++j) {
+                    const int ma = __builtin_amdgcn_sbfe(va0 & vl, L * PER + j, 1), mb = __builtin_amdgcn_sbfe(vb0 & vl, L * PER + j, 1);
+                    const unsigned at = lds0 + (unsigned)(8 * p + R.koff8[L][j]);
+                    const double a1a = *(const __attribute__((address_space(3))) double *)(size_t)((ma & at) | (~ma & lds0));
+                    const double a1b = *(const __attribute__((address_space(3))) double *)(size_t)((mb & at) | (~mb & lds0));
+                    // The source pair.  An entry that only moves the slowest species by one: the lane's own rows one plane
+                    // down / up - the pair it loaded a step ago / loads a step ahead (format 4 gathers x[g + delta] from
+                    // memory).  Any other entry of this species (a propensity that depends on it but moves others): from memory,
+                    // as in format 4.  Where neither row has the entry: the own pair (format 4 reads it and multiplies by 0.0).
+                    const int d = R.delta8[L][j];
+                    box_pair_t xv;
+                    if ((int64_t)d == plane_bytes) xv = xnext;
+                    else if ((int64_t)d == -plane_bytes) xv = xprev;
+                    else xv = *(const __attribute__((address_space(1), aligned(8))) box_pair_t *)(xw + ((ma | mb) ? voff + (unsigned)d : voff));
+                    if (!(ma | mb)) xv = xcur;
+                    acca += a1a * xv.x;
+                    accb += a1b * xv.y;
+                }
+                d2 sum;
+                sum.x = acca - (dsa0 + dsl) * xcur.x;
+                sum.y = accb - (dsb0 + dsl) * xcur.y;
+                if (MODE != 0) {
+                    sum.x *= s;
+                    sum.y *= s;
+                }
+                *reinterpret_cast<d2 *>(a.y + row) = sum;
+                if (MODE == 1 || MODE == 3) {
+                    const d2 u = *reinterpret_cast<const d2 *>(a.udot + row);
+                    acc += u.x * sum.x;
+                    acc += u.y * sum.y;
+                }
+                if (MODE == 2) {
+                    acc += sum.x * sum.x;
+                    acc += sum.y * sum.y;
+                }
+                if (MODE == 3) {
+                    const d2 u = *reinterpret_cast<const d2 *>(a.udot2 + row);
+                    acc2 += u.x * sum.x;
+                    acc2 += u.y * sum.y;
+                }
+                xprev = xcur;
+                xcur = xnext;
+                xb += (uint64_t)plane_bytes;
+                row += plane_rows;
+            }
+        }
+    }
+    if (MODE == 3) {
+        double dummy = 0.0;
+        block_allreduce_sum3(acc, acc2, dummy, red);
+        if (threadIdx.x == 0) {
+            a.partial[blockIdx.x] = acc;
+            a.partial2[blockIdx.x] = acc2;
+        }
+    } else if (MODE != 0) {
+        const double t = block_allreduce_sum(acc, red);
+        if (threadIdx.x == 0) a.partial[blockIdx.x] = t;
+    }
+}
+
+template <int NS, int NE, bool SIMPLE>
+static void launch_pencil_mode(int mode, dim3 g, dim3 b, const SpmvArgs &a, hipStream_t st, size_t lds, int64_t plane_rows, int planes,
+                               int64_t base_trips, const int32_t *order)
+{
+    if (mode == 0) hipLaunchKernelGGL((k_spmv_pencil<0, NS, NE, SIMPLE>), g, b, lds, st, a, plane_rows, planes, base_trips, order);
+    else if (mode == 1) hipLaunchKernelGGL((k_spmv_pencil<1, NS, NE, SIMPLE>), g, b, lds, st, a, plane_rows, planes, base_trips, order);
+    else if (mode == 2) hipLaunchKernelGGL((k_spmv_pencil<2, NS, NE, SIMPLE>), g, b, lds, st, a, plane_rows, planes, base_trips, order);
+    else hipLaunchKernelGGL((k_spmv_pencil<3, NS, NE, SIMPLE>), g, b, lds, st, a, plane_rows, planes, base_trips, order);
+}
+
+// format 7 (the instantiations of format 4 whose species count is the model's: 3 and 6 species with two slots, 6 with four)
+void launch_spmv_pencil(int mode, int grid, const SpmvArgs &a, hipStream_t st, size_t lds_bytes, int64_t plane_rows, int planes,
+                        int64_t base_trips, const int32_t *order, bool simple)
+{
+    dim3 g(grid), b(kBlock);
+    if (simple) {
+        switch (a.B.pad) {
+        case 3 * 16 + 2: launch_pencil_mode<3, 2, true>(mode, g, b, a, st, lds_bytes, plane_rows, planes, base_trips, order); break;
+        case 6 * 16 + 2: launch_pencil_mode<6, 2, true>(mode, g, b, a, st, lds_bytes, plane_rows, planes, base_trips, order); break;
+        default: launch_pencil_mode<6, 4, true>(mode, g, b, a, st, lds_bytes, plane_rows, planes, base_trips, order); break;
+        }
+        return;
+    }
+    switch (a.B.pad) {
+    case 3 * 16 + 2: launch_pencil_mode<3, 2, false>(mode, g, b, a, st, lds_bytes, plane_rows, planes, base_trips, order); break;
+    case 6 * 16 + 2: launch_pencil_mode<6, 2, false>(mode, g, b, a, st, lds_bytes, plane_rows, planes, base_trips, order); break;
+    default: launch_pencil_mode<6, 4, false>(mode, g, b, a, st, lds_bytes, plane_rows, planes, base_trips, order); break;
+    }
+}
+
 // ----------------------------------------------- small-N Arnoldi pass, one launch
 // One workgroup of 1024 lanes owns every row (<= 4 per lane).  Columns are
 // separated by workgroup barriers instead of kernel boundaries, the current

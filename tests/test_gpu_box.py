@@ -281,3 +281,47 @@ def test_matrix_free_random_boxes_with_a_row_partition(oracle, P):
         scale = oracle.spmv_ell(oracle.EllMatrix(adj, np.abs(off), -np.abs(diag)), np.abs(x))
         assert np.all(np.abs(y - oracle.spmv_ell(A, x)) <= 2e-13 * np.abs(scale) + 1e-300), (k, mdl.dims, mdl.stoich.tolist())
     assert done == 10
+
+
+@pytest.mark.parametrize("name,dims", [("repressilator", (31, 24, 19)), ("repressilator", (16, 64, 7)), ("birth_death6", (5, 6, 4, 5, 4, 7)),
+                                       ("birth_death6", (8, 4, 4, 4, 4, 2)), ("birth_death4", (12, 9, 10, 6))])
+def test_pencil_product_equals_the_trip_product_bit_for_bit(oracle, name, dims):
+    """Kernel format 7 (option box_pencil): a wavefront owns 128 rows of one plane of the slowest species and walks the planes;
+    the slowest species' own entries take their source elements from the lane's previous / next pair (registers) and everything
+    that depends on the other coordinates is worked out once per pencil.  Every row is the same sequence of fused multiply-adds
+    over the same operands as in format 4: y must be bit-identical (here box_pencil = 1 forces it on small boxes; by default it
+    serves boxes with >= 4096 base trips - tests/test_gpu_configs.py runs config 5 through it).  Planes that are not a multiple
+    of 128 rows (a last base trip with dead lanes), two planes only, a 4-species model (instantiated with 6: not eligible, the
+    option must leave format 4), and the fused modes (Arnoldi pass, fixed-(m, tau) steps) against the oracle."""
+    from krylovfspssa_amd import KfspContext, synth
+    mdl = synth.repressilator(dims=dims) if name == "repressilator" else synth.birth_death(dims)
+    adj, off, diag = mdl.ell()
+    A = oracle.EllMatrix(adj, off, diag)
+    rng = np.random.default_rng(12)
+    x = rng.random(mdl.n) - 0.3                                  # (both signs: the 0.0 * x of an absent entry may be -0.0)
+    p0 = rng.random(mdl.n)
+    p0 /= p0.sum()
+    m, tau, nsteps = 14, 0.004, 2
+    out = {}
+    for pencil in (0, 1):
+        with KfspContext(0) as c:
+            c.set_option("small_kernel", 0)
+            c.set_option("box_pencil", pencil)
+            c.set_matrix_box(mdl)
+            fmt = c.layout_info()["format"]
+            assert fmt == (7 if pencil and len(dims) in (3, 6) else 4), (fmt, pencil)
+            y = c.spmv(x)
+            c.set_vector(p0)
+            c.begin_step()
+            H, mb, k1, av = c.arnoldi(m)
+            c.set_vector(p0)
+            ws = c.expv_fixed(m, tau, nsteps)
+            out[pencil] = dict(y=y, H=H.copy(), mb=mb, k1=k1, ws=ws, w=c.get_vector())
+    assert np.array_equal(out[0]["y"], out[1]["y"])
+    scale = oracle.spmv_ell(oracle.EllMatrix(adj, np.abs(off), -np.abs(diag)), np.abs(x))
+    assert np.all(np.abs(out[1]["y"] - oracle.spmv_ell(A, x)) <= 1e-13 * np.abs(scale) + 1e-300)
+    wref, wsref = oracle.expv_fixed(A, p0, m, tau, nsteps)
+    V, Href, mbr, k1r, avr = oracle.arnoldi(A, p0 / np.sqrt((p0 * p0).sum()), m)
+    for o in out.values():
+        assert np.abs(o["w"] - wref).sum() < 1e-10 and np.abs(o["ws"] - wsref).max() < 1e-12
+        assert (o["mb"], o["k1"]) == (mbr, k1r) and np.abs(o["H"][:9, :8] - Href[:9, :8]).max() <= 1e-11 * np.abs(Href).max()
