@@ -333,7 +333,9 @@ int run_product(kfsp_ctx *ctx, int mode, SpmvArgs a, const double *src, bool src
         const int g = trips_grid(trips, cap);
         if (fmt == 4 && ctx->box_pencil && ctx->opt_box_pencil != 0 && !ctx->use_comm && ctx->opt_box_lds == 0) {
             // format 7: one wavefront per pencil of 128 rows x all planes of the slowest species
-            const int gp = trips_grid(ctx->pencil_trips, cap);
+            // (3 workgroups per CU: measured best on the 22^6 box and its slab - 768: 798 / 77.7 us, 512: 866 / 84, 1024: 936 / 86,
+            // 2048: 816 / 81; anything that is not a multiple of 256 leaves some CUs with one more - profiles/r04_pencil_grid_sweep.txt)
+            const int gp = trips_grid(ctx->pencil_trips, ctx->opt_grid > 0 ? cap : 768);
             launch_spmv_pencil(mode, gp, a, st, ctx->box_lds_bytes, ctx->pencil_plane_rows, ctx->pencil_planes, ctx->pencil_trips,
                                ctx->pencil_order_n == ctx->pencil_trips ? ctx->d_pencil_order.p : nullptr, ctx->pencil_simple);
             if (p1) *p1 = Pending{P1, gp};
