@@ -118,6 +118,7 @@ CONTAINS
     INTEGER(8) :: C0, C1, CRATE
     LOGICAL :: WAS_RESIDENT
     DOUBLE PRECISION :: T0V
+    REAL(C_DOUBLE) :: PADE_SEC(4)
 
     IFLAG = 0
     ! the device context comes first: the threads its runtime starts must not
@@ -130,6 +131,7 @@ CONTAINS
     CALL KFSP_UPLOAD_PROGRAM(MODEL, SEEDS=SEED)
     CALL SYSTEM_CLOCK(C0, CRATE)
     RC = KFSP_GET_TIMERS(CTX, TMS, 1_C_INT)
+    CALL KFSP_PADM_PROFILE(PADE_SEC, 1_C_INT)
     HOST_SEC = 0.0D0
 
     ATTEMPT: DO
@@ -227,6 +229,9 @@ CONTAINS
        PRINT '(A,A,A,A,A,A,A,A)', ' KFSP MODE: LISTS = ', TRIM(MERGE('RESIDENT', 'HOST    ', WAS_RESIDENT)), ' PROPENSITIES = ', &
             TRIM(MERGE('DEVICE', 'HOST  ', PROGRAM_READY)), ' SSA = ', TRIM(MERGE('STREAMS  ', 'REFERENCE', SSA_STREAMS_REQUESTED())), &
             ' MODEL = ', TRIM(MERGE('CUSTOMPROP ', 'EXPRESSIONS', ASSOCIATED(MODEL%CUSTOMPROP)))
+       CALL KFSP_PADM_PROFILE(PADE_SEC, 1_C_INT)
+       PRINT '(A,4(1X,A,F9.1))', ' KFSP HOST PADE PARTS MS:', 'DENSE_PRODUCTS', 1.0D3 * PADE_SEC(1), 'BANDED_PRODUCTS', 1.0D3 * PADE_SEC(2), &
+            'SOLVE', 1.0D3 * PADE_SEC(3), 'WHOLE_CALLS', 1.0D3 * PADE_SEC(4)
        PRINT '(A,I8,A,I8,A,I8,A,I6,A,I6)', ' KFSP STATS: NMULT =', LAST_SOLVE_STATS%NMULT, ' NEXPH =', &
             LAST_SOLVE_STATS%NEXPH, ' WSUM_EVALS =', LAST_SOLVE_STATS%N_WSUM, ' EXPANSIONS =', &
             LAST_SOLVE_STATS%N_EXPAND, ' DROP_CALLS =', LAST_SOLVE_STATS%N_DROP_CALLS
