@@ -4,6 +4,7 @@
 // (src/expokit/dgpadm.f:2-169, :171-339) with our own products and LU.
 #include "../../include/kfsp.h"
 
+#include <sched.h>
 #include <xmmintrin.h>
 
 #include <algorithm>
@@ -224,6 +225,17 @@ __attribute__((target("avx512f,avx512vl,fma"))) void matmul_dense_avx512(double 
 // call), then sleep until the next call.  KFSP_PADE_THREADS sets their number.  DEFAULT 1 (no workers): measured on the
 // MI355X boxes' host at order 102 (profiles/r04_padm_profile.txt) the dense products go 126 -> 81 us with 4 threads, 45 us of a
 // 300 us call, but 516 us with 2 (a worker on a busy core stalls every product) - worth it only on a host with idle cores.
+// The CPUs this process may use, as they were when the library was loaded: by the time a solve runs, the host's OpenMP
+// runtime has bound the calling thread to ONE core (OMP_PROC_BIND=close, fortran/kfsp_statespace.f90) and a thread started
+// from it inherits that mask - four workers spinning on the caller's core turned a 0.65 s Pade share into 11 s
+// (profiles/r04_padm_profile.txt).  Workers take this mask instead.
+cpu_set_t g_initial_cpus;
+bool g_have_initial_cpus = false;
+__attribute__((constructor)) void remember_initial_cpus()
+{
+    g_have_initial_cpus = sched_getaffinity(0, sizeof(g_initial_cpus), &g_initial_cpus) == 0;
+}
+
 class PadePool {
 public:
     static PadePool &get()
@@ -277,6 +289,7 @@ private:
     }
     void worker(int t)
     {
+        if (g_have_initial_cpus) (void)sched_setaffinity(0, sizeof(g_initial_cpus), &g_initial_cpus);
         uint64_t seen = 0;
         for (;;) {
             int spins = 0;
