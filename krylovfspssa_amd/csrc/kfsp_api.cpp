@@ -331,6 +331,20 @@ int run_product(kfsp_ctx *ctx, int mode, SpmvArgs a, const double *src, bool src
         a.trip_jump = 0;
         a.trip_order = (ctx->trip_order_n == trips && !force_sell) ? ctx->d_trip_order.p : nullptr;
         const int g = trips_grid(trips, cap);
+        if (fmt == 4 && ctx->box_slab && ctx->opt_box_pencil != 0 && ctx->opt_box_pencil != 1 && !ctx->use_comm && ctx->opt_box_lds == 0) {
+            // format 8: one workgroup per 128 rows x W lines of the second-slowest species, walking the planes in step
+            const int64_t total = ctx->slab_lo_trips * ctx->slab_groups;
+            const size_t lds = ((ctx->box_lds_bytes + 15) & ~(size_t)15) + 2 * (size_t)ctx->slab_waves * 1024;
+            // (workgroups of up to 1024 threads: as many as are resident at once, they loop over the slabs)
+            const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(12 / ctx->slab_waves, (int64_t)(160 * 1024) / (int64_t)(lds + 1024)));
+            const int64_t want = ctx->opt_grid > 0 ? ctx->opt_grid : 256 * std::min<int64_t>(per_cu, 2);
+            const int gs = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(total, want), kMaxGrid));
+            launch_spmv_slab(mode, gs, ctx->slab_waves, a, st, lds, ctx->pencil_plane_rows, ctx->pencil_planes, ctx->slab_line_rows,
+                             ctx->slab_lines, ctx->slab_groups, ctx->slab_lo_trips, ctx->pencil_simple);
+            if (p1) *p1 = Pending{P1, gs};
+            if (p2) *p2 = Pending{P2, gs};
+            return 0;
+        }
         if (fmt == 4 && ctx->box_pencil && ctx->opt_box_pencil != 0 && !ctx->use_comm && ctx->opt_box_lds == 0) {
             // format 7: one wavefront per pencil of 128 rows x all planes of the slowest species
             // (3 workgroups per CU: measured best on the 22^6 box and its slab - 768: 798 / 77.7 us, 512: 866 / 84, 1024: 936 / 86,
@@ -1368,6 +1382,24 @@ int kfsp_set_matrix_box(kfsp_ctx *ctx, int32_t ns, const int32_t *dims, int32_t 
             for (int k = 0; k < nr; ++k)
                 if (dep_species[(size_t)k * kfsp::kBoxMaxDep] != Ls && stoich[(size_t)k * ns + Ls] != 0) simple = false;
             ctx->pencil_simple = simple;
+            // Format 8 (slabs): additionally the lines of the second-slowest species have an even number of rows, there are at
+            // least two of them, and at least 256 workgroups' worth of slabs (or the option insists)
+            ctx->box_slab = false;
+            if (ok && ns >= 3) {
+                int64_t line = 1;
+                for (int s = 0; s < Ls - 1; ++s) line *= dims[s];
+                const int lines = dims[Ls - 1];
+                const int groups = (lines + 11) / 12, waves = (lines + groups - 1) / groups;     // (<= 12 wavefronts per workgroup)
+                const int64_t lo_trips = (line + 127) / 128;
+                if (line % 2 == 0 && lines >= 2 && (lo_trips * groups >= 256 || ctx->opt_box_pencil == 2)) {
+                    ctx->box_slab = true;
+                    ctx->slab_line_rows = line;
+                    ctx->slab_lines = lines;
+                    ctx->slab_groups = groups;
+                    ctx->slab_waves = waves;
+                    ctx->slab_lo_trips = lo_trips;
+                }
+            }
             if (ok) {
                 ctx->box_pencil = true;
                 ctx->pencil_plane_rows = plane;
@@ -1520,7 +1552,8 @@ int kfsp_layout_info(const kfsp_ctx *ctx, int64_t *v)
     if (!v) return -2;
     if (ctx->group) return kfsp::group_layout_info(ctx, v);
     v[0] = ctx->use_box ? (ctx->box_fast && !ctx->opt_box_generic ? (ctx->box_reach > 0 && ctx->opt_box_lds && !ctx->use_comm ? 6 :
-                           (ctx->box_pencil && ctx->opt_box_pencil != 0 && !ctx->use_comm ? 7 : 4)) : 3) : ctx->use_dia ? (ctx->dia_masked ? 2 : 1) : (ctx->sell_coded ? 5 : 0);
+                           (ctx->box_slab && ctx->opt_box_pencil != 0 && ctx->opt_box_pencil != 1 && !ctx->use_comm ? 8 :
+                            ctx->box_pencil && ctx->opt_box_pencil != 0 && !ctx->use_comm ? 7 : 4)) : 3) : ctx->use_dia ? (ctx->dia_masked ? 2 : 1) : (ctx->sell_coded ? 5 : 0);
     v[1] = !ctx->use_comm ? 0 : (ctx->use_halo ? 1 : 2);
     v[2] = ctx->halo;
     v[3] = ctx->use_dia ? -1 : ctx->sell_reach;

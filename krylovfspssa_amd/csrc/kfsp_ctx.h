@@ -215,6 +215,10 @@ struct kfsp_ctx {
     // format 7 (pencils along the slowest species, kfsp_kernels.hip): eligible box, rows per plane, planes, base trips
     // (= ceil(rows per plane / 128)) and their tiled order (0 entries: ascending)
     bool box_pencil = false, pencil_simple = false;
+    // format 8 (slabs): rows per line of the second-slowest species, lines, wavefronts per workgroup, workgroups per line set
+    bool box_slab = false;
+    int64_t slab_line_rows = 0, slab_lo_trips = 0;
+    int slab_lines = 0, slab_waves = 0, slab_groups = 0;
     int64_t pencil_plane_rows = 0, pencil_trips = 0, pencil_order_n = 0;
     int pencil_planes = 0;
     DevBuf<int32_t> d_pencil_order;
@@ -314,7 +318,8 @@ struct kfsp_ctx {
     int64_t opt_small_lds = 1;            // 0: the one-launch Arnoldi kernel reads the generator from global memory
     int64_t lds_per_block = 65536;        // device limit (hipDeviceAttributeMaxSharedMemoryPerBlock)
     int64_t opt_dia_mask = 1;             // 0: never skip empty diagonal segments
-    int64_t opt_box_pencil = -1;          // matrix-free boxes as pencils along the slowest species (format 7): -1 where eligible, 0 never
+    int64_t opt_box_pencil = -1;          // matrix-free boxes in pencils along the slowest species: -1 slabs (format 8) / pencils (format 7) where
+                                          // eligible, 0 never, 1 pencils whatever the size, 2 slabs whatever the size
     int64_t opt_box_tile = -1;            // tiled trip order of box generators: -1 when the box outgrows the caches, 0 never, 1 always
     int64_t opt_box_lds = 0;              // 1: the single-factor matrix-free product stages the near part of x in LDS (format 6;
                                           // measured slower than format 4 on every box: DESIGN.md 4.1b - off by default)

@@ -234,6 +234,9 @@ void launch_spmv(int mode, int grid, const SpmvArgs &a, bool nontemporal, int fm
 // format 6: the single-factor matrix-free product with the near part of x staged in LDS (reach rows on either side of a
 // workgroup's 512; lds_bytes = table image + two windows)
 void launch_spmv_boxlds(int mode, int grid, const SpmvArgs &a, hipStream_t s, size_t lds_bytes, int reach);
+// format 8: a workgroup's wavefronts walk the pencils of consecutive lines of the second-slowest species in step (k_spmv_slab)
+void launch_spmv_slab(int mode, int grid, int waves, const SpmvArgs &a, hipStream_t s, size_t lds_bytes, int64_t plane_rows, int planes,
+                      int64_t line_rows, int lines, int groups, int64_t lo_trips, bool simple);
 // format 7: a wavefront walks the planes of the slowest species (kfsp_kernels.hip, k_spmv_pencil)
 void launch_spmv_pencil(int mode, int grid, const SpmvArgs &a, hipStream_t s, size_t lds_bytes, int64_t plane_rows, int planes,
                         int64_t base_trips, const int32_t *order, bool simple);

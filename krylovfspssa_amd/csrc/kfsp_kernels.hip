@@ -1361,6 +1361,309 @@ __global__ __launch_bounds__(kBlock) void k_spmv_pencil(SpmvArgs a, int64_t plan
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Format 8 (round 4): pencils in SLABS.  Format 7 removed the slowest species' streams; what was left of the traffic on the
+// 6-species boxes was the SECOND-slowest species (22^4 rows = 1.9 MB away: the L2 does not hold it across a pencil's 41 MB
+// steps).  Here a WORKGROUP owns the same 128 rows (of the index below the second-slowest stride) in W consecutive lines of
+// that species - wavefront w walks the pencil of line g W + w - and all its wavefronts take the planes in step, one
+// workgroup barrier per step: the second-slowest species' own +-1 entries are then the pair wavefront w -+ 1 holds for the
+// same plane, handed over through LDS (16 bytes per lane, two buffers).  Only the first and the last line of a workgroup
+// gather such a neighbour from memory (22 lines in two workgroups of 11: 2 of 44 neighbour pairs).  Everything else is
+// format 7: invariants hoisted out of the walk, the slowest species' entries from the lane's own previous / next pair.
+// Same fused multiply-adds over the same operands: bit-identical products.
+template <int MODE, int NS, int PER, bool SIMPLE>
+__global__ __launch_bounds__(768) void k_spmv_slab(SpmvArgs a, int64_t plane_rows, int planes, int64_t line_rows, int lines, int groups,
+                                                    int64_t lo_trips)
+{
+    constexpr int L = NS - 1;                       // the slowest species: planes
+    constexpr int M = NS - 2;                       // the second slowest: lines
+    constexpr int NE = M * PER;                     // entries of the species below them: always gathered from memory
+    __shared__ double red[12];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int W = (int)(blockDim.x >> 6);
+    if (MODE != 0) {
+        if (*a.brk_flag) return;
+    }
+    for (int i = threadIdx.x; i < a.B.ntab; i += blockDim.x) box_lds[i] = a.box_tab[i];
+    __syncthreads();
+    BoxRegs<NS, PER> R;
+    box_load(a.box_fast, R);
+    // the exchange area behind the table image: two buffers of W x 64 pairs
+    box_pair_t *xchg = reinterpret_cast<box_pair_t *>(box_lds + ((a.B.ntab + 1) & ~1));
+    double s = 1.0;
+    if (MODE != 0) {
+        // (finish_sum for a workgroup of W wavefronts: the first four sum the partials exactly as the 256-thread kernels do)
+        double t = 0.0;
+        if (threadIdx.x < kBlock)
+            for (int i = threadIdx.x; i < a.sq.n; i += kBlock) t += a.sq.p[i];
+        t = wave_allreduce_sum(t);
+        if (lane == 0 && wave < 4) red[wave] = t;
+        __syncthreads();
+        const double S = (red[0] + red[1]) + (red[2] + red[3]);
+        __syncthreads();
+        const double nrm = sqrt(S);
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            if (a.sq_final) *a.sq_final = S;
+            if (a.h_sub) *a.h_sub = nrm;
+        }
+        if (a.break_tol >= 0.0 && !(nrm > a.break_tol)) {   // happy breakdown :249
+            if (blockIdx.x == 0 && threadIdx.x == 0) *a.brk_flag = 1;
+            return;
+        }
+        s = 1.0 / nrm;
+    }
+    const lds_bytes_t lds = (lds_bytes_t)box_lds;
+    const unsigned lds0 = (unsigned)(size_t)lds;
+    const int64_t plane_bytes = plane_rows * 8, line_bytes = line_rows * 8;
+    const int64_t total = lo_trips * groups;
+    double acc = 0.0, acc2 = 0.0;
+    for (int64_t b = blockIdx.x; b < total; b += gridDim.x) {
+        const int g = (int)(b % groups);
+        const int64_t ct = b / groups;
+        const int sl = g * W + wave;                               // this wavefront's line
+        const int64_t r0 = (ct << 7) + 2 * lane;                   // the lane's rows r0, r0 + 1 of the line (line_rows is even)
+        const bool live = sl < lines && r0 < line_rows;
+        int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+        double dsa0 = 0.0, dsb0 = 0.0;
+        unsigned va0 = 0u, vb0 = 0u;
+        double ta[NE > 0 ? NE : 1], tb[NE > 0 ? NE : 1];
+        unsigned off[NE > 0 ? NE : 1];
+        const unsigned voff = (unsigned)(16 * lane + R.bias8);
+#pragma unroll
+        for (int e = 0; e < (NE > 0 ? NE : 1); ++e) {
+            ta[e] = tb[e] = 0.0;
+            off[e] = voff;
+        }
+        if (live) {
+            uint32_t q = (uint32_t)r0;
+#define KFSP_SLB_DEC(S, VAR)                                             \
+    if (M > S + 1) {                                                     \
+        const int d = R.dims[M > S ? S : 0];                             \
+        uint32_t t = (uint32_t)((double)q * R.inv_dim[M > S ? S : 0]);   \
+        int r = (int)(q - t * (uint32_t)d);                              \
+        const int lo_ = r < 0, hi_ = r >= d;                             \
+        t = t - lo_ + hi_;                                               \
+        r = r + (lo_ ? d : 0) - (hi_ ? d : 0);                           \
+        VAR = r;                                                         \
+        q = t;                                                           \
+    } else if (M == S + 1) {                                             \
+        VAR = (int)q;                                                    \
+    }
+            KFSP_SLB_DEC(0, c0)
+            KFSP_SLB_DEC(1, c1)
+            KFSP_SLB_DEC(2, c2)
+            KFSP_SLB_DEC(3, c3)
+#undef KFSP_SLB_DEC
+            int b0 = c0, b1 = c1, b2 = c2, b3 = c3, carry = 1;
+#define KFSP_SLB_INC(S, VAR)                                             \
+    if (M > S) {                                                         \
+        const int v = VAR + carry;                                       \
+        const int wrap = (M > S + 1) && v >= R.dims[M > S ? S : 0];      \
+        VAR = wrap ? 0 : v;                                              \
+        carry = wrap;                                                    \
+    }
+            KFSP_SLB_INC(0, b0)
+            KFSP_SLB_INC(1, b1)
+            KFSP_SLB_INC(2, b2)
+            KFSP_SLB_INC(3, b3)
+#undef KFSP_SLB_INC
+            {
+                const lds_bytes_t fa = lds + R.df8[0] + 16 * c0, fb = lds + R.df8[0] + 16 * b0;
+                dsa0 = *(const __attribute__((address_space(3))) double *)fa;
+                va0 = *(const __attribute__((address_space(3))) unsigned *)(fa + 8);
+                dsb0 = *(const __attribute__((address_space(3))) double *)fb;
+                vb0 = *(const __attribute__((address_space(3))) unsigned *)(fb + 8);
+            }
+#define KFSP_SLB_DF(S, CA, CB)                                                                       \
+    if (M > S) {                                                                                     \
+        const lds_bytes_t fa = lds + R.df8[M > S ? S : 0] + 16 * CA, fb = lds + R.df8[M > S ? S : 0] + 16 * CB; \
+        dsa0 += *(const __attribute__((address_space(3))) double *)fa;                               \
+        va0 &= *(const __attribute__((address_space(3))) unsigned *)(fa + 8);                        \
+        dsb0 += *(const __attribute__((address_space(3))) double *)fb;                               \
+        vb0 &= *(const __attribute__((address_space(3))) unsigned *)(fb + 8);                        \
+    }
+            KFSP_SLB_DF(1, c1, b1)
+            KFSP_SLB_DF(2, c2, b2)
+            KFSP_SLB_DF(3, c3, b3)
+#undef KFSP_SLB_DF
+            {
+                // the second-slowest species at this wavefront's line: uniform
+                const lds_bytes_t fm = lds + R.df8[M] + 16 * sl;
+                const double dsm = *(const __attribute__((address_space(3))) double *)fm;
+                const unsigned vm = *(const __attribute__((address_space(3))) unsigned *)(fm + 8);
+                dsa0 += dsm;
+                dsb0 += dsm;
+                va0 &= vm;
+                vb0 &= vm;
+            }
+#define KFSP_SLB_ENT(S, CA, CB)                                                                      \
+    if (M > S) {                                                                                     \
+        _Pragma("unroll") for (int j = 0; j < PER; ++j) {                                            \
+            constexpr int e = (M > S ? S : 0) * PER;                                                 \
+            const int ma = __builtin_amdgcn_sbfe(va0, e + j, 1), mb = __builtin_amdgcn_sbfe(vb0, e + j, 1); \
+            const unsigned ata = lds0 + (unsigned)(8 * CA + R.koff8[M > S ? S : 0][j]);              \
+            const unsigned atb = lds0 + (unsigned)(8 * CB + R.koff8[M > S ? S : 0][j]);              \
+            ta[e + j] = *(const __attribute__((address_space(3))) double *)(size_t)((ma & ata) | (~ma & lds0)); \
+            tb[e + j] = *(const __attribute__((address_space(3))) double *)(size_t)((mb & atb) | (~mb & lds0)); \
+            off[e + j] = (ma | mb) ? voff + (unsigned)R.delta8[M > S ? S : 0][j] : voff;             \
+        }                                                                                            \
+    }
+            KFSP_SLB_ENT(0, c0, b0)
+            KFSP_SLB_ENT(1, c1, b1)
+            KFSP_SLB_ENT(2, c2, b2)
+            KFSP_SLB_ENT(3, c3, b3)
+#undef KFSP_SLB_ENT
+        }
+        // ---- the walk over the planes, all wavefronts of the workgroup in step
+        uint64_t xb = reinterpret_cast<uint64_t>(a.xg + (int64_t)(sl < lines ? sl : 0) * line_rows + (ct << 7)) - (uint64_t)(int64_t)R.bias8;
+        box_pair_t xprev = {0.0, 0.0}, xcur = {0.0, 0.0}, xnext = {0.0, 0.0};
+        if (live) {
+            const global_bytes_t xw = (global_bytes_t)((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)xb) |
+                                                       (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(xb >> 32)) << 32);
+            xcur = *(const __attribute__((address_space(1), aligned(8))) box_pair_t *)(xw + voff);
+        }
+        int64_t row = (int64_t)sl * line_rows + r0;
+        for (int p = 0; p < planes; ++p) {
+            box_pair_t *buf = xchg + (size_t)(p & 1) * (size_t)W * 64;
+            buf[wave * 64 + lane] = xcur;
+            __syncthreads();
+            if (live) {
+                const global_bytes_t xw = (global_bytes_t)((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)xb) |
+                                                           (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(xb >> 32)) << 32);
+                if (p + 1 < planes) xnext = *(const __attribute__((address_space(1), aligned(8))) box_pair_t *)(xw + plane_bytes + voff);
+                const lds_bytes_t fl = lds + R.df8[L] + 16 * p;
+                const double dsl = *(const __attribute__((address_space(3))) double *)fl;
+                const unsigned vl = *(const __attribute__((address_space(3))) unsigned *)(fl + 8);
+                double acca = 0.0, accb = 0.0;
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    if (SIMPLE) {
+                        const box_pair_t xv = *(const __attribute__((address_space(1), aligned(8))) box_pair_t *)(xw + off[e]);
+                        acca += ta[e] * xv.x;
+                        accb += tb[e] * xv.y;
+                    } else {
+                        const bool here = (vl >> e) & 1u;
+                        const box_pair_t xv = *(const __attribute__((address_space(1), aligned(8))) box_pair_t *)(xw + (here ? off[e] : voff));
+                        acca += (here ? ta[e] : 0.0) * xv.x;
+                        accb += (here ? tb[e] : 0.0) * xv.y;
+                    }
+                }
+                // the second-slowest species' entries: its population is this wavefront's line, so the table value is uniform;
+                // an entry that moves only this species by one reads the pair of the wavefront one line down / up - from LDS
+                // when that line is in this workgroup, else from memory (as format 4 does for every entry)
+#pragma unroll
+                for (int j = 0; j < PER; ++j) {
+                    const int ma = __builtin_amdgcn_sbfe(va0 & vl, M * PER + j, 1), mb = __builtin_amdgcn_sbfe(vb0 & vl, M * PER + j, 1);
+                    const unsigned at = lds0 + (unsigned)(8 * sl + R.koff8[M][j]);
+                    const double a1a = *(const __attribute__((address_space(3))) double *)(size_t)((ma & at) | (~ma & lds0));
+                    const double a1b = *(const __attribute__((address_space(3))) double *)(size_t)((mb & at) | (~mb & lds0));
+                    const int d = R.delta8[M][j];
+                    box_pair_t xv;
+                    if ((int64_t)d == line_bytes && wave + 1 < W) xv = buf[(wave + 1) * 64 + lane];
+                    else if ((int64_t)d == -line_bytes && wave > 0) xv = buf[(wave - 1) * 64 + lane];
+                    else xv = *(const __attribute__((address_space(1), aligned(8))) box_pair_t *)(xw + ((ma | mb) ? voff + (unsigned)d : voff));
+                    if (!(ma | mb)) xv = xcur;
+                    acca += a1a * xv.x;
+                    accb += a1b * xv.y;
+                }
+#pragma unroll
+                for (int j = 0; j < PER; ++j) {
+                    const int ma = __builtin_amdgcn_sbfe(va0 & vl, L * PER + j, 1), mb = __builtin_amdgcn_sbfe(vb0 & vl, L * PER + j, 1);
+                    const unsigned at = lds0 + (unsigned)(8 * p + R.koff8[L][j]);
+                    const double a1a = *(const __attribute__((address_space(3))) double *)(size_t)((ma & at) | (~ma & lds0));
+                    const double a1b = *(const __attribute__((address_space(3))) double *)(size_t)((mb & at) | (~mb & lds0));
+                    const int d = R.delta8[L][j];
+                    box_pair_t xv;
+                    if ((int64_t)d == plane_bytes) xv = xnext;
+                    else if ((int64_t)d == -plane_bytes) xv = xprev;
+                    else xv = *(const __attribute__((address_space(1), aligned(8))) box_pair_t *)(xw + ((ma | mb) ? voff + (unsigned)d : voff));
+                    if (!(ma | mb)) xv = xcur;
+                    acca += a1a * xv.x;
+                    accb += a1b * xv.y;
+                }
+                d2 sum;
+                sum.x = acca - (dsa0 + dsl) * xcur.x;
+                sum.y = accb - (dsb0 + dsl) * xcur.y;
+                if (MODE != 0) {
+                    sum.x *= s;
+                    sum.y *= s;
+                }
+                *reinterpret_cast<d2 *>(a.y + row) = sum;
+                if (MODE == 1 || MODE == 3) {
+                    const d2 u = *reinterpret_cast<const d2 *>(a.udot + row);
+                    acc += u.x * sum.x;
+                    acc += u.y * sum.y;
+                }
+                if (MODE == 2) {
+                    acc += sum.x * sum.x;
+                    acc += sum.y * sum.y;
+                }
+                if (MODE == 3) {
+                    const d2 u = *reinterpret_cast<const d2 *>(a.udot2 + row);
+                    acc2 += u.x * sum.x;
+                    acc2 += u.y * sum.y;
+                }
+                xprev = xcur;
+                xcur = xnext;
+            }
+            xb += (uint64_t)plane_bytes;
+            row += plane_rows;
+        }
+        __syncthreads();                        // (the next slab's first step writes the buffer the last step may still be read from)
+    }
+    if (MODE != 0) {
+        // W wavefront sums, added in wavefront order by every thread: one partial per workgroup
+        __shared__ double wred[2 * 16];   // (W <= 12)
+        acc = wave_allreduce_sum(acc);
+        acc2 = wave_allreduce_sum(acc2);
+        if (lane == 0) {
+            wred[wave] = acc;
+            wred[16 + wave] = acc2;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0, t2 = 0.0;
+            for (int w = 0; w < W; ++w) {
+                t += wred[w];
+                t2 += wred[16 + w];
+            }
+            a.partial[blockIdx.x] = t;
+            if (MODE == 3) a.partial2[blockIdx.x] = t2;
+        }
+    }
+}
+
+template <int NS, int NE, bool SIMPLE>
+static void launch_slab_mode(int mode, dim3 g, dim3 b, const SpmvArgs &a, hipStream_t st, size_t lds, int64_t plane_rows, int planes,
+                             int64_t line_rows, int lines, int groups, int64_t lo_trips)
+{
+    if (mode == 0) hipLaunchKernelGGL((k_spmv_slab<0, NS, NE, SIMPLE>), g, b, lds, st, a, plane_rows, planes, line_rows, lines, groups, lo_trips);
+    else if (mode == 1) hipLaunchKernelGGL((k_spmv_slab<1, NS, NE, SIMPLE>), g, b, lds, st, a, plane_rows, planes, line_rows, lines, groups, lo_trips);
+    else if (mode == 2) hipLaunchKernelGGL((k_spmv_slab<2, NS, NE, SIMPLE>), g, b, lds, st, a, plane_rows, planes, line_rows, lines, groups, lo_trips);
+    else hipLaunchKernelGGL((k_spmv_slab<3, NS, NE, SIMPLE>), g, b, lds, st, a, plane_rows, planes, line_rows, lines, groups, lo_trips);
+}
+
+// format 8: waves = wavefronts per workgroup (<= 12: three per SIMD, 170 vector registers each); lds_bytes = table image (rounded to 16 B) + 2 x waves x 1 KB
+void launch_spmv_slab(int mode, int grid, int waves, const SpmvArgs &a, hipStream_t st, size_t lds_bytes, int64_t plane_rows, int planes,
+                      int64_t line_rows, int lines, int groups, int64_t lo_trips, bool simple)
+{
+    dim3 g(grid), b(64 * waves);
+    if (simple) {
+        switch (a.B.pad) {
+        case 3 * 16 + 2: launch_slab_mode<3, 2, true>(mode, g, b, a, st, lds_bytes, plane_rows, planes, line_rows, lines, groups, lo_trips); break;
+        case 6 * 16 + 2: launch_slab_mode<6, 2, true>(mode, g, b, a, st, lds_bytes, plane_rows, planes, line_rows, lines, groups, lo_trips); break;
+        default: launch_slab_mode<6, 4, true>(mode, g, b, a, st, lds_bytes, plane_rows, planes, line_rows, lines, groups, lo_trips); break;
+        }
+        return;
+    }
+    switch (a.B.pad) {
+    case 3 * 16 + 2: launch_slab_mode<3, 2, false>(mode, g, b, a, st, lds_bytes, plane_rows, planes, line_rows, lines, groups, lo_trips); break;
+    case 6 * 16 + 2: launch_slab_mode<6, 2, false>(mode, g, b, a, st, lds_bytes, plane_rows, planes, line_rows, lines, groups, lo_trips); break;
+    default: launch_slab_mode<6, 4, false>(mode, g, b, a, st, lds_bytes, plane_rows, planes, line_rows, lines, groups, lo_trips); break;
+    }
+}
+
 template <int NS, int NE, bool SIMPLE>
 static void launch_pencil_mode(int mode, dim3 g, dim3 b, const SpmvArgs &a, hipStream_t st, size_t lds, int64_t plane_rows, int planes,
                                int64_t base_trips, const int32_t *order)

@@ -14,6 +14,8 @@ x = np.random.default_rng(1).random(mdl.n)
 y0 = None
 cases = [(0, 0, 1024), (-1, 0, 1024), (-1, -1, 1024), (-1, -1, 512), (-1, -1, 768), (-1, -1, 1280), (-1, -1, 1536),
          (-1, -1, 2048), (-1, 0, 1280), (-1, 0, 2048)]
+if "slab" in sys.argv:
+    cases = [(0, 0, 1024), (1, 0, 768), (2, 0, 0), (2, 0, 256), (2, 0, 512), (-1, -1, 0)]
 if "fine" in sys.argv:
     cases = [(0, 0, 1024)] + [(-1, 0, g) for g in (576, 640, 704, 768, 832, 896, 960)] + [(-1, -1, 768)]
 for pencil, tile, grid in cases:
@@ -21,7 +23,8 @@ for pencil, tile, grid in cases:
         c.set_option("m_max", 8)
         c.set_option("box_pencil", pencil)
         c.set_option("box_tile", tile)
-        c.set_option("grid_blocks", grid)
+        if grid:
+            c.set_option("grid_blocks", grid)
         c.set_matrix_box(mdl, store=False)
         c.set_vector(x)
         c.begin_step()

@@ -27,9 +27,9 @@ for r in f:
         cal.setdefault(width, []).append(float(r["Counter_Value"]))
 factor = sum((2 << 30) / (med(v) * 1024.0) for v in cal.values()) / len(cal)
 print(f"FETCH_SIZE calibration factor {factor:.4f} (2 GiB reads at {sorted(cal)} B per lane)")
-fs = [float(r["Counter_Value"]) for r in f if ("k_spmv<0" in r["Kernel_Name"] or "k_spmv_pencil<0" in r["Kernel_Name"])]
-ws = [float(r["Counter_Value"]) for r in w if ("k_spmv<0" in r["Kernel_Name"] or "k_spmv_pencil<0" in r["Kernel_Name"])]
-names = [r["Kernel_Name"][:60] for r in f if ("k_spmv<0" in r["Kernel_Name"] or "k_spmv_pencil<0" in r["Kernel_Name"])]
+fs = [float(r["Counter_Value"]) for r in f if ("k_spmv<0" in r["Kernel_Name"] or "k_spmv_pencil<0" in r["Kernel_Name"] or "k_spmv_slab<0" in r["Kernel_Name"])]
+ws = [float(r["Counter_Value"]) for r in w if ("k_spmv<0" in r["Kernel_Name"] or "k_spmv_pencil<0" in r["Kernel_Name"] or "k_spmv_slab<0" in r["Kernel_Name"])]
+names = [r["Kernel_Name"][:60] for r in f if ("k_spmv<0" in r["Kernel_Name"] or "k_spmv_pencil<0" in r["Kernel_Name"] or "k_spmv_slab<0" in r["Kernel_Name"])]
 timing = {}
 for line in open(tlog):
     m = re.match(r"CASE (\S+) n=(\d+) ms=(\S+) real_bytes=(\d+)", line)

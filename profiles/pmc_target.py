@@ -87,10 +87,10 @@ for case in cases:
     else:
         mdl = box(workload)
         n = mdl.n
-        if form in ("mf", "mf4", "mf6", "mf6r2"):
-            ctx.set_option("box_pencil", 0 if form == "mf4" else -1)   # mf4: format 4 also where round 4's pencils (format 7) apply
+        if form in ("mf", "mf4", "mf7", "mf6", "mf6r2"):
+            ctx.set_option("box_pencil", {"mf4": 0, "mf7": 1}.get(form, -1))   # mf7: pencils per wavefront (format 7); mf: slabs (format 8) where eligible   # mf4: format 4 also where round 4's pencils (format 7) apply
             ctx.set_option("box_tile", 0 if form == "mf4" and tile is None else -1)
-            ctx.set_option("box_lds", 0 if form in ("mf", "mf4") else 1)   # mf6: the near part of x staged in LDS (format 6)
+            ctx.set_option("box_lds", 0 if form in ("mf", "mf4", "mf7") else 1)   # mf6: the near part of x staged in LDS (format 6)
             ctx.set_option("box_reach", 2 if form == "mf6r2" else 512)
             ctx.set_matrix_box(mdl, store=False)
         elif form == "stored":

@@ -284,9 +284,14 @@ def test_matrix_free_random_boxes_with_a_row_partition(oracle, P):
 
 
 @pytest.mark.parametrize("name,dims", [("repressilator", (31, 24, 19)), ("repressilator", (16, 64, 7)), ("birth_death6", (5, 6, 4, 5, 4, 7)),
-                                       ("birth_death6", (8, 4, 4, 4, 4, 2)), ("birth_death4", (12, 9, 10, 6))])
+                                       ("birth_death6", (8, 4, 4, 4, 4, 2)), ("birth_death4", (12, 9, 10, 6)),
+                                       ("birth_death6", (6, 4, 3, 2, 22, 3)), ("birth_death6", (4, 4, 4, 2, 13, 2)),
+                                       ("repressilator", (10, 29, 5))])
 def test_pencil_product_equals_the_trip_product_bit_for_bit(oracle, name, dims):
-    """Kernel format 7 (option box_pencil): a wavefront owns 128 rows of one plane of the slowest species and walks the planes;
+    """Kernel formats 7 and 8 (option box_pencil = 1 / 2).  Format 8 (the default for large boxes): a WORKGROUP owns 128 rows in W
+    consecutive lines of the second-slowest species, its wavefronts walk the planes in step and hand each other their own pairs
+    through LDS (that species' +-1 entries); lines that are no multiple of the workgroup, workgroups at the box's edge and group
+    boundaries (memory gathers there) are in the cases below.  Format 7: a wavefront owns 128 rows of one plane of the slowest species and walks the planes;
     the slowest species' own entries take their source elements from the lane's previous / next pair (registers) and everything
     that depends on the other coordinates is worked out once per pencil.  Every row is the same sequence of fused multiply-adds
     over the same operands as in format 4: y must be bit-identical (here box_pencil = 1 forces it on small boxes; by default it
@@ -303,13 +308,13 @@ def test_pencil_product_equals_the_trip_product_bit_for_bit(oracle, name, dims):
     p0 /= p0.sum()
     m, tau, nsteps = 14, 0.004, 2
     out = {}
-    for pencil in (0, 1):
+    for pencil in (0, 1, 2):                                      # format 4 / pencils (format 7) / pencils in slabs (format 8)
         with KfspContext(0) as c:
             c.set_option("small_kernel", 0)
             c.set_option("box_pencil", pencil)
             c.set_matrix_box(mdl)
             fmt = c.layout_info()["format"]
-            assert fmt == (7 if pencil and len(dims) in (3, 6) else 4), (fmt, pencil)
+            assert fmt == ({1: 7, 2: 8}[pencil] if pencil and len(dims) in (3, 6) else 4), (fmt, pencil)
             y = c.spmv(x)
             c.set_vector(p0)
             c.begin_step()
@@ -317,7 +322,7 @@ def test_pencil_product_equals_the_trip_product_bit_for_bit(oracle, name, dims):
             c.set_vector(p0)
             ws = c.expv_fixed(m, tau, nsteps)
             out[pencil] = dict(y=y, H=H.copy(), mb=mb, k1=k1, ws=ws, w=c.get_vector())
-    assert np.array_equal(out[0]["y"], out[1]["y"])
+    assert np.array_equal(out[0]["y"], out[1]["y"]) and np.array_equal(out[0]["y"], out[2]["y"])
     scale = oracle.spmv_ell(oracle.EllMatrix(adj, np.abs(off), -np.abs(diag)), np.abs(x))
     assert np.all(np.abs(out[1]["y"] - oracle.spmv_ell(A, x)) <= 1e-13 * np.abs(scale) + 1e-300)
     wref, wsref = oracle.expv_fixed(A, p0, m, tau, nsteps)
