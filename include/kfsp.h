@@ -183,7 +183,7 @@ int kfsp_matrix_bytes(const kfsp_ctx *ctx, int force_sell, int64_t *bytes);
 /* what the device holds and how a partitioned product exchanges its source vector, v[8]:
  *   v[0] kernel format: 0 SELL-64, 1 banded, 2 banded with group masks, 3 / 4 matrix-free box (interpreted / fast path),
  *        5 SELL-64 with dictionary-coded columns (option "sell_code"), 6 matrix-free fast path with the near part of x in LDS,
- *        7 matrix-free fast path in pencils along the slowest species (option "box_pencil")
+ *        7 matrix-free fast path in pencils along the slowest species (option "box_pencil"), 8 the same in slabs (box_pencil = 2)
  *   v[1] exchange: 0 none (no communicator), 1 halo strips, 2 all-gather of the whole vector;  v[2] halo rows
  *   v[3] reach max |col - row| of the local SELL rows (-1: not a SELL generator)
  *   v[4] chunks with coded columns, v[5] chunks, v[6] 64-bit code words, v[7] internal state order active */
@@ -559,7 +559,9 @@ int kfsp_add_timer(kfsp_ctx *ctx, int phase, double ms);
  * raising it and calling kfsp_arnoldi with the larger m before a new generator returns -2; kfsp_dgexpv needs the default), "box_store" (1: kfsp_set_matrix_box stores the generator as diagonals), "box_pencil" (-1, default: a matrix-free box whose slowest species is
  * coupled only through its own +-1 entries is multiplied PENCIL by PENCIL - a wavefront owns 128 rows of one plane of that species and
  * walks the planes, so that those entries' sources are the lane's own previous / next elements and everything that depends on the other
- * coordinates is worked out once per pencil; kernel format 7, products bit-identical to format 4; 0: never), "box_tile" (the order in which
+ * coordinates is worked out once per pencil; kernel format 7, products bit-identical to format 4; 0: never; 1: also on small boxes; 2: pencils in SLABS, format 8 - a workgroup's
+ * wavefronts walk the lines of the second-slowest species in step and exchange their pairs through LDS: less traffic, bit-identical, but
+ * measured slower than format 7 - one workgroup barrier per step at 11 wavefronts per CU - and therefore never chosen automatically), "box_tile" (the order in which
  * products over a box take their 128-row trips: -1, default: tiled - blocks of 1024 rows below a stride of at most 16 K rows, per
  * block every slower line back to back - when neither the vector nor the windows of its far strides fit the 256 MiB Infinity
  * Cache (22^6: 14 % faster), ascending otherwise; 0 always ascending; 1 always tiled; same bits either way), "box_generic" (1: matrix-free boxes take

@@ -331,7 +331,7 @@ int run_product(kfsp_ctx *ctx, int mode, SpmvArgs a, const double *src, bool src
         a.trip_jump = 0;
         a.trip_order = (ctx->trip_order_n == trips && !force_sell) ? ctx->d_trip_order.p : nullptr;
         const int g = trips_grid(trips, cap);
-        if (fmt == 4 && ctx->box_slab && ctx->opt_box_pencil != 0 && ctx->opt_box_pencil != 1 && !ctx->use_comm && ctx->opt_box_lds == 0) {
+        if (fmt == 4 && ctx->box_slab && ctx->opt_box_pencil == 2 && !ctx->use_comm && ctx->opt_box_lds == 0) {
             // format 8: one workgroup per 128 rows x W lines of the second-slowest species, walking the planes in step
             const int64_t total = ctx->slab_lo_trips * ctx->slab_groups;
             const size_t lds = ((ctx->box_lds_bytes + 15) & ~(size_t)15) + 2 * (size_t)ctx->slab_waves * 1024;
@@ -1552,7 +1552,7 @@ int kfsp_layout_info(const kfsp_ctx *ctx, int64_t *v)
     if (!v) return -2;
     if (ctx->group) return kfsp::group_layout_info(ctx, v);
     v[0] = ctx->use_box ? (ctx->box_fast && !ctx->opt_box_generic ? (ctx->box_reach > 0 && ctx->opt_box_lds && !ctx->use_comm ? 6 :
-                           (ctx->box_slab && ctx->opt_box_pencil != 0 && ctx->opt_box_pencil != 1 && !ctx->use_comm ? 8 :
+                           (ctx->box_slab && ctx->opt_box_pencil == 2 && !ctx->use_comm ? 8 :
                             ctx->box_pencil && ctx->opt_box_pencil != 0 && !ctx->use_comm ? 7 : 4)) : 3) : ctx->use_dia ? (ctx->dia_masked ? 2 : 1) : (ctx->sell_coded ? 5 : 0);
     v[1] = !ctx->use_comm ? 0 : (ctx->use_halo ? 1 : 2);
     v[2] = ctx->halo;

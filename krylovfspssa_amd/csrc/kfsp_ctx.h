@@ -318,8 +318,8 @@ struct kfsp_ctx {
     int64_t opt_small_lds = 1;            // 0: the one-launch Arnoldi kernel reads the generator from global memory
     int64_t lds_per_block = 65536;        // device limit (hipDeviceAttributeMaxSharedMemoryPerBlock)
     int64_t opt_dia_mask = 1;             // 0: never skip empty diagonal segments
-    int64_t opt_box_pencil = -1;          // matrix-free boxes in pencils along the slowest species: -1 slabs (format 8) / pencils (format 7) where
-                                          // eligible, 0 never, 1 pencils whatever the size, 2 slabs whatever the size
+    int64_t opt_box_pencil = -1;          // matrix-free boxes in pencils along the slowest species: -1 pencils (format 7) where eligible and large
+                                          // enough, 0 never, 1 pencils whatever the size, 2 pencils in slabs (format 8: measured slower)
     int64_t opt_box_tile = -1;            // tiled trip order of box generators: -1 when the box outgrows the caches, 0 never, 1 always
     int64_t opt_box_lds = 0;              // 1: the single-factor matrix-free product stages the near part of x in LDS (format 6;
                                           // measured slower than format 4 on every box: DESIGN.md 4.1b - off by default)

@@ -5,7 +5,7 @@ warm-ups in a counter CSV belongs to the k-th case.  With --calib first 3 x k_st
 
     python3 profiles/pmc_target.py [--calib] [--no-time] case [case ...]
     case = workload:form   workload c3 | c3x | c4 | c5s | c5 | fsp (Goutsias ellipsoid, 1.0e7 states, search order)
-                           form     stored | mf (matrix-free: format 7 pencils where eligible, else format 4) | mf4 (format 4, ascending trips) | mf6 / mf6r2 (matrix-free with x staged in LDS, reach 512 / 2: format 6) | sell (plain SELL-64) | coded (SELL-64, coded columns)
+                           form     stored | mf (matrix-free: format 7 pencils where eligible, else format 4) | mf4 (format 4, ascending trips) | mf7 / mf8 (format 7 / format 8 forced) | mf6 / mf6r2 (matrix-free with x staged in LDS, reach 512 / 2: format 6) | sell (plain SELL-64) | coded (SELL-64, coded columns)
                                     | sell_search (plain SELL in the caller's search order; fsp only)
 Every case prints one line `CASE <case> n=<states> ms=<per launch> real_bytes=<kfsp_matrix_bytes> info=<layout>`;
 launch markers `MARK <case> <first launch index> 5` count the k_spmv<0,...> launches of this process."""
@@ -87,10 +87,10 @@ for case in cases:
     else:
         mdl = box(workload)
         n = mdl.n
-        if form in ("mf", "mf4", "mf7", "mf6", "mf6r2"):
-            ctx.set_option("box_pencil", {"mf4": 0, "mf7": 1}.get(form, -1))   # mf7: pencils per wavefront (format 7); mf: slabs (format 8) where eligible   # mf4: format 4 also where round 4's pencils (format 7) apply
+        if form in ("mf", "mf4", "mf7", "mf8", "mf6", "mf6r2"):
+            ctx.set_option("box_pencil", {"mf4": 0, "mf7": 1, "mf8": 2}.get(form, -1))   # mf7 / mf8: pencils (format 7) / pencils in slabs (format 8)   # mf4: format 4 also where round 4's pencils (format 7) apply
             ctx.set_option("box_tile", 0 if form == "mf4" and tile is None else -1)
-            ctx.set_option("box_lds", 0 if form in ("mf", "mf4", "mf7") else 1)   # mf6: the near part of x staged in LDS (format 6)
+            ctx.set_option("box_lds", 0 if form in ("mf", "mf4", "mf7", "mf8") else 1)   # mf6: the near part of x staged in LDS (format 6)
             ctx.set_option("box_reach", 2 if form == "mf6r2" else 512)
             ctx.set_matrix_box(mdl, store=False)
         elif form == "stored":

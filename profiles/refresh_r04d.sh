@@ -4,7 +4,7 @@ set -e
 R=$PWD
 O=$R/gpurun_out/r04
 mkdir -p $O
-CASES="${CASES:-c5s:mf4 c5s:mf7 c5s:mf c5:mf4 c5:mf7 c5:mf}"
+CASES="${CASES:-c5s:mf4 c5s:mf c5s:mf8 c5:mf4 c5:mf c5:mf8}"
 python3 profiles/pmc_target.py $CASES > $O/timing_pencil.log 2>&1
 grep -E "CASE" $O/timing_pencil.log | cut -c1-120
 cd /tmp && export TMPDIR=/tmp
