@@ -33,9 +33,15 @@ def test_two_real_ranks_over_rccl(capfd):
     assert rep["halo_p2p"]["bytes_in"] <= rep["halo"]["bytes_in"]
 
 
+# The two tests below have NEVER executed: no multi-GPU box was available in any round.  They are written to pass, but a first
+# run is a first run - they are reported as xfail / xpass instead of turning a suite red that nobody could have checked.
+UNVERIFIED = pytest.mark.xfail(strict=False, reason="first execution on real multi-GPU hardware (RCCL from the threads of a group context)")
+
+
+@UNVERIFIED
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (a group context on distinct devices: RCCL between its ranks)")
 @pytest.mark.parametrize("state_order", [0, 1])
-def test_group_context_on_two_devices(oracle, state_order):
+def test_group_context_on_two_devices(oracle, state_order, monkeypatch):
     """kfsp_create_group(2, [0, 1]): ONE host thread, two worker threads, each initialising its rank of an RCCL
     communicator (ncclCommInitRank from threads of one process) - the form the serial Fortran host uses with
     KFSP_NRANKS=2 KFSP_DEVICES=0,1.  Product, Arnoldi pass, fixed-(m, tau) exp(tA)v of a reference-assembled FSP against
@@ -43,6 +49,8 @@ def test_group_context_on_two_devices(oracle, state_order):
     import numpy as np
     from krylovfspssa_amd import KfspContext
     from tests.conftest import GOLDEN
+    monkeypatch.setenv("KFSP_GROUP_TIMEOUT_S", "120")            # (a first run: a hang must end as an error, not as a stuck suite)
+    monkeypatch.setenv("KFSP_GROUP_GRACE_S", "20")
     a = np.load(os.path.join(GOLDEN, "assembly_goutsias_k16.npz"))
     adj, off, diag, state = a["adj"], a["offdiag"], a["diag"], a["state"]
     n = adj.shape[0]
@@ -80,6 +88,7 @@ def test_group_context_on_two_devices(oracle, state_order):
     assert two["plan"][1:] == one["plan"][1:] and abs(two["plan"][0] - one["plan"][0]) <= 1e-300 + 1e-12 * abs(one["plan"][0])
 
 
+@UNVERIFIED
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (CME_SOLVE over KFSP_DEVICES=0,1)")
 @pytest.mark.parametrize("mode", ["default", "resident"])
 def test_cme_solve_on_two_devices(tmp_path, mode):
@@ -91,7 +100,7 @@ def test_cme_solve_on_two_devices(tmp_path, mode):
     dump = TF.DUMP
     if not os.path.exists(dump):
         pytest.skip("kfsp_dump not built")
-    two = {"KFSP_NRANKS": "2", "KFSP_DEVICES": "0,1", "KFSP_GROUP_GRACE_S": "20"}
+    two = {"KFSP_NRANKS": "2", "KFSP_DEVICES": "0,1", "KFSP_GROUP_GRACE_S": "20", "KFSP_GROUP_TIMEOUT_S": "120"}
     if mode == "default":
         g, d, log = TF._solve(dump, tmp_path, "goutsias_input_T40", "goutsias_input", env=two)
         assert np.array_equal(log["step_n"], g["step_n"]) and np.array_equal(log["step_tau"], g["step_tau"])
