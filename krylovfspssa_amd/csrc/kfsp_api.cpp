@@ -1015,6 +1015,7 @@ int kfsp_comm_init_loopback(kfsp_ctx *ctx, void *group, int rank)
         ctx->comm = nullptr;
     }
     ctx->loop = g;
+    ctx->comm_aborted = false;
     ctx->nranks = g->n;
     ctx->rank = rank;
     ctx->use_comm = true;
