@@ -561,7 +561,7 @@ int kfsp_add_timer(kfsp_ctx *ctx, int phase, double ms);
  * walks the planes, so that those entries' sources are the lane's own previous / next elements and everything that depends on the other
  * coordinates is worked out once per pencil; kernel format 7, products bit-identical to format 4; 0: never; 1: also on small boxes; 2: pencils in SLABS, format 8 - a workgroup's
  * wavefronts walk the lines of the second-slowest species in step and exchange their pairs through LDS: less traffic, bit-identical, but
- * measured slower than format 7 - one workgroup barrier per step at 11 wavefronts per CU - and therefore never chosen automatically), "box_tile" (the order in which
+ * measured slower than format 7 - one workgroup barrier per step at 11 wavefronts per CU - and therefore never chosen automatically; "box_slab_waves" = most lines a workgroup takes, default and maximum 12), "box_tile" (the order in which
  * products over a box take their 128-row trips: -1, default: tiled - blocks of 1024 rows below a stride of at most 16 K rows, per
  * block every slower line back to back - when neither the vector nor the windows of its far strides fit the 256 MiB Infinity
  * Cache (22^6: 14 % faster), ascending otherwise; 0 always ascending; 1 always tiled; same bits either way), "box_generic" (1: matrix-free boxes take

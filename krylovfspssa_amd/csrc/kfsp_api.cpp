@@ -337,7 +337,7 @@ int run_product(kfsp_ctx *ctx, int mode, SpmvArgs a, const double *src, bool src
             const size_t lds = ((ctx->box_lds_bytes + 15) & ~(size_t)15) + 2 * (size_t)ctx->slab_waves * 1024;
             // (workgroups of up to 1024 threads: as many as are resident at once, they loop over the slabs)
             const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(12 / ctx->slab_waves, (int64_t)(160 * 1024) / (int64_t)(lds + 1024)));
-            const int64_t want = ctx->opt_grid > 0 ? ctx->opt_grid : 256 * std::min<int64_t>(per_cu, 2);
+            const int64_t want = ctx->opt_grid > 0 ? ctx->opt_grid : 256 * per_cu;
             const int gs = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(total, want), kMaxGrid));
             launch_spmv_slab(mode, gs, ctx->slab_waves, a, st, lds, ctx->pencil_plane_rows, ctx->pencil_planes, ctx->slab_line_rows,
                              ctx->slab_lines, ctx->slab_groups, ctx->slab_lo_trips, ctx->pencil_simple);
@@ -1390,7 +1390,8 @@ int kfsp_set_matrix_box(kfsp_ctx *ctx, int32_t ns, const int32_t *dims, int32_t 
                 int64_t line = 1;
                 for (int s = 0; s < Ls - 1; ++s) line *= dims[s];
                 const int lines = dims[Ls - 1];
-                const int groups = (lines + 11) / 12, waves = (lines + groups - 1) / groups;     // (<= 12 wavefronts per workgroup)
+                const int wmax = (int)std::max<int64_t>(1, std::min<int64_t>(12, ctx->opt_box_slab_waves));   // (<= 12 wavefronts per workgroup)
+                const int groups = (lines + wmax - 1) / wmax, waves = (lines + groups - 1) / groups;
                 const int64_t lo_trips = (line + 127) / 128;
                 if (line % 2 == 0 && lines >= 2 && (lo_trips * groups >= 256 || ctx->opt_box_pencil == 2)) {
                     ctx->box_slab = true;
@@ -2520,6 +2521,7 @@ int kfsp_set_option(kfsp_ctx *ctx, const char *name, int64_t value)
     else if (k == "box_store") ctx->opt_box_store = value;
     else if (k == "box_tile") ctx->opt_box_tile = value;
     else if (k == "box_pencil") ctx->opt_box_pencil = value;
+    else if (k == "box_slab_waves") ctx->opt_box_slab_waves = value;
     else if (k == "sell_code") ctx->opt_sell_code = value;
     else if (k == "ssa_resident") ctx->opt_ssa_resident = value;
     else if (k == "keep_coords") ctx->opt_keep_coords = value;

@@ -222,9 +222,9 @@ __attribute__((target("avx512f,avx512vl,fma"))) void matmul_dense_avx512(double 
 // step - 19 % of the resident Goutsias run in round 3.  Output columns are independent and every element is the same
 // expression whichever thread makes it, so the columns are dealt to a few threads in groups of four: the bits cannot change
 // (tests/test_padm_bits.py pins them).  The workers spin for a moment after a product (the next one follows at once inside a
-// call), then sleep until the next call.  KFSP_PADE_THREADS sets their number.  DEFAULT 1 (no workers): measured on the
-// MI355X boxes' host at order 102 (profiles/r04_padm_profile.txt) the dense products go 126 -> 81 us with 4 threads, 45 us of a
-// 300 us call, but 516 us with 2 (a worker on a busy core stalls every product) - worth it only on a host with idle cores.
+// call), then sleep until the next call.  KFSP_PADE_THREADS sets their number (default 4 on hosts with >= 16 CPUs, else none).
+// Measured inside the resident Goutsias run on the MI355X boxes' host (profiles/r04_padm_profile.txt): the dense products
+// 355 -> 259 -> 167 ms with 1 / 2 / 4 threads, the whole run 3.03 -> 2.95 -> 2.86 s.
 // The CPUs this process may use, as they were when the library was loaded: by the time a solve runs, the host's OpenMP
 // runtime has bound the calling thread to ONE core (OMP_PROC_BIND=close, fortran/kfsp_statespace.f90) and a thread started
 // from it inherits that mask - four workers spinning on the caller's core turned a 0.65 s Pade share into 11 s
@@ -273,9 +273,10 @@ public:
 private:
     PadePool()
     {
-        int want = 1;                                    // (opt-in: see the comment above the class)
-        if (const char *e = std::getenv("KFSP_PADE_THREADS")) want = std::atoi(e);
+        // (default: 4 threads on a host with >= 16 CPUs - the MI355X boxes give a one-GPU job 16 -, none on a smaller one)
         const int hw = (int)std::thread::hardware_concurrency();
+        int want = hw >= 16 ? 4 : 1;
+        if (const char *e = std::getenv("KFSP_PADE_THREADS")) want = std::atoi(e);
         if (hw > 0) want = std::min(want, std::max(1, hw / 2));
         nthreads_ = std::max(1, std::min(want, 16));
         for (int t = 1; t < nthreads_; ++t) {

@@ -18,9 +18,14 @@ if "slab" in sys.argv:
     cases = [(0, 0, 1024), (1, 0, 768), (2, 0, 0), (2, 0, 256), (2, 0, 512), (-1, -1, 0)]
 if "fine" in sys.argv:
     cases = [(0, 0, 1024)] + [(-1, 0, g) for g in (576, 640, 704, 768, 832, 896, 960)] + [(-1, -1, 768)]
+if "waves" in sys.argv:
+    cases = [(1, 0, 768)] + [(2, w, 0) for w in (2, 3, 4, 6, 8, 11)]          # (second field: box_slab_waves)
 for pencil, tile, grid in cases:
     with KfspContext(0) as c:
         c.set_option("m_max", 8)
+        if "waves" in sys.argv and pencil == 2:
+            c.set_option("box_slab_waves", tile)
+            tile = 0
         c.set_option("box_pencil", pencil)
         c.set_option("box_tile", tile)
         if grid:
