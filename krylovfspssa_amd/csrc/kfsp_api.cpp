@@ -859,6 +859,16 @@ int kfsp_create(int device, kfsp_ctx **out)
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0) return 1000 + (int)(e == hipSuccess ? hipErrorNoDevice : e);
     if (device < 0 || device >= count) return -1;
+    // How the host waits for the device (every pass of the time loop ends in one stream synchronisation: thousands per solve).
+    // KFSP_SYNC=spin / yield / block asks the runtime for that policy; it only takes effect on a device this process has not
+    // used yet, and a runtime that refuses is left alone.
+    if (const char *w = std::getenv("KFSP_SYNC")) {
+        const std::string how(w);
+        const unsigned f = how == "spin" ? hipDeviceScheduleSpin : how == "yield" ? hipDeviceScheduleYield :
+                           how == "block" ? hipDeviceScheduleBlockingSync : hipDeviceScheduleAuto;
+        if (hipSetDevice(device) == hipSuccess) (void)hipSetDeviceFlags(f);
+        (void)hipGetLastError();
+    }
     kfsp_ctx *ctx = new (std::nothrow) kfsp_ctx;
     if (!ctx) return 4001;
     ctx->device = device;
