@@ -188,6 +188,14 @@ int kfsp_matrix_bytes(const kfsp_ctx *ctx, int force_sell, int64_t *bytes);
  *   v[3] reach max |col - row| of the local SELL rows (-1: not a SELL generator)
  *   v[4] chunks with coded columns, v[5] chunks, v[6] 64-bit code words, v[7] internal state order active */
 int kfsp_layout_info(const kfsp_ctx *ctx, int64_t *v);
+/* How the rebuilds of a RESIDENT FSP went (kfsp_expand_resident, kfsp_drop_rebuild; option "build_speculate"), v[6]:
+ *   v[0] generators built without stopping for the link statistics and the slot count, v[1] of those (or of the speculative
+ *   state orders before them) repeated the slow way because a check at the end failed - a coordinate range crossed a power of
+ *   two, or the slow path would have stored diagonals, v[2] the last generator built from resident arrays is a SELL one,
+ *   v[3] a key layout is cached for the next state order, v[4] state orders made FROM the previous one - the appended states'
+ *   keys sorted and merged into the kept list, or the list compacted after a drop - instead of sorting every key, v[5] 0.
+ *   A group context answers for its first rank. */
+int kfsp_build_info(const kfsp_ctx *ctx, int64_t *v);
 /* The ORDER in which a product takes its wavefront trips (one trip = 128 consecutive rows of a banded or matrix-free
  * generator, 64 of a SELL one; ntrips = ceil(local rows / that)): position t of the sweep computes trip order[t].  Rows
  * are independent (FMATVEC as a row gather), so y does not depend on the order - bits included; what changes is which rows
@@ -569,7 +577,12 @@ int kfsp_add_timer(kfsp_ctx *ctx, int phase, double ms);
  * kfsp_set_state_coords, the default; 0: never), "state_order_min" (smallest generator that is
  * reordered, default 32768), "state_order_products" (products the previous
  * generator must have seen, default 48), "sell_sigma" (rows per window in which the internal order puts the longest
- * rows first, >= 128; default 0: plain lexicographic order) ... see DESIGN.md */
+ * rows first, >= 128; default 0: plain lexicographic order), "build_speculate" (1, default: a resident FSP is re-ordered and its
+ * generator rebuilt with ONE host synchronisation instead of five - the key layout of the last order and the SELL form of the last
+ * generator are assumed, the entry arrays reserved for their bound, everything checked at the end and repeated the slow way when
+ * it did not hold (kfsp_build_info); the order itself is carried over - appended keys merged in, dropped ones compacted out -
+ * instead of sorted anew; and rows of at most 16 entries are put into FMATVEC's order by ranking them in registers;
+ * 0: every number is waited for, rows are insertion-sorted in memory; same generator, bit for bit, either way) ... see DESIGN.md */
 int kfsp_set_option(kfsp_ctx *ctx, const char *name, int64_t value);
 
 #ifdef __cplusplus

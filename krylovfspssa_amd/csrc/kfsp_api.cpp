@@ -775,7 +775,8 @@ int adopt_pending_vector(kfsp_ctx *ctx)
         kfsp::launch_gather_index(ctx->n, ctx->d_perm.p, ctx->d_tmp.p, ctx->d_w.p, ctx->stream);
     else
         HIP_TRY(hipMemcpyAsync(ctx->d_w.p, ctx->d_tmp.p, (size_t)ctx->n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    // (one context works on one stream: whatever reads the vector next is ordered behind this)
+    if (!ctx->opt_build_speculate || ctx->use_comm) HIP_TRY(hipStreamSynchronize(ctx->stream));
     return 0;
 }
 
@@ -801,6 +802,7 @@ int init_context(kfsp_ctx *ctx)
     }
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_H), ((size_t)kMH * kMH + 2) * sizeof(double), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_pin), (size_t)(kMH + 8) * sizeof(double), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_build), 8192, hipHostMallocDefault));
     std::memset(ctx->h_H, 0, ((size_t)kMH * kMH + 2) * sizeof(double));
     return 0;
 }
@@ -859,16 +861,6 @@ int kfsp_create(int device, kfsp_ctx **out)
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0) return 1000 + (int)(e == hipSuccess ? hipErrorNoDevice : e);
     if (device < 0 || device >= count) return -1;
-    // How the host waits for the device (every pass of the time loop ends in one stream synchronisation: thousands per solve).
-    // KFSP_SYNC=spin / yield / block asks the runtime for that policy; it only takes effect on a device this process has not
-    // used yet, and a runtime that refuses is left alone.
-    if (const char *w = std::getenv("KFSP_SYNC")) {
-        const std::string how(w);
-        const unsigned f = how == "spin" ? hipDeviceScheduleSpin : how == "yield" ? hipDeviceScheduleYield :
-                           how == "block" ? hipDeviceScheduleBlockingSync : hipDeviceScheduleAuto;
-        if (hipSetDevice(device) == hipSuccess) (void)hipSetDeviceFlags(f);
-        (void)hipGetLastError();
-    }
     kfsp_ctx *ctx = new (std::nothrow) kfsp_ctx;
     if (!ctx) return 4001;
     ctx->device = device;
@@ -937,6 +929,7 @@ int kfsp_destroy(kfsp_ctx *ctx)
     if (ctx->h_loop) (void)hipHostFree(ctx->h_loop);
     if (ctx->h_H) (void)hipHostFree(ctx->h_H);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
+    if (ctx->h_build) (void)hipHostFree(ctx->h_build);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1573,6 +1566,20 @@ int kfsp_layout_info(const kfsp_ctx *ctx, int64_t *v)
     v[5] = ctx->nchunks;
     v[6] = ctx->sell_coded ? ctx->code_words : 0;
     v[7] = ctx->perm_on ? 1 : 0;
+    return 0;
+}
+
+int kfsp_build_info(const kfsp_ctx *ctx, int64_t *v)
+{
+    if (!ctx) return -1;
+    if (!v) return -2;
+    if (ctx->group) ctx = kfsp::group_rank0(ctx);
+    v[0] = ctx->spec_builds;
+    v[1] = ctx->spec_redone;
+    v[2] = ctx->last_build_sell ? 1 : 0;
+    v[3] = ctx->kc_ok ? 1 : 0;
+    v[4] = ctx->order_merges;
+    v[5] = 0;
     return 0;
 }
 
@@ -2246,8 +2253,20 @@ int kfsp_drop_rebuild(kfsp_ctx *ctx)
         ctx->perm_pending_n = 0;
         ctx->coords_n = 0;
         bool ordered = false;
-        if (coords && want_order)
-            if (int rc = kfsp::state_order_from_resident(ctx, (int32_t)n_new, cns, cld, &ordered)) return rc;
+        const bool spec = ctx->opt_build_speculate && !ctx->use_comm;
+        if (coords && want_order) {
+            // (the kept states keep their relative order: compact the order that is here, or make it from the coordinates)
+            int rc = 0;
+            const int32_t *scan = ctx->d_sortidx.p + n_old;             // (left there by compact_resident_ell)
+            if (spec && cns == ctx->kc_ns && kfsp::state_order_after_drop(ctx, (int32_t)n_old, (int32_t)n_new, keep, scan, &rc)) {
+                if (rc) return rc;
+                ordered = true;
+                ctx->coords_n = n_new;                                  // (as state_order_from_resident leaves them)
+                ctx->coords_ld = cld;
+                ctx->coords_ns = cns;
+            } else if ((rc = kfsp::state_order_from_resident(ctx, (int32_t)n_new, cns, cld, &ordered, spec)))
+                return rc;
+        }
         if (coords && !ordered) {                              // (the coordinates are resident either way)
             ctx->coords_n = n_new;
             ctx->coords_ld = cld;
@@ -2259,7 +2278,15 @@ int kfsp_drop_rebuild(kfsp_ctx *ctx)
         ctx->perm_on = ordered;
         ctx->prod_last = ctx->prod_count;
         ctx->prod_count = 0;
-        int rc = kfsp::build_from_resident_ell(ctx, (int32_t)n_new, bw, ld);
+        int rc = kfsp::build_from_resident_ell(ctx, (int32_t)n_new, bw, ld, spec);
+        if (rc == kfsp::kRedoBuild) {                          // (a speculation did not hold: order and generator again, waiting for every number)
+            ++ctx->spec_redone;
+            if (coords && want_order) {
+                if (int rc2 = kfsp::state_order_from_resident(ctx, (int32_t)n_new, cns, cld, &ordered)) return rc2;
+                ctx->perm_on = ordered;
+            }
+            rc = kfsp::build_from_resident_ell(ctx, (int32_t)n_new, bw, ld);
+        }
         if (!rc) rc = setup_exchange(ctx);
         if (!rc) rc = adopt_pending_vector(ctx);
         ctx->t_ms[KFSP_T_UPLOAD] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -2318,8 +2345,9 @@ int kfsp_expand_resident(kfsp_ctx *ctx, double t_ssa, int64_t seedmix, int32_t n
         const bool want_order = ctx->opt_state_order && n2 >= ctx->opt_state_order_min && ctx->prod_count >= ctx->opt_state_order_products;
         ctx->perm_pending_n = 0;
         bool ordered = false;
+        const bool spec = ctx->opt_build_speculate && !ctx->use_comm;
         if (want_order)
-            if (int rc2 = kfsp::state_order_from_resident(ctx, (int32_t)n2, ns, cld, &ordered)) return rc2;
+            if (int rc2 = kfsp::state_order_from_resident(ctx, (int32_t)n2, ns, cld, &ordered, spec, (int32_t)n)) return rc2;
         ctx->coords_n = n2;
         ctx->coords_ld = cld;
         ctx->coords_ns = ns;
@@ -2327,7 +2355,16 @@ int kfsp_expand_resident(kfsp_ctx *ctx, double t_ssa, int64_t seedmix, int32_t n
         ctx->perm_on = ordered;
         ctx->prod_last = ctx->prod_count;
         ctx->prod_count = 0;
-        rc = kfsp::build_from_resident_ell(ctx, (int32_t)n2, nr, ctx->ell_ld);
+        rc = kfsp::build_from_resident_ell(ctx, (int32_t)n2, nr, ctx->ell_ld, spec);
+        if (rc == kfsp::kRedoBuild) {                          // (a speculation did not hold: order and generator again, waiting for every number)
+            ++ctx->spec_redone;
+            if (want_order) {
+                if (int rc2 = kfsp::state_order_from_resident(ctx, (int32_t)n2, ns, cld, &ordered)) return rc2;
+                ctx->coords_n = n2;
+                ctx->perm_on = ordered;
+            }
+            rc = kfsp::build_from_resident_ell(ctx, (int32_t)n2, nr, ctx->ell_ld);
+        }
         if (!rc) rc = setup_exchange(ctx);
         if (!rc) rc = adopt_pending_vector(ctx);
         ctx->t_ms[KFSP_T_UPLOAD] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -2545,6 +2582,7 @@ int kfsp_set_option(kfsp_ctx *ctx, const char *name, int64_t value)
     else if (k == "halo_p2p") ctx->opt_halo_p2p = value;
     else if (k == "halo_sell") ctx->opt_halo_sell = value;
     else if (k == "sell_sigma") ctx->opt_sell_sigma = value;
+    else if (k == "build_speculate") ctx->opt_build_speculate = value != 0;
     else if (k == "overlap") ctx->opt_overlap = value;
     else if (k == "small_kernel") ctx->opt_small = value;
     else if (k == "m_max") {

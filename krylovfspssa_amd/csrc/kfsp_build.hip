@@ -165,14 +165,63 @@ struct KeyLayout {
 // species 1 in the lowest bits: ascending keys = lexicographic order with the
 // first species running fastest (the order of the benchmark boxes)
 __global__ __launch_bounds__(kBlock) void k_pack_keys(int64_t n, int ld, const int32_t *__restrict__ state, KeyLayout L,
-                                                      unsigned long long *__restrict__ keys, int32_t *__restrict__ idx)
+                                                      unsigned long long *__restrict__ keys, int32_t *__restrict__ idx, int32_t base,
+                                                      unsigned long long mask)
 {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     unsigned long long key = 0;
     for (int k = 0; k < L.ns; ++k) key |= (unsigned long long)(unsigned)(state[i * ld + k] - L.lo[k]) << L.shift[k];
-    keys[i] = key;
-    idx[i] = (int32_t)i;
+    // (mask: the bits the sort looks at.  A state that has outgrown a speculative layout spills above them - cut off, its
+    // key is wrong but the sorted list IS sorted, which the merge's binary searches rely on to hand out every place once)
+    keys[i] = key & mask;
+    idx[i] = base + (int32_t)i;
+}
+
+// Two sorted key lists into one: element i of list A lands i + (keys of B below it) places in, element j of B lands
+// j + (keys of A not above it) - the stable merge, A first among equals.  The keys of an FSP are distinct, but a key packed
+// under a layout its state has outgrown (the speculation state_order_check catches AFTER this has run) can collide with
+// another: with this rule the places are a permutation whatever the keys are, so nothing downstream indexes through a hole.
+// The launch covers na + nb lanes, the first na for A.  pa / pb: the caller's indices that travel with the keys.
+__global__ __launch_bounds__(kBlock) void k_merge_sorted(int64_t na, const unsigned long long *__restrict__ ka, const int32_t *__restrict__ pa,
+                                                         int64_t nb, const unsigned long long *__restrict__ kb, const int32_t *__restrict__ pb,
+                                                         unsigned long long *__restrict__ kout, int32_t *__restrict__ pout)
+{
+    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= na + nb) return;
+    const bool a = t < na;
+    const int64_t i = a ? t : t - na;
+    const unsigned long long key = a ? ka[i] : kb[i];
+    const unsigned long long *__restrict__ other = a ? kb : ka;
+    int64_t lo = 0, hi = a ? nb : na;
+    while (lo < hi) {                                       // A: first element of B not below key; B: first of A above it
+        const int64_t mid = (lo + hi) >> 1;
+        if (a ? other[mid] < key : other[mid] <= key) lo = mid + 1;
+        else hi = mid;
+    }
+    kout[i + lo] = key;
+    pout[i + lo] = a ? pa[i] : pb[i];
+}
+
+// The order of the states a drop keeps: they stay in the order they had.  f[i'] = 1 when the state at internal place i' is
+// kept (keep[] is in the caller's order); after the exclusive sum of f, the kept ones move up to pos[i'] and carry the
+// caller's NEW index of their state (scan[]: the exclusive sum of keep[] the compaction of the lists used).
+__global__ __launch_bounds__(kBlock) void k_order_keep_flags(int64_t n, const int32_t *__restrict__ perm, const uint8_t *__restrict__ keep,
+                                                             int32_t *__restrict__ f)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) f[i] = keep[perm[i]] ? 1 : 0;
+}
+
+__global__ __launch_bounds__(kBlock) void k_order_keep_apply(int64_t n, const int32_t *__restrict__ perm, const int32_t *__restrict__ f,
+                                                             const int32_t *__restrict__ pos, const int32_t *__restrict__ scan,
+                                                             const unsigned long long *__restrict__ keys, int32_t *__restrict__ perm2,
+                                                             unsigned long long *__restrict__ keys2)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n || !f[i]) return;
+    perm2[pos[i]] = scan[perm[i]];
+    keys2[pos[i]] = keys[i];
 }
 
 __global__ __launch_bounds__(kBlock) void k_invert_perm(int64_t n, const int32_t *__restrict__ perm,
@@ -350,6 +399,69 @@ __global__ __launch_bounds__(kBlock) void k_sell_sort_rows(int64_t nloc, const i
     }
 }
 
+// The same order for rows of at most CAP entries, from registers: every entry is read once, ranked against the others
+// (rank = how many entries sort before it under the insertion sort's rule - key, then value, then position: a stable
+// ascending order, so the result is the insertion sort's, entry for entry) and written once to its place.  The insertion
+// sort re-reads and re-writes the row from memory for every entry it places (96 us for the 10^6 rows of the Goutsias run,
+// the longest kernel of a rebuild); loops over CAP are unrolled so nothing is indexed dynamically.
+template <int CAP>
+__global__ __launch_bounds__(kBlock) void k_sell_rank_rows(int64_t nloc, const int32_t *__restrict__ cnt,
+                                                           const int64_t *__restrict__ off, int32_t *__restrict__ col,
+                                                           double *__restrict__ val, const int32_t *__restrict__ perm)
+{
+    const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= nloc) return;
+    const int m = cnt[r];
+    if (m < 2) return;
+    const int64_t o = off[r >> 6];
+    const int w = (int)((off[(r >> 6) + 1] - o) >> 6);
+    const int l = (int)(r & 63);
+    int32_t c[CAP], k[CAP];
+    double v[CAP];
+#pragma unroll
+    for (int a = 0; a < CAP; ++a) {
+        c[a] = 0;
+        k[a] = 0;
+        v[a] = 0.0;
+        if (a < m) {
+            c[a] = col[sell_pos(o, w, a, l)];
+            v[a] = val[sell_pos(o, w, a, l)];
+            k[a] = perm ? perm[c[a]] : c[a];
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < CAP; ++a) {
+        if (a < m) {
+            int rank = 0;
+#pragma unroll
+            for (int b = 0; b < CAP; ++b) {
+                if (b == a) continue;
+                // b stays in front of a exactly when the insertion sort would stop a behind it: (k_b, v_b) <= (k_a, v_a)
+                // for an earlier b, strictly smaller for a later one
+                const bool before = b < a ? (k[b] < k[a] || (k[b] == k[a] && v[b] <= v[a]))
+                                          : (k[b] < k[a] || (k[b] == k[a] && v[b] < v[a]));
+                rank += (b < m && before) ? 1 : 0;
+            }
+            col[sell_pos(o, w, rank, l)] = c[a];
+            val[sell_pos(o, w, rank, l)] = v[a];
+        }
+    }
+}
+
+void launch_sell_sort_rows(kfsp_ctx *ctx, int64_t nloc, int bw, hipStream_t st)
+{
+    if (nloc < 1) return;
+    const dim3 grid((int)((nloc + kBlock - 1) / kBlock)), block(kBlock);
+    const int32_t *perm = ctx->perm_on ? ctx->d_perm.p : (const int32_t *)nullptr;
+    // (a row holds at most one entry per reaction)
+    if (bw <= 8 && ctx->opt_build_speculate)
+        hipLaunchKernelGGL(k_sell_rank_rows<8>, grid, block, 0, st, nloc, ctx->d_cnt.p, ctx->d_off.p, ctx->d_col.p, ctx->d_val.p, perm);
+    else if (bw <= 16 && ctx->opt_build_speculate)
+        hipLaunchKernelGGL(k_sell_rank_rows<16>, grid, block, 0, st, nloc, ctx->d_cnt.p, ctx->d_off.p, ctx->d_col.p, ctx->d_val.p, perm);
+    else
+        hipLaunchKernelGGL(k_sell_sort_rows, grid, block, 0, st, nloc, ctx->d_cnt.p, ctx->d_off.p, ctx->d_col.p, ctx->d_val.p, perm);
+}
+
 // SELL-sigma: inside windows of `sigma` rows of the internal order, the longest rows first (stable), so
 // that the 64 rows of a chunk are about equally long and few slots are padding.
 __global__ __launch_bounds__(kBlock) void k_sigma_keys(int64_t n, int sigma, const int32_t *__restrict__ cnt,
@@ -412,7 +524,14 @@ int build_from_ell_device(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, cons
 
 // the gather form from the reference arrays that are ALREADY on the device (d_ell_adj / d_ell_off / d_ell_diag, n columns
 // of leading dimension ld): what build_from_ell_device does after its upload, and all kfsp_drop_rebuild needs
-int build_from_resident_ell(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld)
+bool state_order_check(kfsp_ctx *ctx);
+
+// speculate (a resident FSP being rebuilt, kfsp_expand_resident / kfsp_drop_rebuild): when the last generator built
+// here was SELL, assume this one is too and run scan, chunk widths, fill and row sort WITHOUT stopping for the link
+// statistics or the slot count - the entry arrays are reserved for the bound nact * bw (a row has at most one link per
+// reaction) - then wait once and check what the slow path would have looked at first: a bad link, the banded form the
+// slow path would have chosen, a state order packed under stale ranges (state_order_check).  kRedoBuild: not held.
+int build_from_resident_ell(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, bool speculate)
 {
     hipStream_t st = ctx->stream;
     const int64_t row0 = ctx->row0, nloc = ctx->nloc;
@@ -451,30 +570,82 @@ int build_from_resident_ell(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld)
     const int gsrc = (int)((n + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(k_ell_scan, dim3(std::min(gsrc, 1024)), dim3(kBlock), 0, st, (int64_t)n, (int)bw, (int)ld, ell_adj,
                        row0, nloc, ctx->d_cnt.p, dscan);
-    ScanOut res;
+    const bool spec = speculate && ctx->last_build_sell && ctx->h_build && nloc > 0 &&
+                      !(ctx->perm_on && ctx->opt_sell_sigma >= 128) && (double)nact * (double)bw * 12.0 <= 16e9;
+    ScanOut res_stack;
+    ScanOut &res = spec ? *reinterpret_cast<ScanOut *>(ctx->h_build) : res_stack;
     HIP_TRY_B(hipMemcpyAsync(&res, dscan, sizeof(res), hipMemcpyDeviceToHost, st));
-    HIP_TRY_B(hipStreamSynchronize(st));
-    if (res.bad) {
-        ctx->err = "adj entry exceeds n";
-        return -5;
+    if (!spec) {
+        HIP_TRY_B(hipStreamSynchronize(st));
+        if (!state_order_check(ctx)) return kRedoBuild;
+        if (res.bad) {
+            ctx->err = "adj entry exceeds n";
+            return -5;
+        }
     }
     ctx->nchunks = nchunks;
-    ctx->nnz = nloc + (int64_t)res.nnz_off;
     const int64_t nact2 = round_up(nact, 2 * kChunk);      // the banded kernel works on 128-row groups
     HIP_TRY_B(ctx->d_diag.reserve((size_t)std::max<int64_t>(nact2, 128), false));
+    ctx->last_build_sell = false;
 
     // banded?  every used slot is one constant shift, and the diagonals are full enough
-    int nd = 0;
-    bool banded = ctx->opt_format != 1 && nloc > 0;
-    std::pair<int, int> dl[kMaxBw];                        // (source - target, slot)
-    for (int j = 0; j < bw && banded; ++j) {
-        if (res.dmin[j] == INT_MAX) continue;              // slot never links
-        if (res.dmin[j] != res.dmax[j]) banded = false;
-        else dl[nd++] = {-res.dmin[j], j};
+    auto banded_form = [&](std::pair<int, int> *dl, int &nd) {
+        nd = 0;
+        bool banded = ctx->opt_format != 1 && nloc > 0;
+        for (int j = 0; j < bw && banded; ++j) {
+            if (res.dmin[j] == INT_MAX) continue;              // slot never links
+            if (res.dmin[j] != res.dmax[j]) banded = false;
+            else dl[nd++] = {-res.dmin[j], j};
+        }
+        if (nd == 0 || nd > kMaxDiag) banded = false;
+        // (8 bytes per stored diagonal entry against 12 per SELL slot, cf. maybe_upload_dia)
+        if (banded && (double)nd * (double)nloc > 1.5 * (double)res.nnz_off + 1024.0) banded = false;
+        return banded;
+    };
+    if (spec) {
+        ctx->use_dia = false;
+        ctx->dia_masked = false;
+        ctx->nd = 0;
+        ctx->have_sell = false;
+        ctx->sell_coded = false;
+        ctx->sell_reach = -1;
+        const int64_t bound = nact * (int64_t)bw;
+        HIP_TRY_B(ctx->d_off.reserve((size_t)nchunks + 1, false));
+        HIP_TRY_B(ctx->d_col.reserve((size_t)std::max<int64_t>(bound, 64), false));
+        HIP_TRY_B(ctx->d_val.reserve((size_t)std::max<int64_t>(bound, 64), false));
+        HIP_TRY_B(ctx->d_ticket.reserve((size_t)std::max<int64_t>(nact, 64), false));
+        HIP_TRY_B(hipMemsetAsync(ctx->d_off.p, 0, sizeof(int64_t), st));
+        HIP_TRY_B(hipMemsetAsync(ctx->d_ticket.p, 0, (size_t)std::max<int64_t>(nact, 64) * sizeof(int32_t), st));
+        hipLaunchKernelGGL(k_chunk_width, dim3((int)((nchunks + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, nchunks, nloc,
+                           ctx->d_cnt.p, ctx->d_off.p);
+        hipLaunchKernelGGL(k_scan_offsets, dim3(1), dim3(1024), 0, st, nchunks, ctx->d_off.p);
+        int64_t *hslots = reinterpret_cast<int64_t *>(ctx->h_build + 2048);
+        HIP_TRY_B(hipMemcpyAsync(hslots, ctx->d_off.p + nchunks, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        hipLaunchKernelGGL(k_sell_init, dim3((int)((nchunks + 3) / 4)), dim3(kBlock), 0, st, nchunks, nloc, row0, ctx->d_off.p,
+                           ctx->d_col.p, ctx->d_val.p, ell_diag, ctx->d_diag.p);
+        hipLaunchKernelGGL(k_sell_fill, dim3((int)(((int64_t)n * ld + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, (int64_t)n,
+                           (int)bw, (int)ld, ell_adj, ell_off, row0, nloc, ctx->d_off.p, ctx->d_ticket.p, ctx->d_col.p, ctx->d_val.p);
+        launch_sell_sort_rows(ctx, nloc, bw, st);
+        HIP_TRY_B(hipStreamSynchronize(st));
+        ++ctx->spec_builds;
+        if (!state_order_check(ctx)) return kRedoBuild;
+        if (res.bad) {
+            ctx->err = "adj entry exceeds n";
+            return -5;
+        }
+        std::pair<int, int> dl[kMaxBw];
+        int nd = 0;
+        if (banded_form(dl, nd)) return kRedoBuild;           // (the slow path would store diagonals: let it)
+        ctx->nnz = nloc + (int64_t)res.nnz_off;
+        ctx->slots = *hslots;
+        ctx->have_sell = true;
+        ctx->last_build_sell = true;
+        return build_sell_code(ctx);
     }
-    if (nd == 0 || nd > kMaxDiag) banded = false;
-    // (8 bytes per stored diagonal entry against 12 per SELL slot, cf. maybe_upload_dia)
-    if (banded && (double)nd * (double)nloc > 1.5 * (double)res.nnz_off + 1024.0) banded = false;
+    ctx->nnz = nloc + (int64_t)res.nnz_off;
+    std::pair<int, int> dl[kMaxBw];                        // (source - target, slot)
+    int nd = 0;
+    const bool banded = banded_form(dl, nd);
 
     ctx->use_dia = false;
     ctx->dia_masked = false;
@@ -522,6 +693,7 @@ int build_from_resident_ell(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld)
         // slots (own x, zeros) did.  perm / iperm are replaced by the composed order and the reference
         // arrays relabelled once more; rows are still summed in the caller's column order.
         const int sigma = (int)ctx->opt_sell_sigma;
+        ctx->order_n = 0;                                  // (d_perm is about to stop being the lexicographic order)
         const int grid = (int)(((int64_t)n + kBlock - 1) / kBlock);
         HIP_TRY_B(ctx->d_ticket.reserve((size_t)std::max<int64_t>(nact, 64), false));
         unsigned long long *kin = ctx->d_keys.p, *kout = ctx->d_keys.p + n;     // (reserved by state_order_from_coords)
@@ -563,12 +735,11 @@ int build_from_resident_ell(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld)
                            ctx->d_off.p, ctx->d_col.p, ctx->d_val.p, ell_diag, ctx->d_diag.p);
         hipLaunchKernelGGL(k_sell_fill, dim3((int)(((int64_t)n * ld + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, (int64_t)n, (int)bw, (int)ld, ell_adj,
                            ell_off, row0, nloc, ctx->d_off.p, ctx->d_ticket.p, ctx->d_col.p, ctx->d_val.p);
-        hipLaunchKernelGGL(k_sell_sort_rows, dim3((int)((nloc + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, nloc,
-                           ctx->d_cnt.p, ctx->d_off.p, ctx->d_col.p, ctx->d_val.p,
-                           ctx->perm_on ? ctx->d_perm.p : (const int32_t *)nullptr);
+        launch_sell_sort_rows(ctx, nloc, bw, st);
     }
     HIP_TRY_B(hipStreamSynchronize(st));
     ctx->have_sell = true;
+    ctx->last_build_sell = true;
     return build_sell_code(ctx);
 }
 
@@ -794,7 +965,8 @@ int compact_resident_ell(kfsp_ctx *ctx, int64_t n, int bw, int ld, const uint8_t
     hipLaunchKernelGGL(k_ell_compact, dim3(grid_e), dim3(kBlock), 0, st, n, bw, ld, lds, lds, keep, scan, ctx->d_ell_adj.p,
                        ctx->d_ell_off.p, ctx->d_ell_diag.p, with_coords ? ctx->d_coords.p : (const int32_t *)nullptr, ctx->d_ell_adj2.p,
                        ctx->d_ell_off2.p, ctx->d_ell_diag2.p, with_coords ? ctx->d_coords2.p : (int32_t *)nullptr);
-    HIP_TRY_B(hipStreamSynchronize(st));
+    // (everything that follows is ordered behind this on the same stream; the rebuild waits once, at its end)
+    if (!ctx->opt_build_speculate || ctx->use_comm) HIP_TRY_B(hipStreamSynchronize(st));
     std::swap(ctx->d_ell_adj, ctx->d_ell_adj2);
     std::swap(ctx->d_ell_off, ctx->d_ell_off2);
     std::swap(ctx->d_ell_diag, ctx->d_ell_diag2);
@@ -900,60 +1072,169 @@ int state_order_from_coords(kfsp_ctx *ctx, int32_t n, int32_t ns, int32_t ld, co
     return state_order_from_resident(ctx, n, ns, ld, ok);
 }
 
-// the same from coordinates that are already in d_coords (n x ld, room for 64 more entries behind them)
-int state_order_from_resident(kfsp_ctx *ctx, int32_t n, int32_t ns, int32_t ld, bool *ok)
+// the same from coordinates that are already in d_coords (n x ld, room for 64 more entries behind them).
+// speculate: when the key layout of the last order is still here (kc_*), pack with IT - its fields are as wide as the bits
+// they occupy, so it holds until a coordinate range crosses a power of two - and let the ranges of this FSP land in the
+// pinned block: build_from_resident_ell checks them at its one synchronisation (order_check) and answers kRedoBuild when
+// a coordinate fell outside.  The ORDER does not depend on the layout (lexicographic, first species fastest), only its
+// validity does: the speculative order is the order the slow path would have made, bit for bit.
+// n_prev > 0 (with speculate): the first n_prev states are the FSP the current order (d_perm, its sorted keys d_skeys) was
+// made for and the rest were appended to it - only THEIR keys are packed, checked and sorted, and merged into the kept
+// list (KrylovSolver.f90:528-529 appends; StateSpace.f90:136-246 never moves an old state).
+int state_order_from_resident(kfsp_ctx *ctx, int32_t n, int32_t ns, int32_t ld, bool *ok, bool speculate, int32_t n_prev)
 {
     *ok = false;
     ctx->coords_n = 0;
+    ctx->order_check = false;
+    const int64_t had_order = ctx->order_n;
+    ctx->order_n = 0;
     if (ns > 16) return 0;
     hipStream_t st = ctx->stream;
     const size_t nent = (size_t)n * (size_t)ld;
-    int mm[32];
+    const bool spec = speculate && ctx->kc_ok && ctx->kc_ns == ns && ctx->h_build && n > 0;
+    const bool merge = spec && n_prev > 0 && n_prev < n && ctx->perm_on && had_order == n_prev && ctx->skeys_n == n_prev &&
+                       ctx->opt_sell_sigma < 128;
+    const int64_t first = merge ? n_prev : 0, count = (int64_t)n - first;      // the states whose keys are made now
+    int mm_stack[32];
+    int *mm = spec ? reinterpret_cast<int *>(ctx->h_build + 2304) : mm_stack;      // (pinned: the copy back does not stop the host)
+    int *mm_init = spec ? reinterpret_cast<int *>(ctx->h_build + 2560) : mm_stack;
     for (int k = 0; k < ns; ++k) {
-        mm[2 * k] = INT_MAX;
-        mm[2 * k + 1] = INT_MIN;
+        mm_init[2 * k] = INT_MAX;
+        mm_init[2 * k + 1] = INT_MIN;
     }
     int *dmm = reinterpret_cast<int *>(ctx->d_coords.p + nent);
-    HIP_TRY_B(hipMemcpyAsync(dmm, mm, sizeof(int) * 2 * (size_t)ns, hipMemcpyHostToDevice, st));
-    const int grid = (int)(((int64_t)n + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(k_coord_minmax, dim3(std::min(grid, 1024)), dim3(kBlock), 0, st, (int64_t)n, (int)ns, (int)ld,
-                       ctx->d_coords.p, dmm);
+    HIP_TRY_B(hipMemcpyAsync(dmm, mm_init, sizeof(int) * 2 * (size_t)ns, hipMemcpyHostToDevice, st));
+    const int grid = (int)((count + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_coord_minmax, dim3(std::min(grid, 1024)), dim3(kBlock), 0, st, count, (int)ns, (int)ld,
+                       ctx->d_coords.p + (size_t)first * (size_t)ld, dmm);
     HIP_TRY_B(hipMemcpyAsync(mm, dmm, sizeof(int) * 2 * (size_t)ns, hipMemcpyDeviceToHost, st));
-    HIP_TRY_B(hipStreamSynchronize(st));
-    ctx->coords_n = n;                                     // (the coordinates stay resident: kfsp_ssa_streams may use them)
-    ctx->coords_ld = ld;
-    ctx->coords_ns = ns;
     KeyLayout L;
     L.ns = ns;
     int bits = 0;
-    for (int k = 0; k < ns; ++k) {
-        const long long range = (long long)mm[2 * k + 1] - (long long)mm[2 * k];
-        if (range < 0) return 0;                           // no states
-        int b = 0;
-        while ((1LL << b) <= range) ++b;
-        L.lo[k] = mm[2 * k];
-        L.shift[k] = bits;
-        bits += b;
+    if (spec) {
+        ctx->order_check = true;
+        for (int k = 0; k < ns; ++k) {
+            L.lo[k] = ctx->kc_lo[k];
+            L.shift[k] = ctx->kc_shift[k];
+        }
+        bits = ctx->kc_bits;
+    } else {
+        HIP_TRY_B(hipStreamSynchronize(st));
+        ctx->kc_ok = false;
+        for (int k = 0; k < ns; ++k) {
+            const long long range = (long long)mm[2 * k + 1] - (long long)mm[2 * k];
+            if (range < 0) return 0;                           // no states
+            int b = 0;
+            while ((1LL << b) <= range) ++b;
+            L.lo[k] = mm[2 * k];
+            L.shift[k] = bits;
+            bits += b;
+            ctx->kc_lo[k] = L.lo[k];
+            ctx->kc_shift[k] = L.shift[k];
+            ctx->kc_hi[k] = (int)std::min<long long>((long long)L.lo[k] + (1LL << b) - 1, (long long)INT_MAX);
+        }
+        if (bits > 64) return 0;                               // does not pack: keep the caller's order
+        if (bits == 0) bits = 1;
+        ctx->kc_ns = ns;
+        ctx->kc_bits = bits;
+        ctx->kc_ok = true;
     }
-    if (bits > 64) return 0;                               // does not pack: keep the caller's order
-    if (bits == 0) bits = 1;
+    ctx->coords_n = n;                                     // (the coordinates stay resident: kfsp_ssa_streams may use them)
+    ctx->coords_ld = ld;
+    ctx->coords_ns = ns;
     HIP_TRY_B(ctx->d_keys.reserve(2 * (size_t)n, false));
-    HIP_TRY_B(ctx->d_sortidx.reserve((size_t)n, false));
-    HIP_TRY_B(ctx->d_perm.reserve((size_t)n, false));
+    HIP_TRY_B(ctx->d_sortidx.reserve(std::max((size_t)n, 2 * (size_t)count), false));
     HIP_TRY_B(ctx->d_iperm.reserve((size_t)n, false));
-    unsigned long long *kin = ctx->d_keys.p, *kout = ctx->d_keys.p + n;
-    hipLaunchKernelGGL(k_pack_keys, dim3(grid), dim3(kBlock), 0, st, (int64_t)n, (int)ld, ctx->d_coords.p, L, kin,
-                       ctx->d_sortidx.p);
-    size_t tmp_bytes = 0;
-    HIP_TRY_B(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, kin, kout, ctx->d_sortidx.p, ctx->d_perm.p, (int)n,
-                                                 0, bits, st));
-    HIP_TRY_B(ctx->d_sorttmp.reserve(tmp_bytes + 256, false));
-    HIP_TRY_B(hipcub::DeviceRadixSort::SortPairs(ctx->d_sorttmp.p, tmp_bytes, kin, kout, ctx->d_sortidx.p, ctx->d_perm.p,
-                                                 (int)n, 0, bits, st));
-    hipLaunchKernelGGL(k_invert_perm, dim3(grid), dim3(kBlock), 0, st, (int64_t)n, ctx->d_perm.p, ctx->d_iperm.p);
-    HIP_TRY_B(hipStreamSynchronize(st));
+    const int gridn = (int)(((int64_t)n + kBlock - 1) / kBlock);
+    unsigned long long *kin = ctx->d_keys.p;
+    hipLaunchKernelGGL(k_pack_keys, dim3(grid), dim3(kBlock), 0, st, count, (int)ld, ctx->d_coords.p + (size_t)first * (size_t)ld, L, kin,
+                       ctx->d_sortidx.p, (int32_t)first, bits >= 64 ? ~0ull : (1ull << bits) - 1ull);
+    if (merge) {
+        // the appended keys sorted behind kin (d_keys holds 2 n), then both lists into the second pair of buffers
+        unsigned long long *knew = ctx->d_keys.p + count;
+        int32_t *inew = ctx->d_sortidx.p + count;
+        size_t tmp_bytes = 0;
+        HIP_TRY_B(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, kin, knew, ctx->d_sortidx.p, inew, (int)count, 0, bits, st));
+        HIP_TRY_B(ctx->d_sorttmp.reserve(tmp_bytes + 256, false));
+        HIP_TRY_B(hipcub::DeviceRadixSort::SortPairs(ctx->d_sorttmp.p, tmp_bytes, kin, knew, ctx->d_sortidx.p, inew, (int)count, 0, bits, st));
+        HIP_TRY_B(ctx->d_perm2.reserve((size_t)n, false));
+        HIP_TRY_B(ctx->d_skeys2.reserve((size_t)n, false));
+        hipLaunchKernelGGL(k_merge_sorted, dim3(gridn), dim3(kBlock), 0, st, (int64_t)n_prev, ctx->d_skeys.p, ctx->d_perm.p, count, knew, inew,
+                           ctx->d_skeys2.p, ctx->d_perm2.p);
+        std::swap(ctx->d_perm, ctx->d_perm2);
+        std::swap(ctx->d_skeys, ctx->d_skeys2);
+        ++ctx->order_merges;
+    } else {
+        HIP_TRY_B(ctx->d_perm.reserve((size_t)n, false));
+        HIP_TRY_B(ctx->d_skeys.reserve((size_t)n, false));
+        size_t tmp_bytes = 0;
+        HIP_TRY_B(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, kin, ctx->d_skeys.p, ctx->d_sortidx.p, ctx->d_perm.p, (int)n,
+                                                     0, bits, st));
+        HIP_TRY_B(ctx->d_sorttmp.reserve(tmp_bytes + 256, false));
+        HIP_TRY_B(hipcub::DeviceRadixSort::SortPairs(ctx->d_sorttmp.p, tmp_bytes, kin, ctx->d_skeys.p, ctx->d_sortidx.p, ctx->d_perm.p,
+                                                     (int)n, 0, bits, st));
+    }
+    hipLaunchKernelGGL(k_invert_perm, dim3(gridn), dim3(kBlock), 0, st, (int64_t)n, ctx->d_perm.p, ctx->d_iperm.p);
+    if (!spec) HIP_TRY_B(hipStreamSynchronize(st));
+    ctx->order_n = n;
+    ctx->skeys_n = n;
     *ok = true;
     return 0;
+}
+
+// The order after a drop (kfsp_drop_rebuild), from the order before it: the kept states keep their relative order, so
+// the sorted keys and the permutation are compacted instead of made again - no key is packed, nothing is sorted, nothing
+// needs a check (the kept states are a subset of states whose keys were checked).  keep / scan: one byte per OLD state and
+// the exclusive sum of it, both in the caller's order (compact_resident_ell leaves them in d_dropflag / d_sortidx).
+// false: the order of the old FSP is not here - make it from the coordinates.
+bool state_order_after_drop(kfsp_ctx *ctx, int32_t n_old, int32_t n_new, const uint8_t *keep, const int32_t *scan, int *rc)
+{
+    *rc = 0;
+    if (!(ctx->perm_on && ctx->order_n == n_old && ctx->skeys_n == n_old && ctx->kc_ok && ctx->opt_sell_sigma < 128 && n_new > 0)) return false;
+    hipStream_t st = ctx->stream;
+    auto bad = [&](hipError_t e) {
+        if (e == hipSuccess) return false;
+        ctx->err = std::string("state_order_after_drop: ") + hipGetErrorString(e);
+        *rc = 1000 + (int)e;
+        return true;
+    };
+    ctx->order_n = 0;
+    ctx->order_check = false;
+    if (bad(ctx->d_keys.reserve(2 * (size_t)n_old, false))) return true;
+    int32_t *f = reinterpret_cast<int32_t *>(ctx->d_keys.p), *pos = f + n_old;          // (scratch: 2 n_old int32 of the 2 n_old keys)
+    const int grid = (int)(((int64_t)n_old + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_order_keep_flags, dim3(grid), dim3(kBlock), 0, st, (int64_t)n_old, ctx->d_perm.p, keep, f);
+    size_t tmp_bytes = 0;
+    if (bad(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, f, pos, (int)n_old, st))) return true;
+    if (bad(ctx->d_sorttmp.reserve(tmp_bytes + 256, false))) return true;
+    if (bad(hipcub::DeviceScan::ExclusiveSum(ctx->d_sorttmp.p, tmp_bytes, f, pos, (int)n_old, st))) return true;
+    if (bad(ctx->d_perm2.reserve((size_t)n_old, false)) || bad(ctx->d_skeys2.reserve((size_t)n_old, false)) ||
+        bad(ctx->d_iperm.reserve((size_t)n_old, false)))
+        return true;
+    hipLaunchKernelGGL(k_order_keep_apply, dim3(grid), dim3(kBlock), 0, st, (int64_t)n_old, ctx->d_perm.p, f, pos, scan, ctx->d_skeys.p,
+                       ctx->d_perm2.p, ctx->d_skeys2.p);
+    std::swap(ctx->d_perm, ctx->d_perm2);
+    std::swap(ctx->d_skeys, ctx->d_skeys2);
+    hipLaunchKernelGGL(k_invert_perm, dim3((int)(((int64_t)n_new + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, (int64_t)n_new, ctx->d_perm.p,
+                       ctx->d_iperm.p);
+    ctx->order_n = n_new;
+    ctx->skeys_n = n_new;
+    ++ctx->order_merges;
+    return true;
+}
+
+// the ranges the speculative order was packed under, once the stream has been waited for
+bool state_order_check(kfsp_ctx *ctx)
+{
+    if (!ctx->order_check) return true;
+    ctx->order_check = false;
+    const int *mm = reinterpret_cast<const int *>(ctx->h_build + 2304);
+    for (int k = 0; k < ctx->kc_ns; ++k)
+        if (mm[2 * k] < ctx->kc_lo[k] || mm[2 * k + 1] > ctx->kc_hi[k]) {
+            ctx->kc_ok = false;
+            return false;
+        }
+    return true;
 }
 
 }  // namespace kfsp

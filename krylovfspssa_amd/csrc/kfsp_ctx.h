@@ -233,6 +233,19 @@ struct kfsp_ctx {
     DevBuf<double> d_ell_off, d_ell_diag;
     DevBuf<int> d_slot;
     DevBuf<char> d_scan;
+    // Speculative rebuild of a resident FSP (option build_speculate; kfsp_build.hip): the numbers the host would stop for
+    // (coordinate ranges, link statistics, SELL slots) land in this pinned block instead and are checked ONCE, when the
+    // generator is built - a failed check repeats order and build the slow way.  kc_*: the key layout of the last state
+    // order (each species' field widened to its full bit width), valid while every coordinate stays inside [kc_lo, kc_hi].
+    char *h_build = nullptr;
+    bool kc_ok = false, order_check = false, last_build_sell = false;
+    int kc_ns = 0, kc_bits = 0, kc_lo[16] = {0}, kc_hi[16] = {0}, kc_shift[16] = {0};
+    int64_t opt_build_speculate = 1, spec_builds = 0, spec_redone = 0;
+    // the sorted keys of the current order (d_perm) and for how many states both are valid: an expansion merges the appended
+    // states' keys into them, a drop compacts them (state_order_from_resident, state_order_after_drop)
+    DevBuf<unsigned long long> d_skeys, d_skeys2;
+    DevBuf<int32_t> d_perm2;
+    int64_t order_n = 0, skeys_n = 0, order_merges = 0;
     // Internal state order (kfsp_set_state_coords): the device keeps generator and
     // vectors in lexicographic order of the state coordinates, the host sees its
     // own order.  perm[new] = old, iperm[old] = new (0-based).
@@ -393,8 +406,10 @@ int build_from_ell_device(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, cons
                           const double *offdiag, const double *diag, int64_t keep = 0);
 // after a banded generator was stored: find the empty (diagonal, 128-row group) segments and
 // switch the masked kernel variant on if they are worth skipping
-int build_from_resident_ell(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld);
-int state_order_from_resident(kfsp_ctx *ctx, int32_t n, int32_t ns, int32_t ld, bool *ok);
+constexpr int kRedoBuild = 7777;      // a speculative order / build did not hold: repeat both with speculate = false
+int build_from_resident_ell(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, bool speculate = false);
+int state_order_from_resident(kfsp_ctx *ctx, int32_t n, int32_t ns, int32_t ld, bool *ok, bool speculate = false, int32_t n_prev = 0);
+bool state_order_after_drop(kfsp_ctx *ctx, int32_t n_old, int32_t n_new, const uint8_t *keep, const int32_t *scan, int *rc);
 int compact_resident_ell(kfsp_ctx *ctx, int64_t n, int bw, int ld, const uint8_t *keep, int64_t n_keep, bool with_coords, int lds);
 int build_dia_mask(kfsp_ctx *ctx);
 // after a SELL image was stored (d_off, d_col, d_val): try the dictionary-coded column form

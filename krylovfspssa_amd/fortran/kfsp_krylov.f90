@@ -119,6 +119,7 @@ CONTAINS
     LOGICAL :: WAS_RESIDENT
     DOUBLE PRECISION :: T0V
     REAL(C_DOUBLE) :: PADE_SEC(4)
+    INTEGER(C_INT64_T) :: BUILD_INFO(6)
 
     IFLAG = 0
     ! the device context comes first: the threads its runtime starts must not
@@ -229,6 +230,10 @@ CONTAINS
        PRINT '(A,A,A,A,A,A,A,A)', ' KFSP MODE: LISTS = ', TRIM(MERGE('RESIDENT', 'HOST    ', WAS_RESIDENT)), ' PROPENSITIES = ', &
             TRIM(MERGE('DEVICE', 'HOST  ', PROGRAM_READY)), ' SSA = ', TRIM(MERGE('STREAMS  ', 'REFERENCE', SSA_STREAMS_REQUESTED())), &
             ' MODEL = ', TRIM(MERGE('CUSTOMPROP ', 'EXPRESSIONS', ASSOCIATED(MODEL%CUSTOMPROP)))
+       ! (rebuilds of the resident FSP that did not stop for their sizes, and those repeated because a check failed: kfsp.h)
+       IF (WAS_RESIDENT .AND. KFSP_BUILD_INFO(CTX, BUILD_INFO) == 0) &
+            PRINT '(A,I7,A,I5,A,I7)', ' KFSP RESIDENT REBUILDS: SPECULATIVE =', BUILD_INFO(1), ' REPEATED =', BUILD_INFO(2), &
+            ' ORDERS CARRIED OVER =', BUILD_INFO(5)
        CALL KFSP_PADM_PROFILE(PADE_SEC, 1_C_INT)
        PRINT '(A,4(1X,A,F9.1))', ' KFSP HOST PADE PARTS MS:', 'DENSE_PRODUCTS', 1.0D3 * PADE_SEC(1), 'BANDED_PRODUCTS', 1.0D3 * PADE_SEC(2), &
             'SOLVE', 1.0D3 * PADE_SEC(3), 'WHOLE_CALLS', 1.0D3 * PADE_SEC(4)

@@ -62,6 +62,7 @@ def load_library():
         "kfsp_matrix_bytes": [vp, C.c_int, C.POINTER(i64)],
         "kfsp_num_states": [vp, C.POINTER(i64)],
         "kfsp_layout_info": [vp, vp],
+        "kfsp_build_info": [vp, vp],
         "kfsp_set_trip_order": [vp, i64, vp],
         "kfsp_onestep": [vp, i32, i32, vp, i32, vp, i32, vp, i32, i32, i32, C.POINTER(i32), vp, vp],
         "kfsp_onestep_columns": [vp, i32, i32, vp, i32, vp, i32, vp, i32, i32, i32, C.POINTER(i32), vp, vp, vp, i32, vp],
@@ -493,6 +494,12 @@ class KfspContext:
         self._chk(self._lib.kfsp_layout_info(self._h, _p(v)), "kfsp_layout_info")
         keys = ("format", "exchange", "halo_rows", "sell_reach", "coded_chunks", "chunks", "code_words", "state_order")
         return dict(zip(keys, (int(x) for x in v)))
+
+    def build_info(self):
+        """how the rebuilds of a resident FSP went (kfsp_build_info)"""
+        v = np.zeros(6, dtype=np.int64)
+        self._chk(self._lib.kfsp_build_info(self._h, _p(v)), "kfsp_build_info")
+        return dict(zip(("speculative", "repeated", "sell", "key_layout_cached", "orders_carried_over"), (int(x) for x in v)))
 
     def set_vector(self, w):
         w = np.ascontiguousarray(w, dtype=np.float64)

@@ -71,6 +71,7 @@ def test_resident_expansion_equals_the_two_calls_on_host_lists(golden_dir, name,
             x.set_option("state_order", order)
             x.set_option("state_order_min", 64)
             x.set_option("state_order_products", 0)
+        ref.set_option("build_speculate", 0)              # (the reference side waits for every number and insertion-sorts its rows)
         off, diag = c.propensities(state)
         n = len(state)
         t = 2.0 / float(np.mean(diag[diag > 0]))
@@ -114,6 +115,7 @@ def test_drop_rebuild_expand_cycle_stays_on_the_device(golden_dir):
             x.set_propensity_program(ns, params, progs)
             x.set_option("state_order_min", 64)
             x.set_option("state_order_products", 0)
+        ref.set_option("build_speculate", 0)              # (the reference side waits for every number and insertion-sorts its rows)
         off, diag = c.propensities(state)
         c.set_option("keep_coords", 1)
         c.set_state_coords(state)
@@ -156,6 +158,46 @@ def test_drop_rebuild_expand_cycle_stays_on_the_device(golden_dir):
             w = np.abs(x) * np.where(np.arange(n2) >= n2 // 2, 1e-14, 1.0)
             w /= w.sum()
             c.set_vector(w)
+        info = c.build_info()
+        assert info["speculative"] + info["repeated"] >= 6 and info["sell"] == 1, info     # 3 drops + 3 expansions, none the slow way first
+        assert info["orders_carried_over"] >= 5, info      # (compacted after a drop, the appended keys merged in after an expansion)
+        assert ref.build_info()["speculative"] == 0
+
+
+def test_a_speculation_that_does_not_hold_is_repeated_the_slow_way(golden_dir):
+    """The resident FSP is re-ordered with the key layout of the LAST order (fields as wide as the bits they occupy) and
+    rebuilt as the SELL generator the last one was, with one synchronisation at the end (option build_speculate).  Growing
+    an FSP until a population crosses a power of two makes the cached layout too narrow: the check at the end must see it
+    and repeat order and build - the generator is the one a fresh upload of the same lists gives, bit for bit, every time."""
+    from krylovfspssa_amd import KfspContext
+    rng = np.random.default_rng(17)
+    with KfspContext(0) as c, KfspContext(0) as ref:
+        nu, state, adj = _grown(c, "goutsias_k16", golden_dir, 2)
+        nr, ns = nu.shape
+        params, progs = _mass_action(nu)
+        for x in (c, ref):
+            x.set_propensity_program(ns, params, progs)
+            x.set_option("state_order_min", 64)
+            x.set_option("state_order_products", 0)
+        ref.set_option("build_speculate", 0)
+        off, diag = c.propensities(state)
+        c.set_option("keep_coords", 1)
+        c.set_state_coords(state)
+        c.set_matrix_ell(adj, off, diag)
+        c.set_vector(np.full(len(state), 1.0 / len(state)))
+        top = int(state.max())
+        for step in range(12):
+            n2, _ = c.expand_resident(4.0 / float(np.mean(diag[diag > 0])), 77 + step, nu, max_count=100000)
+            state, adj, off, diag = c.download_fsp(ns, nr)
+            assert len(state) == n2
+            ref.set_state_coords(state)
+            ref.set_matrix_ell(adj, off, diag)
+            x = rng.random(n2)
+            assert np.array_equal(c.spmv(x), ref.spmv(x)), step
+            info = c.build_info()
+            if info["repeated"] >= 1 and info["speculative"] >= 1:
+                break
+        assert info["repeated"] >= 1 and info["speculative"] >= 1, (info, top, int(state.max()), n2)
 
 
 @pytest.mark.parametrize("P", [2, 3])
