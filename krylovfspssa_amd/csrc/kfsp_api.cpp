@@ -2253,7 +2253,7 @@ int kfsp_drop_rebuild(kfsp_ctx *ctx)
         ctx->perm_pending_n = 0;
         ctx->coords_n = 0;
         bool ordered = false;
-        const bool spec = ctx->opt_build_speculate && !ctx->use_comm;
+        const bool spec = ctx->opt_build_speculate != 0;    // (under a row partition too: order and build are rank-local, every rank repeats the same checks)
         if (coords && want_order) {
             // (the kept states keep their relative order: compact the order that is here, or make it from the coordinates)
             int rc = 0;
@@ -2345,7 +2345,7 @@ int kfsp_expand_resident(kfsp_ctx *ctx, double t_ssa, int64_t seedmix, int32_t n
         const bool want_order = ctx->opt_state_order && n2 >= ctx->opt_state_order_min && ctx->prod_count >= ctx->opt_state_order_products;
         ctx->perm_pending_n = 0;
         bool ordered = false;
-        const bool spec = ctx->opt_build_speculate && !ctx->use_comm;
+        const bool spec = ctx->opt_build_speculate != 0;    // (under a row partition too: order and build are rank-local, every rank repeats the same checks)
         if (want_order)
             if (int rc2 = kfsp::state_order_from_resident(ctx, (int32_t)n2, ns, cld, &ordered, spec, (int32_t)n)) return rc2;
         ctx->coords_n = n2;

@@ -237,8 +237,11 @@ def test_resident_expansion_under_a_row_partition(golden_dir, P, order):
             nk = c.drop_compact()
             c.drop_rebuild()
             n3, _ = c.expand_resident(t, 4243, nu)
-            res[-1].update(nk=nk, n3=n3, lists3=c.download_fsp(ns, nr), w3=c.get_vector())
+            res[-1].update(nk=nk, n3=n3, lists3=c.download_fsp(ns, nr), w3=c.get_vector(), info=c.build_info())
     a, b = res
+    # (the ranks of the partition rebuild speculatively and carry their order over as one context does: 2 expansions + 1 drop)
+    assert b["info"]["speculative"] + b["info"]["repeated"] >= 3, b["info"]
+    assert b["info"]["orders_carried_over"] >= (2 if order else 0), b["info"]
     assert (a["n2"], a["nssa"], a["nk"], a["n3"]) == (b["n2"], b["nssa"], b["nk"], b["n3"]) and a["nssa"] > 0 and a["n2"] > a["nssa"]
     for u, v in zip(a["lists"] + a["lists3"], b["lists"] + b["lists3"]):
         assert np.array_equal(u, v)
