@@ -926,6 +926,7 @@ int kfsp_destroy(kfsp_ctx *ctx)
     ctx->d_perm.release(); ctx->d_iperm.release(); ctx->d_coords.release(); ctx->d_coords2.release(); ctx->d_ell_adj2.release();
     ctx->d_ell_off2.release(); ctx->d_ell_diag2.release(); ctx->d_pstage.release(); ctx->d_keys.release();
     ctx->d_sortidx.release(); ctx->d_sorttmp.release(); ctx->d_gmask.release(); ctx->d_zero.release();
+    ctx->d_skeys.release(); ctx->d_skeys2.release(); ctx->d_perm2.release();
     if (ctx->h_loop) (void)hipHostFree(ctx->h_loop);
     if (ctx->h_H) (void)hipHostFree(ctx->h_H);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);

@@ -295,31 +295,31 @@ __global__ __launch_bounds__(kBlock) void k_chunk_width(int64_t nchunks, int64_t
     off[c + 1] = (int64_t)w * kChunk;                      // scanned in place next
 }
 
-// exclusive scan of off[1..nchunks] by one workgroup (nchunks <= a few 1e5)
+// exclusive scan of off[1..nchunks] by one workgroup (nchunks <= a few 1e5): every thread sums its stretch, the 1024 sums
+// are scanned by wavefront shuffles (a single thread walking them through LDS took 20 of this kernel's 23 us), every thread
+// writes its stretch.  Integers: the same offsets in whatever order they are added.
 __global__ __launch_bounds__(1024) void k_scan_offsets(int64_t nchunks, int64_t *__restrict__ off)
 {
-    __shared__ int64_t part[1024];
-    const int t = threadIdx.x;
+    __shared__ int64_t wsum[16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int64_t per = (nchunks + 1023) / 1024;
     const int64_t b = (int64_t)t * per, e = min(nchunks, b + per);
     int64_t s = 0;
     for (int64_t c = b; c < e; ++c) s += off[c + 1];
-    part[t] = s;
-    __syncthreads();
-    if (t == 0) {
-        int64_t run = 0;
-        for (int i = 0; i < 1024; ++i) {
-            const int64_t v = part[i];
-            part[i] = run;
-            run += v;
-        }
-        off[0] = 0;
+    int64_t v = s;                                          // inclusive over the wavefront
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int64_t u = __shfl_up(v, d, 64);
+        if (lane >= d) v += u;
     }
+    if (lane == 63) wsum[wave] = v;
     __syncthreads();
-    int64_t run = part[t];
+    int64_t run = v - s;                                    // exclusive: what lies in front of this thread's stretch
+    for (int w = 0; w < wave; ++w) run += wsum[w];
+    if (t == 0) off[0] = 0;
     for (int64_t c = b; c < e; ++c) {
-        const int64_t v = off[c + 1];
-        run += v;
+        const int64_t x = off[c + 1];
+        run += x;
         off[c + 1] = run;
     }
 }
