@@ -238,7 +238,7 @@ struct kfsp_ctx {
     // generator is built - a failed check repeats order and build the slow way.  kc_*: the key layout of the last state
     // order (each species' field widened to its full bit width), valid while every coordinate stays inside [kc_lo, kc_hi].
     char *h_build = nullptr;
-    bool kc_ok = false, order_check = false, last_build_sell = false;
+    bool kc_ok = false, order_check = false, last_build_sell = false, h_build_ready = false;
     int kc_ns = 0, kc_bits = 0, kc_lo[16] = {0}, kc_hi[16] = {0}, kc_shift[16] = {0};
     int64_t opt_build_speculate = 1, spec_builds = 0, spec_redone = 0;
     // the sorted keys of the current order (d_perm) and for how many states both are valid: an expansion merges the appended

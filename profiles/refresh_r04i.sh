@@ -1,10 +1,10 @@
 #!/bin/bash
 # Round 4: the speculative rebuild of the resident FSP (option build_speculate): its tests, then the resident Goutsias run
-# (T = 300) with the option off and on, and the kernel statistics of the run with it on.
+# (T = 300) with the option off and on (kernel statistics of the run with it on: profiles/r04_e2e_resident_goutsias_kernel_stats.csv).
 R=$PWD
 O=$R/gpurun_out/r04
 mkdir -p $O
-timeout -k 10 900 python -m pytest tests/test_gpu_expand.py tests/test_gpu_drop.py tests/test_gpu_edge_cases.py tests/test_fortran_host.py tests/test_gpu_group.py -m gpu -x -q > $O/i_tests.log 2>&1
+timeout -k 10 900 python -m pytest tests/test_gpu_expand.py tests/test_gpu_drop.py tests/test_gpu_edge_cases.py -m gpu -x -q > $O/i_tests.log 2>&1
 echo "tests rc=$?"; tail -5 $O/i_tests.log
 cd tests/golden/models
 D=$R/krylovfspssa_amd/fortran/_build/kfsp_dump
@@ -16,7 +16,4 @@ for s in 0 1; do
 done
 done
 cmp /tmp/p0.bin /tmp/p1.bin && echo "dumps identical"
-export TMPDIR=/tmp
-KFSP_SSA_STREAMS=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/spec_prof -o spec -- $D solve goutsias_input /tmp/p2.bin 300.0 > $O/spec_prof.log 2>&1
-f=$(ls $O/spec_prof/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && head -25 $f | cut -c1-160
 cd $R
