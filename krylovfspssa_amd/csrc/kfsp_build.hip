@@ -156,6 +156,13 @@ __global__ __launch_bounds__(kBlock) void k_coord_minmax(int64_t n, int ns, int 
     }
 }
 
+// the pinned block of a context (h_build, 8 KB): where the numbers of a speculative rebuild land, and the constants it uploads
+constexpr size_t kHbStats = 0;            // ScanOut: the link statistics of the build
+constexpr size_t kHbSlots = 2048;         // int64: SELL slots
+constexpr size_t kHbRanges = 2304;        // int[32]: min / max of every species' count over the states that were packed
+constexpr size_t kHbRangesInit = 2560;    // int[32]: what those start from
+constexpr size_t kHbStatsInit = 4096;     // ScanOut: what the statistics start from
+
 struct KeyLayout {
     int ns;
     int lo[16];
@@ -560,7 +567,7 @@ int build_from_resident_ell(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, bo
     // (the initial statistics come from the pinned block: a copy from pageable memory makes the host wait for everything
     // enqueued before it - one more hidden synchronisation per rebuild)
     static_assert(sizeof(ScanOut) <= 2048, "h_build layout");
-    ScanOut &init = *reinterpret_cast<ScanOut *>(ctx->h_build + 4096);
+    ScanOut &init = *reinterpret_cast<ScanOut *>(ctx->h_build + kHbStatsInit);
     if (!ctx->h_build_ready) {
         for (int j = 0; j < kMaxBw; ++j) {
             init.dmin[j] = INT_MAX;
@@ -579,7 +586,7 @@ int build_from_resident_ell(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, bo
     const bool spec = speculate && ctx->last_build_sell && ctx->h_build && nloc > 0 &&
                       !(ctx->perm_on && ctx->opt_sell_sigma >= 128) && (double)nact * (double)bw * 12.0 <= 16e9;
     ScanOut res_stack;
-    ScanOut &res = spec ? *reinterpret_cast<ScanOut *>(ctx->h_build) : res_stack;
+    ScanOut &res = spec ? *reinterpret_cast<ScanOut *>(ctx->h_build + kHbStats) : res_stack;
     HIP_TRY_B(hipMemcpyAsync(&res, dscan, sizeof(res), hipMemcpyDeviceToHost, st));
     if (!spec) {
         HIP_TRY_B(hipStreamSynchronize(st));
@@ -625,7 +632,7 @@ int build_from_resident_ell(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, bo
         hipLaunchKernelGGL(k_chunk_width, dim3((int)((nchunks + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, nchunks, nloc,
                            ctx->d_cnt.p, ctx->d_off.p);
         hipLaunchKernelGGL(k_scan_offsets, dim3(1), dim3(1024), 0, st, nchunks, ctx->d_off.p);
-        int64_t *hslots = reinterpret_cast<int64_t *>(ctx->h_build + 2048);
+        int64_t *hslots = reinterpret_cast<int64_t *>(ctx->h_build + kHbSlots);
         HIP_TRY_B(hipMemcpyAsync(hslots, ctx->d_off.p + nchunks, sizeof(int64_t), hipMemcpyDeviceToHost, st));
         hipLaunchKernelGGL(k_sell_init, dim3((int)((nchunks + 3) / 4)), dim3(kBlock), 0, st, nchunks, nloc, row0, ctx->d_off.p,
                            ctx->d_col.p, ctx->d_val.p, ell_diag, ctx->d_diag.p);
@@ -1102,8 +1109,8 @@ int state_order_from_resident(kfsp_ctx *ctx, int32_t n, int32_t ns, int32_t ld, 
                        ctx->opt_sell_sigma < 128;
     const int64_t first = merge ? n_prev : 0, count = (int64_t)n - first;      // the states whose keys are made now
     int mm_stack[32];
-    int *mm = spec ? reinterpret_cast<int *>(ctx->h_build + 2304) : mm_stack;      // (pinned: the copy back does not stop the host)
-    int *mm_init = spec ? reinterpret_cast<int *>(ctx->h_build + 2560) : mm_stack;
+    int *mm = spec ? reinterpret_cast<int *>(ctx->h_build + kHbRanges) : mm_stack;      // (pinned: the copy back does not stop the host)
+    int *mm_init = spec ? reinterpret_cast<int *>(ctx->h_build + kHbRangesInit) : mm_stack;
     for (int k = 0; k < ns; ++k) {
         mm_init[2 * k] = INT_MAX;
         mm_init[2 * k + 1] = INT_MIN;
@@ -1234,7 +1241,7 @@ bool state_order_check(kfsp_ctx *ctx)
 {
     if (!ctx->order_check) return true;
     ctx->order_check = false;
-    const int *mm = reinterpret_cast<const int *>(ctx->h_build + 2304);
+    const int *mm = reinterpret_cast<const int *>(ctx->h_build + kHbRanges);
     for (int k = 0; k < ctx->kc_ns; ++k)
         if (mm[2 * k] < ctx->kc_lo[k] || mm[2 * k + 1] > ctx->kc_hi[k]) {
             ctx->kc_ok = false;
