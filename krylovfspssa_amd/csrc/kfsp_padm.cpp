@@ -63,7 +63,7 @@ inline void swap_storage(Dense &x, Dense &y) { std::swap(x.a.p, y.a.p); }
     const double *a = A.a.data();                                                             \
     const double *b = B.a.data();                                                             \
     double *c = C.a.data();                                                                   \
-    for (int j = 0; j < m; ++j) {                                                             \
+    for (int j = jbeg; j < jend; ++j) {                                                       \
         double *__restrict__ cj = c + (size_t)j * m;                                          \
         for (int i = 0; i < m; ++i) cj[i] = 0.0;                                              \
         int idx[4];                                                                           \
@@ -93,12 +93,13 @@ inline void swap_storage(Dense &x, Dense &y) { std::swap(x.a.p, y.a.p); }
         }                                                                                     \
     }
 
-void matmul_base(double alpha, const Dense &A, const Dense &B, Dense &C) { KFSP_MATMUL_BODY }
-__attribute__((target("avx2,fma"))) void matmul_avx2(double alpha, const Dense &A, const Dense &B, Dense &C)
+// (columns jbeg .. jend - 1 of the product: a column is made by the same expressions whoever makes it)
+void matmul_base(double alpha, const Dense &A, const Dense &B, Dense &C, int jbeg, int jend) { KFSP_MATMUL_BODY }
+__attribute__((target("avx2,fma"))) void matmul_avx2(double alpha, const Dense &A, const Dense &B, Dense &C, int jbeg, int jend)
 {
     KFSP_MATMUL_BODY
 }
-__attribute__((target("avx512f,avx512vl,fma"))) void matmul_avx512(double alpha, const Dense &A, const Dense &B, Dense &C)
+__attribute__((target("avx512f,avx512vl,fma"))) void matmul_avx512(double alpha, const Dense &A, const Dense &B, Dense &C, int jbeg, int jend)
 {
     KFSP_MATMUL_BODY
 }
@@ -273,7 +274,9 @@ public:
 private:
     PadePool()
     {
-        // (default: 4 threads on a host with >= 16 CPUs - the MI355X boxes give a one-GPU job 16 -, none on a smaller one)
+        // (default: 4 threads on a host with >= 16 CPUs - the MI355X boxes give a one-GPU job 16; the resident Goutsias run
+        // spends 0.61 / 0.37 s in here with 1 / 4, and between 0.32 and 0.59 s with 6 depending on what else the host is
+        // doing: spinning workers on a shared machine -, none on a smaller one)
         const int hw = (int)std::thread::hardware_concurrency();
         int want = hw >= 16 ? 4 : 1;
         if (const char *e = std::getenv("KFSP_PADE_THREADS")) want = std::atoi(e);
@@ -354,9 +357,15 @@ void matmul(double alpha, const Dense &A, const Dense &B, Dense &C)
         return;
     }
     ProfTimer pt(g_prof[1]);
-    if (wider) matmul_avx512(alpha, A, B, C);
-    else if (wide) matmul_avx2(alpha, A, B, C);
-    else matmul_base(alpha, A, B, C);
+    const int m = A.m;
+    auto part = [&](int jbeg, int jend) {
+        if (wider) matmul_avx512(alpha, A, B, C, jbeg, jend);
+        else if (wide) matmul_avx2(alpha, A, B, C, jbeg, jend);
+        else matmul_base(alpha, A, B, C, jbeg, jend);
+    };
+    // (measured with the columns dealt to the pool as the dense products' are: 93 -> 103-120 ms over the resident Goutsias run -
+    // a banded product is a few microseconds, less than the threads' hand-shake)
+    part(0, m);
 }
 
 // X <- Q^{-1} X: LU with row pivoting, then forward and back substitution, all
@@ -368,23 +377,30 @@ bool solve_in_place(Dense &Q, Dense &X)
     const int m = Q.m;
     double *q = Q.a.data();
     double *x = X.a.data();
+    // The factorisation touches Q only; what it does to the right-hand sides - the row exchange and the multipliers of
+    // every step - is kept (piv, last; the multipliers sit below Q's diagonal) and applied afterwards, column by column:
+    // the columns of X are independent, every element sees the same operations in the same order as when they were
+    // applied step by step inside the factorisation, and the column ranges can go to the pool's threads.
+    static thread_local std::vector<int> piv, lastrow, top;
+    piv.resize((size_t)m);
+    lastrow.resize((size_t)m);
+    top.resize((size_t)m);
     for (int k = 0; k < m; ++k) {
         double *qk = q + (size_t)k * m;
         int p = k;
         for (int i = k + 1; i < m; ++i)
             if (std::fabs(qk[i]) > std::fabs(qk[p])) p = i;
         if (qk[p] == 0.0) return false;
+        piv[(size_t)k] = p;
         if (p != k)
-            for (int j = 0; j < m; ++j) {
-                std::swap(q[(size_t)j * m + k], q[(size_t)j * m + p]);
-                std::swap(x[(size_t)j * m + k], x[(size_t)j * m + p]);
-            }
+            for (int j = 0; j < m; ++j) std::swap(q[(size_t)j * m + k], q[(size_t)j * m + p]);
         const double inv = 1.0 / qk[k];
         int last = k;                                    // last row with a non-zero multiplier
         for (int i = k + 1; i < m; ++i) {
             qk[i] *= inv;
             if (qk[i] != 0.0) last = i;
         }
+        lastrow[(size_t)k] = last;
         if (last == k) continue;
         for (int j = k + 1; j < m; ++j) {                // trailing update, column by column
             double *qj = q + (size_t)j * m;
@@ -392,31 +408,43 @@ bool solve_in_place(Dense &Q, Dense &X)
             if (f == 0.0) continue;
             for (int i = k + 1; i <= last; ++i) qj[i] -= qk[i] * f;
         }
-        for (int j = 0; j < m; ++j) {                    // L^{-1} applied to the right-hand sides
-            double *xj = x + (size_t)j * m;
-            const double f = xj[k];
-            if (f == 0.0) continue;
-            for (int i = k + 1; i <= last; ++i) xj[i] -= qk[i] * f;
-        }
     }
     // first non-zero row of every column of U: banded factors stay banded
-    std::vector<int> top((size_t)m);
     for (int k = 0; k < m; ++k) {
         const double *qk = q + (size_t)k * m;
         int f = 0;
         while (f < k && qk[f] == 0.0) ++f;
         top[(size_t)k] = f;
     }
-    for (int j = 0; j < m; ++j) {                        // U^{-1}, column-oriented back substitution
-        double *xj = x + (size_t)j * m;
-        for (int k = m - 1; k >= 0; --k) {
-            const double *qk = q + (size_t)k * m;
-            const double v = xj[k] / qk[k];
-            xj[k] = v;
-            if (v == 0.0) continue;
-            for (int i = top[(size_t)k]; i < k; ++i) xj[i] -= qk[i] * v;
+    const int *pv = piv.data(), *lr = lastrow.data(), *tp = top.data();
+    auto columns = [=](int jbeg, int jend) {
+        for (int j = jbeg; j < jend; ++j) {
+            double *xj = x + (size_t)j * m;
+            for (int k = 0; k < m; ++k) {                // P and L^{-1}, step by step
+                if (pv[k] != k) std::swap(xj[k], xj[pv[k]]);
+                const int last = lr[k];
+                if (last == k) continue;
+                const double *qk = q + (size_t)k * m;
+                const double f = xj[k];
+                if (f == 0.0) continue;
+                for (int i = k + 1; i <= last; ++i) xj[i] -= qk[i] * f;
+            }
+            for (int k = m - 1; k >= 0; --k) {           // U^{-1}, column-oriented back substitution
+                const double *qk = q + (size_t)k * m;
+                const double v = xj[k] / qk[k];
+                xj[k] = v;
+                if (v == 0.0) continue;
+                for (int i = tp[k]; i < k; ++i) xj[i] -= qk[i] * v;
+            }
         }
+    };
+    PadePool &pool = PadePool::get();
+    const int T = m >= 48 ? pool.threads() : 1;
+    if (T <= 1) {
+        columns(0, m);
+        return true;
     }
+    pool.run([&](int t) { columns((int)((long long)m * t / T), (int)((long long)m * (t + 1) / T)); });
     return true;
 }
 
