@@ -282,6 +282,7 @@ private:
         if (const char *e = std::getenv("KFSP_PADE_THREADS")) want = std::atoi(e);
         if (hw > 0) want = std::min(want, std::max(1, hw / 2));
         nthreads_ = std::max(1, std::min(want, 16));
+        if (const char *e = std::getenv("KFSP_PADE_SPIN_US")) spin_us_ = std::max(0.0, std::atof(e));
         for (int t = 1; t < nthreads_; ++t) {
             try {
                 std::thread(&PadePool::worker, this, t).detach();
@@ -296,12 +297,18 @@ private:
         if (g_have_initial_cpus) (void)sched_setaffinity(0, sizeof(g_initial_cpus), &g_initial_cpus);
         uint64_t seen = 0;
         for (;;) {
+            // a worker spins for spin_us_ after its last job before it goes to sleep: the exponentials of a solve follow each
+            // other every 1-2 ms (an Arnoldi pass on the device lies between them), and a sleeping worker costs the next
+            // product a futex wake-up
             int spins = 0;
+            auto t_idle = std::chrono::steady_clock::now();
             while (gen_.load(std::memory_order_acquire) == seen) {
-                if (++spins < 20000) {
+                if (++spins < 256) {
                     _mm_pause();
                     continue;
                 }
+                spins = 0;
+                if (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_idle).count() < spin_us_) continue;
                 std::unique_lock<std::mutex> lk(mu_);
                 sleepers_.fetch_add(1, std::memory_order_acq_rel);
                 cv_.wait(lk, [&] { return gen_.load(std::memory_order_acquire) != seen; });
@@ -313,6 +320,7 @@ private:
         }
     }
     int nthreads_ = 1;
+    double spin_us_ = 800.0;
     std::function<void(int)> job_;
     std::atomic<uint64_t> gen_{0};
     std::atomic<int> remaining_{0}, sleepers_{0};
