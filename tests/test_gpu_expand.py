@@ -200,6 +200,58 @@ def test_a_speculation_that_does_not_hold_is_repeated_the_slow_way(golden_dir):
         assert info["repeated"] >= 1 and info["speculative"] >= 1, (info, top, int(state.max()), n2)
 
 
+def test_random_sequences_of_drops_and_expansions_keep_the_carried_order_right(golden_dir):
+    """24 FSP changes in random order - expansions of random horizons, drops of random depth, two drops in a row, the state
+    order switched off for a while (the carried order must not survive that) and on again: after every change the resident
+    generator multiplies exactly as one uploaded from the downloaded lists into a context that sorts every key and waits for
+    every number (build_speculate = 0)."""
+    from krylovfspssa_amd import KfspContext
+    rng = np.random.default_rng(2026)
+    with KfspContext(0) as c, KfspContext(0) as ref:
+        nu, state, adj = _grown(c, "goutsias_k16", golden_dir, 3)
+        nr, ns = nu.shape
+        params, progs = _mass_action(nu)
+        for x in (c, ref):
+            x.set_propensity_program(ns, params, progs)
+            x.set_option("state_order_min", 64)
+            x.set_option("state_order_products", 0)
+        ref.set_option("build_speculate", 0)
+        off, diag = c.propensities(state)
+        c.set_option("keep_coords", 1)
+        c.set_state_coords(state)
+        c.set_matrix_ell(adj, off, diag)
+        n = len(state)
+        carried = 0
+        for step in range(24):
+            if step in (8, 16):                                   # the order off for four changes, then on again
+                c.set_option("state_order", 0)
+            if step in (12, 20):
+                c.set_option("state_order", 1)
+            w = rng.random(n) * np.where(rng.random(n) < rng.uniform(0.2, 0.6), 1e-14, 1.0)
+            c.set_vector(w / w.sum())
+            drop = n > 3000 and rng.random() < 0.5
+            if drop:
+                _, _, nflag = c.drop_plan(1e-7)
+                if nflag == 0 or nflag == n:
+                    drop = False
+                else:
+                    n = c.drop_compact()
+                    c.drop_rebuild()
+            if not drop:
+                t = float(rng.uniform(0.5, 3.0)) / float(np.mean(diag[diag > 0]))
+                n, _ = c.expand_resident(t, int(rng.integers(1, 2 ** 31 - 2)), nu, max_count=100000)
+            state, adj, off, diag = c.download_fsp(ns, nr)
+            assert len(state) == n
+            ref.set_option("state_order", 1 if c.state_order_active() else 0)
+            ref.set_state_coords(state)
+            ref.set_matrix_ell(adj, off, diag)
+            x = rng.random(n)
+            assert np.array_equal(c.spmv(x), ref.spmv(x)), (step, drop, n)
+            carried = c.build_info()["orders_carried_over"]
+        info = c.build_info()
+        assert info["speculative"] >= 12 and carried >= 8, info
+
+
 @pytest.mark.parametrize("P", [2, 3])
 @pytest.mark.parametrize("order", [0, 1])
 def test_resident_expansion_under_a_row_partition(golden_dir, P, order):
