@@ -926,7 +926,7 @@ int kfsp_destroy(kfsp_ctx *ctx)
     ctx->d_perm.release(); ctx->d_iperm.release(); ctx->d_coords.release(); ctx->d_coords2.release(); ctx->d_ell_adj2.release();
     ctx->d_ell_off2.release(); ctx->d_ell_diag2.release(); ctx->d_pstage.release(); ctx->d_keys.release();
     ctx->d_sortidx.release(); ctx->d_sorttmp.release(); ctx->d_gmask.release(); ctx->d_zero.release();
-    ctx->d_skeys.release(); ctx->d_skeys2.release(); ctx->d_perm2.release();
+    ctx->d_skeys.release(); ctx->d_skeys2.release(); ctx->d_perm2.release(); ctx->d_prop_fast_i.release(); ctx->d_prop_fast_d.release();
     if (ctx->h_loop) (void)hipHostFree(ctx->h_loop);
     if (ctx->h_H) (void)hipHostFree(ctx->h_H);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
@@ -2584,6 +2584,7 @@ int kfsp_set_option(kfsp_ctx *ctx, const char *name, int64_t value)
     else if (k == "halo_sell") ctx->opt_halo_sell = value;
     else if (k == "sell_sigma") ctx->opt_sell_sigma = value;
     else if (k == "build_speculate") ctx->opt_build_speculate = value != 0;
+    else if (k == "ssa_regs") ctx->opt_ssa_regs = value != 0;
     else if (k == "overlap") ctx->opt_overlap = value;
     else if (k == "small_kernel") ctx->opt_small = value;
     else if (k == "m_max") {

@@ -241,6 +241,7 @@ struct kfsp_ctx {
     bool kc_ok = false, order_check = false, last_build_sell = false, h_build_ready = false;
     int kc_ns = 0, kc_bits = 0, kc_lo[16] = {0}, kc_hi[16] = {0}, kc_shift[16] = {0};
     int64_t opt_build_speculate = 1, spec_builds = 0, spec_redone = 0;
+    int64_t opt_ssa_regs = 1;             // the walk evaluates unlisted states from descriptors in registers when the program allows it
     // the sorted keys of the current order (d_perm) and for how many states both are valid: an expansion merges the appended
     // states' keys into them, a drop compacts them (state_order_from_resident, state_order_after_drop)
     DevBuf<unsigned long long> d_skeys, d_skeys2;
@@ -279,6 +280,12 @@ struct kfsp_ctx {
     // the program runs through prop_eval_light: whatever the populations / as long as they stay below prop_tab_len (its
     // library functions sit in tabulated reactions only)
     bool prop_light = false, prop_light_tab = false;
+    // every reaction is a product chain of at most three operands with at most one constant among them, or sits behind a
+    // one-species table: the register-resident walk evaluates an unlisted state from descriptors it keeps in registers
+    // (d_prop_fast_i: one word per reaction, d_prop_fast_d: its constant; kfsp_ssa.hip)
+    bool prop_fast = false;
+    DevBuf<int32_t> d_prop_fast_i;
+    DevBuf<double> d_prop_fast_d;
     int prop_ncode = 0, prop_nimm = 0;
     size_t prop_mono_off = 0, prop_monoc_off = 0;      // where the product-chain tables sit in d_prop_i / d_prop_d
     int prop_ns = 0, prop_nr = 0, prop_np = 0, prop_np_pad = 1, prop_nimm_pad = 1, prop_tab_len = 0;

@@ -137,6 +137,31 @@ int prop_set_program(kfsp_ctx *ctx, int32_t ns, int32_t nr, int32_t np, const do
         if (ok && (len == 1 || (len >= 3 && len % 2 == 1)) && n == (len + 1) / 2) m[0] = n;
         else m[0] = 0;
     }
+    // descriptors for the walk's register path: bits 0-2 operands of a chain (0: the reaction reads its one-species table),
+    // bits 4-7 / 8-11 / 12-15 the species of operand 1 / 2 / 3 (15: the chain's one constant), table: bits 4-7 its species
+    std::vector<int32_t> fast_i((size_t)std::max(nr, 1), 0);
+    std::vector<double> fast_d((size_t)std::max(nr, 1), 0.0);
+    bool fast_ok = ns <= 8;
+    for (int k = 0; k < nr && fast_ok; ++k) {
+        const int32_t *m = mono.data() + (size_t)k * (1 + kPropMonoOps);
+        const double *mc = mono_c.data() + (size_t)k * kPropMonoOps;
+        if (m[0] >= 1 && m[0] <= 3) {
+            int d = m[0], nconst = 0;
+            for (int i = 0; i < m[0]; ++i) {
+                if (m[1 + i] < 0) {
+                    ++nconst;
+                    fast_d[(size_t)k] = mc[i];
+                    d |= 15 << (4 + 4 * i);
+                } else
+                    d |= m[1 + i] << (4 + 4 * i);
+            }
+            if (nconst > 1) fast_ok = false;
+            fast_i[(size_t)k] = d;
+        } else if (m[0] == 0 && tab_species[k] >= 0 && tab_len > 0) {
+            fast_i[(size_t)k] = tab_species[k] << 4;
+        } else
+            fast_ok = false;
+    }
     hipStream_t st = ctx->stream;
     std::vector<int32_t> ib((size_t)(2 * (nr + 1) + nr + std::max(ncode, 1)));
     std::memcpy(ib.data(), code_off, sizeof(int32_t) * (size_t)(nr + 1));
@@ -157,7 +182,12 @@ int prop_set_program(kfsp_ctx *ctx, int32_t ns, int32_t nr, int32_t np, const do
     HIP_TRY_P(ctx->d_prop_d.reserve(db.size(), false));
     HIP_TRY_P(hipMemcpyAsync(ctx->d_prop_i.p, ib.data(), ib.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
     HIP_TRY_P(hipMemcpyAsync(ctx->d_prop_d.p, db.data(), db.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY_P(ctx->d_prop_fast_i.reserve(fast_i.size(), false));
+    HIP_TRY_P(ctx->d_prop_fast_d.reserve(fast_d.size(), false));
+    HIP_TRY_P(hipMemcpyAsync(ctx->d_prop_fast_i.p, fast_i.data(), fast_i.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY_P(hipMemcpyAsync(ctx->d_prop_fast_d.p, fast_d.data(), fast_d.size() * sizeof(double), hipMemcpyHostToDevice, st));
     HIP_TRY_P(hipStreamSynchronize(st));
+    ctx->prop_fast = fast_ok;
     ctx->prop_ns = ns;
     ctx->prop_nr = nr;
     ctx->prop_np = np;

@@ -49,6 +49,8 @@ struct SsaDev {
     // else all of them, [0, nwaves))
     long long wave0, wave1;
     PropDev P;
+    const int32_t *fast_i;     // descriptors of the register path (kfsp_prop.hip prop_set_program), one per reaction
+    const double *fast_d;
 };
 
 // index (1-based) of state y among the listed ones, 0 = not listed
@@ -299,7 +301,24 @@ __device__ __forceinline__ int lookup_regs(const SsaDev &A, const int32_t (&y)[N
     }
 }
 
-template <int NS, int NR, bool LIGHT>
+// x[s] for a run-time s (the same in every lane) out of the registers: a chain of selects, no memory
+template <int NS>
+__device__ __forceinline__ int x_select(const int32_t (&x)[NS], int s)
+{
+    int v = x[0];
+#pragma unroll
+    for (int i = 1; i < NS; ++i) v = s == i ? x[i] : v;
+    return v;
+}
+
+// REGS: every reaction of the program is a product chain of at most three operands (one constant among them at most) or
+// reads its one-species table, and the wavefront keeps one descriptor word and one constant per reaction in registers
+// (SsaDev::fast_i / fast_d).  An unlisted state - every jump of a path once it has left the FSP at its rim, the paths
+// a launch waits for - is then evaluated without a trip to memory except the tables': the interpreter reads the
+// program word by word from LDS, one dependent load after the other, and the state through scratch memory because it
+// indexes it at run time.  The chain ((o1 * o2) * o3) is multiplied in the code's order, the table entry is the table
+// entry, a population beyond the table goes to the interpreter as before: same bits, same paths, same records.
+template <int NS, int NR, bool LIGHT, bool REGS = false>
 __global__ __launch_bounds__(kBlock) void k_ssa_walk(SsaDev A, unsigned long long *__restrict__ nrec_total, long long cap,
                                                      unsigned long long *__restrict__ keys, int32_t *__restrict__ rec)
 {
@@ -366,6 +385,19 @@ __global__ __launch_bounds__(kBlock) void k_ssa_walk(SsaDev A, unsigned long lon
         pr[k] = 0.0;
         aj[k] = 0;
     }
+    int32_t fd[REGS ? NR : 1];
+    double fc[REGS ? NR : 1];
+    if (REGS) {
+#pragma unroll
+        for (int k = 0; k < (REGS ? NR : 1); ++k) {
+            fd[k] = 0;
+            fc[k] = 0.0;
+            if (k < A.nr) {
+                fd[k] = A.fast_i[k];
+                fc[k] = A.fast_d[k];
+            }
+        }
+    }
     // the row of a listed state is REQUESTED as soon as the state is known (when a path starts, and at the end of the
     // jump that reaches it) and USED after the next jump's random numbers and logarithm have been computed
 #define KFSP_SSA_ROW_REGS()                                                     \
@@ -409,12 +441,40 @@ __global__ __launch_bounds__(kBlock) void k_ssa_walk(SsaDev A, unsigned long lon
             if (r1 <= 0.0) r1 = 0x1p-54;
             const double wait = -plog(r1);
             if (virt) {
-                // (rare: an unlisted state; its propensities come from the program, through memory)
-                int32_t xs[NS];
+                // (an unlisted state: its propensities come from the program)
                 double ps[NR];
+                if (REGS) {
 #pragma unroll
-                for (int s = 0; s < NS; ++s) xs[s] = x[s];
-                for (int k = 0; k < A.nr; ++k) ps[k] = LIGHT ? prop_eval_light(P, k, xs) : prop_eval(A.P, k, xs);
+                    for (int k = 0; k < (REGS ? NR : 1); ++k) {
+                        ps[k] = 0.0;
+                        if (k < A.nr) {
+                            const int d = __builtin_amdgcn_readfirstlane(fd[k]);
+                            const int n = d & 7;
+                            if (n == 0) {
+                                const int v = x_select<NS>(x, (d >> 4) & 15);
+                                if (v >= 0 && v < P.tab_len) {
+                                    ps[k] = A.P.tab[(int64_t)k * P.tab_len + v];
+                                } else {
+                                    int32_t xs[NS];
+#pragma unroll
+                                    for (int s = 0; s < NS; ++s) xs[s] = x[s];
+                                    ps[k] = LIGHT ? prop_eval_light(P, k, xs) : prop_eval(A.P, k, xs);
+                                }
+                            } else {
+                                const int s0 = (d >> 4) & 15, s1 = (d >> 8) & 15, s2 = (d >> 12) & 15;
+                                double v = s0 == 15 ? fc[k] : (double)x_select<NS>(x, s0);
+                                if (n > 1) v = v * (s1 == 15 ? fc[k] : (double)x_select<NS>(x, s1));
+                                if (n > 2) v = v * (s2 == 15 ? fc[k] : (double)x_select<NS>(x, s2));
+                                ps[k] = v;
+                            }
+                        }
+                    }
+                } else {
+                    int32_t xs[NS];
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) xs[s] = x[s];
+                    for (int k = 0; k < A.nr; ++k) ps[k] = LIGHT ? prop_eval_light(P, k, xs) : prop_eval(A.P, k, xs);
+                }
                 a0 = 0.0;
 #pragma unroll
                 for (int k = 0; k < NR; ++k)
@@ -650,7 +710,17 @@ int ssa_streams_core(kfsp_ctx *ctx, double tstep, int64_t seedmix, int32_t ns, i
         const bool light = (ctx->prop_light || (ctx->prop_light_tab && ctx->prop_tab_len > max_count)) && ctx->prop_ncode <= kSsaLdsCode &&
                            ctx->prop_nimm <= kSsaLdsDbl && ctx->prop_np <= kSsaLdsDbl;
         // (the unrolled per-path code is as long as its bounds: the smallest instance that holds the model)
-        if (fast && light && ns <= 2 && nr <= 4)
+        // (product chains and one-species tables only, no two-species table in the way: descriptors in registers)
+        const bool regs = fast && light && ctx->prop_fast && !ctx->prop_has_tab2 && ctx->opt_ssa_regs != 0;
+        A.fast_i = ctx->d_prop_fast_i.p;
+        A.fast_d = ctx->d_prop_fast_d.p;
+        if (regs && ns <= 2 && nr <= 4)
+            hipLaunchKernelGGL((k_ssa_walk<2, 4, true, true>), dim3(wgrid), dim3(kBlock), 0, st, A, d_total, cap, d_keys, d_rec);
+        else if (regs && ns <= 6 && nr <= 12)
+            hipLaunchKernelGGL((k_ssa_walk<6, 12, true, true>), dim3(wgrid), dim3(kBlock), 0, st, A, d_total, cap, d_keys, d_rec);
+        else if (regs)
+            hipLaunchKernelGGL((k_ssa_walk<8, 16, true, true>), dim3(wgrid), dim3(kBlock), 0, st, A, d_total, cap, d_keys, d_rec);
+        else if (fast && light && ns <= 2 && nr <= 4)
             hipLaunchKernelGGL((k_ssa_walk<2, 4, true>), dim3(wgrid), dim3(kBlock), 0, st, A, d_total, cap, d_keys, d_rec);
         else if (fast && light && ns <= 6 && nr <= 12)
             hipLaunchKernelGGL((k_ssa_walk<6, 12, true>), dim3(wgrid), dim3(kBlock), 0, st, A, d_total, cap, d_keys, d_rec);

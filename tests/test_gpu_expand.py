@@ -72,6 +72,7 @@ def test_resident_expansion_equals_the_two_calls_on_host_lists(golden_dir, name,
             x.set_option("state_order_min", 64)
             x.set_option("state_order_products", 0)
         ref.set_option("build_speculate", 0)              # (the reference side waits for every number and insertion-sorts its rows)
+        ref.set_option("ssa_regs", 0)                     # (and walks unlisted states through the interpreter)
         off, diag = c.propensities(state)
         n = len(state)
         t = 2.0 / float(np.mean(diag[diag > 0]))
@@ -344,6 +345,7 @@ def test_random_networks_resident_equals_host_lists():
                 x.set_option("state_order", case % 2)
                 x.set_option("state_order_min", 1)
                 x.set_option("state_order_products", 0)
+            ref.set_option("ssa_regs", 0)                      # (the reference side walks unlisted states through the interpreter)
             idx = {tuple(v): i + 1 for i, v in enumerate(state.tolist())}
             adj = np.zeros((len(state), nr), dtype=np.int32)                # complete links among the listed states
             for j, v in enumerate(state):
