@@ -45,6 +45,8 @@ struct SsaDev {
     const int32_t *nu;         // [nr][ns]
     const int32_t *tab;        // hash table of the listed states: index + 1, 0 = empty
     unsigned tmask;
+    // the same table with a tag (the register-resident kernels): (upper half of the state's hash) << 32 | index + 1, 0 = empty
+    const unsigned long long *tab64;
     // the wavefronts of this launch are wavefronts [wave0, wave1) of the walk (a partitioned expansion: this rank's share;
     // else all of them, [0, nwaves))
     long long wave0, wave1;
@@ -63,6 +65,34 @@ __global__ __launch_bounds__(kBlock) void k_ht_build(int n, int ns, int lds, con
     unsigned slot = hash_state(state + (int64_t)j * lds, ns) & mask;
     for (;;) {
         if (atomicCAS(&tab[slot], 0, j + 1) == 0) return;
+        slot = (slot + 1) & mask;
+    }
+}
+
+// The tagged table: a probe that meets another state's slot sees it from the tag and moves on without fetching that state's
+// coordinates - a look-up of an UNLISTED target (every jump of a path outside the FSP) ends at an empty slot after one
+// cache miss instead of one miss per occupied slot on its way plus one per coordinate row behind them.
+__device__ __forceinline__ unsigned long long hash_state64(const int32_t *x, int ns)
+{
+    unsigned long long h = 0x9E3779B97F4A7C15ull;
+    for (int s = 0; s < ns; ++s) {
+        h ^= (unsigned long long)(unsigned)x[s] + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+        h *= 0xBF58476D1CE4E5B9ull;
+        h ^= h >> 29;
+    }
+    return h;
+}
+
+__global__ __launch_bounds__(kBlock) void k_ht_build64(int n, int ns, int lds, const int32_t *__restrict__ state, unsigned long long *tab,
+                                                       unsigned mask)
+{
+    const int j = blockIdx.x * kBlock + threadIdx.x;
+    if (j >= n) return;
+    const unsigned long long h = hash_state64(state + (int64_t)j * lds, ns);
+    const unsigned long long entry = (h & 0xFFFFFFFF00000000ull) | (unsigned long long)(unsigned)(j + 1);
+    unsigned slot = (unsigned)(h ^ (h >> 32)) & mask;               // (the slot hash_state gives)
+    for (;;) {
+        if (atomicCAS(&tab[slot], 0ull, entry) == 0ull) return;
         slot = (slot + 1) & mask;
     }
 }
@@ -285,18 +315,37 @@ __device__ __forceinline__ unsigned hash_regs(const int32_t (&x)[NS], int ns)
 }
 
 template <int NS>
+__device__ __forceinline__ unsigned long long hash_regs64(const int32_t (&x)[NS], int ns)
+{
+    unsigned long long h = 0x9E3779B97F4A7C15ull;
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+        if (s < ns) {
+            h ^= (unsigned long long)(unsigned)x[s] + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+            h *= 0xBF58476D1CE4E5B9ull;
+            h ^= h >> 29;
+        }
+    return h;
+}
+
+template <int NS>
 __device__ __forceinline__ int lookup_regs(const SsaDev &A, const int32_t (&y)[NS])
 {
-    unsigned slot = hash_regs<NS>(y, A.ns) & A.tmask;
+    const unsigned long long h = hash_regs64<NS>(y, A.ns);
+    const unsigned tag = (unsigned)(h >> 32);
+    unsigned slot = (unsigned)(h ^ (h >> 32)) & A.tmask;
     for (;;) {
-        const int e = A.tab[slot];
-        if (e == 0) return 0;
-        const int32_t *z = A.state + (int64_t)(e - 1) * A.lds;
-        bool same = true;
+        const unsigned long long e = A.tab64[slot];
+        if (e == 0ull) return 0;
+        if ((unsigned)(e >> 32) == tag) {                           // (else: another state's slot - no need to look at it)
+            const int idx = (int)(unsigned)e;
+            const int32_t *z = A.state + (int64_t)(idx - 1) * A.lds;
+            bool same = true;
 #pragma unroll
-        for (int s = 0; s < NS; ++s)
-            if (s < A.ns) same = same && z[s] == y[s];
-        if (same) return e;
+            for (int s = 0; s < NS; ++s)
+                if (s < A.ns) same = same && z[s] == y[s];
+            if (same) return idx;
+        }
         slot = (slot + 1) & A.tmask;
     }
 }
@@ -653,15 +702,26 @@ int ssa_streams_core(kfsp_ctx *ctx, double tstep, int64_t seedmix, int32_t ns, i
     const auto blocks = [](long long k) { return (int)std::max<long long>(1, (k + kBlock - 1) / kBlock); };
     unsigned slots = 64;
     while (slots < 2u * (unsigned)n) slots <<= 1;
-    // arena 1: the table of the listed states, the reaction vectors, the record counter
-    const size_t need1 = (size_t)nr * ns * 4 + (size_t)slots * 4 + 4096;
+    bool fast = ns <= 8 && nr <= 16 && !ctx->opt_ssa_general;
+    // (the register-resident kernels keep a reaction vector as signed bytes: a coefficient outside them takes the general kernel)
+    for (size_t i = 0; i < (size_t)nr * ns; ++i)
+        if (stoich[i] < -128 || stoich[i] > 127) fast = false;
+    // arena 1: the table of the listed states (tagged, 8 bytes per slot, for the register-resident kernels), the reaction
+    // vectors, the record counter
+    const size_t need1 = (size_t)nr * ns * 4 + (size_t)slots * 8 + 4096;
     SSA_TRY(ctx->d_os2.reserve(need1, false));
     Arena a1{ctx->d_os2.p};
-    int32_t *d_nu = a1.take<int32_t>((size_t)nr * ns), *d_tab = a1.take<int32_t>(slots);
+    int32_t *d_nu = a1.take<int32_t>((size_t)nr * ns);
+    unsigned long long *d_tab64 = a1.take<unsigned long long>(slots);
+    int32_t *d_tab = reinterpret_cast<int32_t *>(d_tab64);
     unsigned long long *d_total = a1.take<unsigned long long>(2);
     SSA_TRY(hipMemcpyAsync(d_nu, stoich, (size_t)nr * ns * 4, hipMemcpyHostToDevice, st));
-    SSA_TRY(hipMemsetAsync(d_tab, 0, (size_t)slots * 4, st));
-    launch_table_build(n, ns, lds, d_state, d_tab, slots - 1, st);
+    SSA_TRY(hipMemsetAsync(d_tab64, 0, (size_t)slots * (fast ? 8 : 4), st));
+    if (fast) {
+        if (n > 0) hipLaunchKernelGGL(k_ht_build64, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, n, ns, lds, d_state, d_tab64, slots - 1);
+    } else {
+        launch_table_build(n, ns, lds, d_state, d_tab, slots - 1, st);
+    }
     SsaDev A;
     A.ns = ns;
     A.nr = nr;
@@ -677,12 +737,9 @@ int ssa_streams_core(kfsp_ctx *ctx, double tstep, int64_t seedmix, int32_t ns, i
     A.diag = d_diag;
     A.nu = d_nu;
     A.tab = d_tab;
+    A.tab64 = d_tab64;
     A.tmask = slots - 1;
     A.P = prop_dev(ctx);
-    bool fast = ns <= 8 && nr <= 16 && !ctx->opt_ssa_general;
-    // (the register-resident kernels keep a reaction vector as signed bytes: a coefficient outside them takes the general kernel)
-    for (size_t i = 0; i < (size_t)nr * ns; ++i)
-        if (stoich[i] < -128 || stoich[i] > 127) fast = false;
     // one wavefront per kSsaSeedsPerWave seed states (4 wavefronts per workgroup); the record list is sized by a guess
     // and, should the paths meet more unlisted states than that, by the count the first attempt returns
     // Under a row partition (partitioned: every rank is here, with the same lists) rank p walks wavefronts
