@@ -10,6 +10,10 @@ D=$R/krylovfspssa_amd/fortran/_build/kfsp_dump
 export KFSP_CASE_CAPACITY=2097169
 KFSP_SSA_STREAMS=1 timeout -k 10 120 $D solve goutsias_input /tmp/p1.bin 300.0 > $O/k_goutsias.log 2>&1
 grep -E "KFSP WALL|KFSP RESIDENT REBUILDS|FINAL" $O/k_goutsias.log | cut -c1-250
+export TMPDIR=/tmp
+KFSP_SSA_STREAMS=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_k -o k -- $D solve goutsias_input /tmp/p2.bin 300.0 > $O/k_prof.log 2>&1
+cp $(find /tmp/prof_k -name "k_kernel_stats.csv" | head -1) $O/k_resident_goutsias_kernel_stats.csv
+head -12 $O/k_resident_goutsias_kernel_stats.csv | cut -c1-140
 cd $R
 timeout -k 10 300 python bench.py > $O/k_bench.json 2> $O/k_bench.err
 echo "bench rc=$?"; cut -c1-600 $O/k_bench.json
