@@ -72,15 +72,34 @@ __global__ __launch_bounds__(kBlock) void k_ht_build(int n, int ns, int lds, con
 // The tagged table: a probe that meets another state's slot sees it from the tag and moves on without fetching that state's
 // coordinates - a look-up of an UNLISTED target (every jump of a path outside the FSP) ends at an empty slot after one
 // cache miss instead of one miss per occupied slot on its way plus one per coordinate row behind them.
+// Its hash is made of 32-bit multiplications that do not wait for each other - two sums of x_s times odd constants, one
+// finished into the slot, one into the tag - instead of the 64-bit multiply-and-shift chain of hash_state, whose six
+// dependent 64-bit products stand on the critical path of every jump of a lone wavefront.  Any hash gives the same answers;
+// this table is private to the walk.
+__device__ __constant__ unsigned kMixA[8] = {0x9E3779B1u, 0x85EBCA77u, 0xC2B2AE3Du, 0x27D4EB2Fu, 0x165667B1u, 0xD3A2646Du, 0xFD7046C5u, 0xB55A4F09u};
+__device__ __constant__ unsigned kMixB[8] = {0x7FEB352Du, 0x846CA68Bu, 0xE6546B65u, 0x9E485565u, 0xAF836E39u, 0xC5A308D3u, 0x2C1B3C6Du, 0x297A2D39u};
+
+__device__ __forceinline__ unsigned long long mix_finish(unsigned a, unsigned b)
+{
+    a ^= a >> 16;
+    a *= 0x7FEB352Du;
+    a ^= a >> 15;
+    a *= 0x846CA68Bu;
+    a ^= a >> 16;
+    b ^= b >> 15;
+    b *= 0x2C1B3C6Du;
+    b ^= b >> 13;
+    return ((unsigned long long)b << 32) | a;                      // tag | slot bits
+}
+
 __device__ __forceinline__ unsigned long long hash_state64(const int32_t *x, int ns)
 {
-    unsigned long long h = 0x9E3779B97F4A7C15ull;
+    unsigned a = 0x68E31DA4u, b = 0xB5297A4Du;
     for (int s = 0; s < ns; ++s) {
-        h ^= (unsigned long long)(unsigned)x[s] + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
-        h *= 0xBF58476D1CE4E5B9ull;
-        h ^= h >> 29;
+        a += (unsigned)x[s] * kMixA[s & 7];
+        b += (unsigned)x[s] * kMixB[s & 7];
     }
-    return h;
+    return mix_finish(a, b);
 }
 
 __global__ __launch_bounds__(kBlock) void k_ht_build64(int n, int ns, int lds, const int32_t *__restrict__ state, unsigned long long *tab,
@@ -90,7 +109,7 @@ __global__ __launch_bounds__(kBlock) void k_ht_build64(int n, int ns, int lds, c
     if (j >= n) return;
     const unsigned long long h = hash_state64(state + (int64_t)j * lds, ns);
     const unsigned long long entry = (h & 0xFFFFFFFF00000000ull) | (unsigned long long)(unsigned)(j + 1);
-    unsigned slot = (unsigned)(h ^ (h >> 32)) & mask;               // (the slot hash_state gives)
+    unsigned slot = (unsigned)h & mask;
     for (;;) {
         if (atomicCAS(&tab[slot], 0ull, entry) == 0ull) return;
         slot = (slot + 1) & mask;
@@ -317,15 +336,17 @@ __device__ __forceinline__ unsigned hash_regs(const int32_t (&x)[NS], int ns)
 template <int NS>
 __device__ __forceinline__ unsigned long long hash_regs64(const int32_t (&x)[NS], int ns)
 {
-    unsigned long long h = 0x9E3779B97F4A7C15ull;
+    static_assert(NS <= 8, "kMixA / kMixB hold eight constants");
+    constexpr unsigned ca[8] = {0x9E3779B1u, 0x85EBCA77u, 0xC2B2AE3Du, 0x27D4EB2Fu, 0x165667B1u, 0xD3A2646Du, 0xFD7046C5u, 0xB55A4F09u};
+    constexpr unsigned cb[8] = {0x7FEB352Du, 0x846CA68Bu, 0xE6546B65u, 0x9E485565u, 0xAF836E39u, 0xC5A308D3u, 0x2C1B3C6Du, 0x297A2D39u};
+    unsigned a = 0x68E31DA4u, b = 0xB5297A4Du;
 #pragma unroll
     for (int s = 0; s < NS; ++s)
         if (s < ns) {
-            h ^= (unsigned long long)(unsigned)x[s] + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
-            h *= 0xBF58476D1CE4E5B9ull;
-            h ^= h >> 29;
+            a += (unsigned)x[s] * ca[s];
+            b += (unsigned)x[s] * cb[s];
         }
-    return h;
+    return mix_finish(a, b);
 }
 
 template <int NS>
@@ -333,7 +354,7 @@ __device__ __forceinline__ int lookup_regs(const SsaDev &A, const int32_t (&y)[N
 {
     const unsigned long long h = hash_regs64<NS>(y, A.ns);
     const unsigned tag = (unsigned)(h >> 32);
-    unsigned slot = (unsigned)(h ^ (h >> 32)) & A.tmask;
+    unsigned slot = (unsigned)h & A.tmask;
     for (;;) {
         const unsigned long long e = A.tab64[slot];
         if (e == 0ull) return 0;
