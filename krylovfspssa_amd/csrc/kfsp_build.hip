@@ -526,6 +526,7 @@ int build_from_ell_device(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, cons
     ctx->ell_cols = n;
     ctx->ell_ld = ld;
     ctx->ell_bw = bw;
+    ctx->order_check = false;          // (an order made for an upload waited for its ranges: nothing is pending from an earlier call)
     return build_from_resident_ell(ctx, n, bw, ld);
 }
 
