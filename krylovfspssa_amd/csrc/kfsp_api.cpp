@@ -1699,9 +1699,8 @@ int kfsp_arnoldi(kfsp_ctx *ctx, int m, int jold, int qiop, double break_tol, dou
     const int gv = vec_grid(ctx);
     double *V = vcol(ctx, 0), *Hd = ctx->d_H.p, *sq = ctx->d_sq.p;
     int *flag = ctx->d_flag.p;
-    HIP_TRY(hipMemsetAsync(flag, 0, sizeof(int), st));
-    // entries this pass will not write must not look like a breakdown
-    HIP_TRY(hipMemsetAsync(Hd, 0, (size_t)kMH * kMH * sizeof(double), st));
+    // (entries this pass will not write must not look like a breakdown)
+    kfsp::launch_pass_reset(Hd, kMH * kMH, flag, st);
 
     const bool fused = (qiop == 2) && ctx->opt_fused != 0;
     double *gfin = ctx->d_g.p;

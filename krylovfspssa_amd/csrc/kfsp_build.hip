@@ -628,7 +628,7 @@ int build_from_resident_ell(kfsp_ctx *ctx, int32_t n, int32_t bw, int32_t ld, bo
         HIP_TRY_B(ctx->d_col.reserve((size_t)std::max<int64_t>(bound, 64), false));
         HIP_TRY_B(ctx->d_val.reserve((size_t)std::max<int64_t>(bound, 64), false));
         HIP_TRY_B(ctx->d_ticket.reserve((size_t)std::max<int64_t>(nact, 64), false));
-        HIP_TRY_B(hipMemsetAsync(ctx->d_off.p, 0, sizeof(int64_t), st));
+        // (off[0] = 0 is k_scan_offsets' own first store)
         HIP_TRY_B(hipMemsetAsync(ctx->d_ticket.p, 0, (size_t)std::max<int64_t>(nact, 64) * sizeof(int32_t), st));
         hipLaunchKernelGGL(k_chunk_width, dim3((int)((nchunks + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, nchunks, nloc,
                            ctx->d_cnt.p, ctx->d_off.p);
@@ -881,19 +881,19 @@ int build_sell_code(kfsp_ctx *ctx)
     const int64_t nchunks = ctx->nchunks;
     HIP_TRY_B(ctx->d_scan.reserve(sizeof(ScanOut), false));
     unsigned long long *stats = reinterpret_cast<unsigned long long *>(ctx->d_scan.p);
-    HIP_TRY_B(hipMemsetAsync(stats, 0, 8 * sizeof(unsigned long long), st));
     // the reach of the rows (a bounded reach lets a partitioned product exchange halo strips instead of whole vectors):
     // only a communicator asks for it
     const bool want_reach = ctx->use_comm && ctx->opt_halo_sell != 0;
-    if (want_reach)
-        hipLaunchKernelGGL(k_sell_reach, dim3((int)((nchunks + 3) / 4)), dim3(kBlock), 0, st, nchunks, ctx->row0, ctx->d_off.p,
-                           ctx->d_col.p, stats + 4);
     // auto: under the internal state order AND only for generators that cannot stay in the 256 MiB Infinity Cache - a
     // cache-resident product is not bound by bytes, and coding costs about 30 products (Goutsias run, T = 300, N <= 1e6:
     // Arnoldi 1.02 -> 1.09 s, uploads + 0.26 s with the columns coded at every FSP change; profiles/r03_end_to_end_goutsias.txt)
     const bool want = ctx->opt_sell_code > 0 ||
                       (ctx->opt_sell_code < 0 && ctx->perm_on && (double)ctx->slots * 12.0 > 256.0 * 1024 * 1024);
     if (!want && !want_reach) return 0;
+    HIP_TRY_B(hipMemsetAsync(stats, 0, 8 * sizeof(unsigned long long), st));
+    if (want_reach)
+        hipLaunchKernelGGL(k_sell_reach, dim3((int)((nchunks + 3) / 4)), dim3(kBlock), 0, st, nchunks, ctx->row0, ctx->d_off.p,
+                           ctx->d_col.p, stats + 4);
     if (want) {
         HIP_TRY_B(ctx->d_codeoff.reserve((size_t)nchunks + 1, false));
         HIP_TRY_B(hipMemsetAsync(ctx->d_codeoff.p, 0, sizeof(int64_t), st));

@@ -241,6 +241,8 @@ void launch_spmv_slab(int mode, int grid, int waves, const SpmvArgs &a, hipStrea
 void launch_spmv_pencil(int mode, int grid, const SpmvArgs &a, hipStream_t s, size_t lds_bytes, int64_t plane_rows, int planes,
                         int64_t base_trips, const int32_t *order, bool simple);
 void launch_ortho2(int grid, const Ortho2Args &a, hipStream_t s);
+// H image and breakdown flag of an Arnoldi pass cleared by ONE launch (two memsets before: 6 400 of them in the Goutsias run)
+void launch_pass_reset(double *H, int count, int *flag, hipStream_t s);
 void launch_ortho(int grid, const OrthoArgs &a, hipStream_t s);
 void launch_combine(int grid, const CombineArgs &a, hipStream_t s);
 // u1 = w, partial = sum w^2

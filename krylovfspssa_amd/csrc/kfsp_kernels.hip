@@ -1117,6 +1117,18 @@ void launch_ortho2(int grid, const Ortho2Args &a, hipStream_t st)
     hipLaunchKernelGGL(k_ortho2, dim3(grid), dim3(kBlock), 0, st, a);
 }
 
+__global__ __launch_bounds__(kBlock) void k_pass_reset(double *__restrict__ H, int count, int *__restrict__ flag)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < count) H[i] = 0.0;
+    if (i == 0) *flag = 0;
+}
+
+void launch_pass_reset(double *H, int count, int *flag, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_pass_reset, dim3((count + kBlock - 1) / kBlock), dim3(kBlock), 0, st, H, count, flag);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Format 7 (round 4): the PENCIL product of a matrix-free box (single-factor fast form, one rank).
 //
