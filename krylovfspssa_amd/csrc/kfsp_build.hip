@@ -463,6 +463,8 @@ void launch_sell_sort_rows(kfsp_ctx *ctx, int64_t nloc, int bw, hipStream_t st)
     // (a row holds at most one entry per reaction)
     if (bw <= 8 && ctx->opt_build_speculate)
         hipLaunchKernelGGL(k_sell_rank_rows<8>, grid, block, 0, st, nloc, ctx->d_cnt.p, ctx->d_off.p, ctx->d_col.p, ctx->d_val.p, perm);
+    else if (bw <= 12 && ctx->opt_build_speculate)
+        hipLaunchKernelGGL(k_sell_rank_rows<12>, grid, block, 0, st, nloc, ctx->d_cnt.p, ctx->d_off.p, ctx->d_col.p, ctx->d_val.p, perm);
     else if (bw <= 16 && ctx->opt_build_speculate)
         hipLaunchKernelGGL(k_sell_rank_rows<16>, grid, block, 0, st, nloc, ctx->d_cnt.p, ctx->d_off.p, ctx->d_col.p, ctx->d_val.p, perm);
     else
