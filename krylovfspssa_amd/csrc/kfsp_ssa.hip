@@ -320,20 +320,6 @@ __global__ __launch_bounds__(kBlock) void k_ssa_walk_any(SsaDev A, unsigned long
 // scratch memory: every access a trip to the cache, on the critical path of every jump).  The reaction vectors sit in
 // LDS, one 64-bit word of signed bytes per reaction.  Same arithmetic in the same order: same paths, same records.
 template <int NS>
-__device__ __forceinline__ unsigned hash_regs(const int32_t (&x)[NS], int ns)
-{
-    unsigned long long h = 0x9E3779B97F4A7C15ull;
-#pragma unroll
-    for (int s = 0; s < NS; ++s)
-        if (s < ns) {
-            h ^= (unsigned long long)(unsigned)x[s] + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
-            h *= 0xBF58476D1CE4E5B9ull;
-            h ^= h >> 29;
-        }
-    return (unsigned)(h ^ (h >> 32));
-}
-
-template <int NS>
 __device__ __forceinline__ unsigned long long hash_regs64(const int32_t (&x)[NS], int ns)
 {
     static_assert(NS <= 8, "kMixA / kMixB hold eight constants");
