@@ -559,7 +559,8 @@ int kfsp_add_timer(kfsp_ctx *ctx, int phase, double ms);
  * 0: every rank walks all seeds), "ssa_general" (1: kfsp_ssa_streams / kfsp_expand_resident walk with the general kernel even for models of <= 8 species and
  * <= 16 reactions, which otherwise take the register-resident one; same paths; default 0), "ssa_regs" (1, default: when every propensity is a product chain of at
  * most three operands or sits behind a one-species table, the register-resident walk evaluates an unlisted state from descriptors it keeps in registers
- * instead of interpreting the program - the paths a launch waits for are the ones that walk outside the FSP; same paths; 0: always the program), "keep_coords" (1: the coordinates of kfsp_set_state_coords / kfsp_update_state_coords stay on the device
+ * instead of interpreting the program - the paths a launch waits for are the ones that walk outside the FSP; same paths; 0: always the program), "ssa_filter" (1, default:
+ * a bit map in front of the walk's table of listed states answers "not listed" for most unlisted targets without a trip to the table; 0: every look-up probes the table), "keep_coords" (1: the coordinates of kfsp_set_state_coords / kfsp_update_state_coords stay on the device
  * even when no state order is derived from them - kfsp_expand_resident needs them; default 0), "ssa_resident" (1: the caller vouches that the FSP arrays handed to kfsp_ssa_streams are the ones of its last
  * kfsp_update_matrix_ell / kfsp_set_state_coords: they are taken from the device's copies instead of being uploaded again; default 0),
  * "sell_code" (dictionary-coded SELL columns, DESIGN.md 4.1c: -1 auto = under the internal state order,

@@ -2584,6 +2584,7 @@ int kfsp_set_option(kfsp_ctx *ctx, const char *name, int64_t value)
     else if (k == "sell_sigma") ctx->opt_sell_sigma = value;
     else if (k == "build_speculate") ctx->opt_build_speculate = value != 0;
     else if (k == "ssa_regs") ctx->opt_ssa_regs = value != 0;
+    else if (k == "ssa_filter") ctx->opt_ssa_filter = value != 0;
     else if (k == "overlap") ctx->opt_overlap = value;
     else if (k == "small_kernel") ctx->opt_small = value;
     else if (k == "m_max") {

@@ -242,6 +242,7 @@ struct kfsp_ctx {
     bool kc_ok = false, order_check = false, last_build_sell = false, h_build_ready = false;
     int kc_ns = 0, kc_bits = 0, kc_lo[16] = {0}, kc_hi[16] = {0}, kc_shift[16] = {0};
     int64_t opt_build_speculate = 1, spec_builds = 0, spec_redone = 0;
+    int64_t opt_ssa_filter = 1;           // a one-bit-per-slot filter in front of the walk's table of listed states
     int64_t opt_ssa_regs = 1;             // the walk evaluates unlisted states from descriptors in registers when the program allows it
     // the sorted keys of the current order (d_perm) and for how many states both are valid: an expansion merges the appended
     // states' keys into them, a drop compacts them (state_order_from_resident, state_order_after_drop)

@@ -47,6 +47,10 @@ struct SsaDev {
     unsigned tmask;
     // the same table with a tag (the register-resident kernels): (upper half of the state's hash) << 32 | index + 1, 0 = empty
     const unsigned long long *tab64;
+    // a filter in front of it (option ssa_filter): one bit per listed state in a map of bmask + 1 words, addressed by the
+    // tag half of the hash; a clear bit means "not listed" without touching the table
+    const unsigned *bitmap;
+    unsigned bmask;
     // the wavefronts of this launch are wavefronts [wave0, wave1) of the walk (a partitioned expansion: this rank's share;
     // else all of them, [0, nwaves))
     long long wave0, wave1;
@@ -103,12 +107,16 @@ __device__ __forceinline__ unsigned long long hash_state64(const int32_t *x, int
 }
 
 __global__ __launch_bounds__(kBlock) void k_ht_build64(int n, int ns, int lds, const int32_t *__restrict__ state, unsigned long long *tab,
-                                                       unsigned mask)
+                                                       unsigned mask, unsigned *bitmap, unsigned bmask)
 {
     const int j = blockIdx.x * kBlock + threadIdx.x;
     if (j >= n) return;
     const unsigned long long h = hash_state64(state + (int64_t)j * lds, ns);
     const unsigned long long entry = (h & 0xFFFFFFFF00000000ull) | (unsigned long long)(unsigned)(j + 1);
+    if (bitmap) {
+        const unsigned t = (unsigned)(h >> 32);
+        atomicOr(&bitmap[(t >> 5) & bmask], 1u << (t & 31));
+    }
     unsigned slot = (unsigned)h & mask;
     for (;;) {
         if (atomicCAS(&tab[slot], 0ull, entry) == 0ull) return;
@@ -340,6 +348,7 @@ __device__ __forceinline__ int lookup_regs(const SsaDev &A, const int32_t (&y)[N
 {
     const unsigned long long h = hash_regs64<NS>(y, A.ns);
     const unsigned tag = (unsigned)(h >> 32);
+    if (A.bitmap && !((A.bitmap[(tag >> 5) & A.bmask] >> (tag & 31)) & 1u)) return 0;
     unsigned slot = (unsigned)h & A.tmask;
     for (;;) {
         const unsigned long long e = A.tab64[slot];
@@ -715,17 +724,24 @@ int ssa_streams_core(kfsp_ctx *ctx, double tstep, int64_t seedmix, int32_t ns, i
         if (stoich[i] < -128 || stoich[i] > 127) fast = false;
     // arena 1: the table of the listed states (tagged, 8 bytes per slot, for the register-resident kernels), the reaction
     // vectors, the record counter
-    const size_t need1 = (size_t)nr * ns * 4 + (size_t)slots * 8 + 4096;
+    // (the filter: 4 bits per slot = 8 to 16 per listed state, one word per 32)
+    const unsigned bwords = slots / 8;
+    const bool filter = fast && ctx->opt_ssa_filter != 0;
+    const size_t need1 = (size_t)nr * ns * 4 + (size_t)slots * 8 + (size_t)bwords * 4 + 4096;
     SSA_TRY(ctx->d_os2.reserve(need1, false));
     Arena a1{ctx->d_os2.p};
     int32_t *d_nu = a1.take<int32_t>((size_t)nr * ns);
     unsigned long long *d_tab64 = a1.take<unsigned long long>(slots);
+    unsigned *d_bitmap = a1.take<unsigned>(bwords);
     int32_t *d_tab = reinterpret_cast<int32_t *>(d_tab64);
     unsigned long long *d_total = a1.take<unsigned long long>(2);
     SSA_TRY(hipMemcpyAsync(d_nu, stoich, (size_t)nr * ns * 4, hipMemcpyHostToDevice, st));
-    SSA_TRY(hipMemsetAsync(d_tab64, 0, (size_t)slots * (fast ? 8 : 4), st));
+    // (table and filter are neighbours in the arena: one memset)
+    SSA_TRY(hipMemsetAsync(d_tab64, 0, fast ? (size_t)((char *)(d_bitmap + bwords) - (char *)d_tab64) : (size_t)slots * 4, st));
     if (fast) {
-        if (n > 0) hipLaunchKernelGGL(k_ht_build64, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, n, ns, lds, d_state, d_tab64, slots - 1);
+        if (n > 0)
+            hipLaunchKernelGGL(k_ht_build64, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, n, ns, lds, d_state, d_tab64, slots - 1,
+                               filter ? d_bitmap : (unsigned *)nullptr, bwords - 1);
     } else {
         launch_table_build(n, ns, lds, d_state, d_tab, slots - 1, st);
     }
@@ -745,6 +761,8 @@ int ssa_streams_core(kfsp_ctx *ctx, double tstep, int64_t seedmix, int32_t ns, i
     A.nu = d_nu;
     A.tab = d_tab;
     A.tab64 = d_tab64;
+    A.bitmap = filter ? d_bitmap : nullptr;
+    A.bmask = bwords - 1;
     A.tmask = slots - 1;
     A.P = prop_dev(ctx);
     // one wavefront per kSsaSeedsPerWave seed states (4 wavefronts per workgroup); the record list is sized by a guess
