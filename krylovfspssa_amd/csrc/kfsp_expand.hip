@@ -44,7 +44,7 @@ struct XDev {
     int32_t *adj;                           // [n][lda]            completed in place
     int32_t *state_new;                     // [nu][lds]           the appended states (numbers n + 1 ..)
     int32_t *adj_new;                       // [nu][lda]
-    const int32_t *tab;                     // listed states: index + 1, 0 = empty
+    const unsigned long long *tab;          // listed states, tagged table (kfsp_hash_dev.h): tag << 32 | index + 1, 0 = empty
     unsigned tmask;
     int32_t *tab2;                          // candidates' targets: smallest ordinal naming the target, kFree = empty
     int32_t *newidx;                        // per slot of tab2: number (1-based) of the appended state
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(kBlock) void k_x_mark(XDev A, unsigned long long *_
         if (!x_target(A, x, k, y, &neg)) {
             if (neg) A.adj[e] = -1;
         } else {
-            const int f = table_find(A.tab, A.tmask, A.state, A.lds, A.ns, y);
+            const int f = table_find64(A.tab, A.tmask, A.state, A.lds, A.ns, y);
             if (f > 0) {
                 A.adj[e] = f;
             } else {
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(kBlock) void k_x_newcols(XDev A, int nu)
         int32_t y[kXMaxS];
         bool neg;
         if (x_target(A, A.state_new + (int64_t)r * A.lds, k, y, &neg)) {
-            link = table_find(A.tab, A.tmask, A.state, A.lds, A.ns, y);
+            link = table_find64(A.tab, A.tmask, A.state, A.lds, A.ns, y);
             if (link == 0) {
                 const int slot = x_find2(A, y);
                 if (slot >= 0) link = A.newidx[slot];
@@ -303,14 +303,14 @@ int sweep_count(kfsp_ctx *ctx, XDev &A, int **cnt_out, int **off_out, int *nu_ou
     const int n = A.n;
     unsigned slots = 64;
     while (slots < 2u * (unsigned)n) slots <<= 1;
-    X_TRY(ctx->d_os1.reserve((size_t)slots * 4 + 2 * ((size_t)n + 1) * 4 + 4096, false));
+    X_TRY(ctx->d_os1.reserve((size_t)slots * 8 + 2 * ((size_t)n + 1) * 4 + 4096, false));
     Arena a1{ctx->d_os1.p};
-    int32_t *d_tab = a1.take<int32_t>(slots);
+    unsigned long long *d_tab = a1.take<unsigned long long>(slots);
     int *d_cnt = a1.take<int>((size_t)n + 1), *d_off = a1.take<int>((size_t)n + 1);
     unsigned long long *d_ncand = a1.take<unsigned long long>(2);
-    X_TRY(hipMemsetAsync(d_tab, 0, (size_t)slots * 4, st));
+    X_TRY(hipMemsetAsync(d_tab, 0, (size_t)slots * 8, st));
     X_TRY(hipMemsetAsync(d_ncand, 0, 16, st));
-    launch_table_build(n, A.ns, A.lds, A.state, d_tab, slots - 1, st);
+    launch_table_build64(n, A.ns, A.lds, A.state, d_tab, slots - 1, nullptr, 0, st);
     A.tab = d_tab;
     A.tmask = slots - 1;
     const int64_t nent = (int64_t)n * A.lda;

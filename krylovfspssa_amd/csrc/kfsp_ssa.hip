@@ -73,39 +73,7 @@ __global__ __launch_bounds__(kBlock) void k_ht_build(int n, int ns, int lds, con
     }
 }
 
-// The tagged table: a probe that meets another state's slot sees it from the tag and moves on without fetching that state's
-// coordinates - a look-up of an UNLISTED target (every jump of a path outside the FSP) ends at an empty slot after one
-// cache miss instead of one miss per occupied slot on its way plus one per coordinate row behind them.
-// Its hash is made of 32-bit multiplications that do not wait for each other - two sums of x_s times odd constants, one
-// finished into the slot, one into the tag - instead of the 64-bit multiply-and-shift chain of hash_state, whose six
-// dependent 64-bit products stand on the critical path of every jump of a lone wavefront.  Any hash gives the same answers;
-// this table is private to the walk.
-__device__ __constant__ unsigned kMixA[8] = {0x9E3779B1u, 0x85EBCA77u, 0xC2B2AE3Du, 0x27D4EB2Fu, 0x165667B1u, 0xD3A2646Du, 0xFD7046C5u, 0xB55A4F09u};
-__device__ __constant__ unsigned kMixB[8] = {0x7FEB352Du, 0x846CA68Bu, 0xE6546B65u, 0x9E485565u, 0xAF836E39u, 0xC5A308D3u, 0x2C1B3C6Du, 0x297A2D39u};
-
-__device__ __forceinline__ unsigned long long mix_finish(unsigned a, unsigned b)
-{
-    a ^= a >> 16;
-    a *= 0x7FEB352Du;
-    a ^= a >> 15;
-    a *= 0x846CA68Bu;
-    a ^= a >> 16;
-    b ^= b >> 15;
-    b *= 0x2C1B3C6Du;
-    b ^= b >> 13;
-    return ((unsigned long long)b << 32) | a;                      // tag | slot bits
-}
-
-__device__ __forceinline__ unsigned long long hash_state64(const int32_t *x, int ns)
-{
-    unsigned a = 0x68E31DA4u, b = 0xB5297A4Du;
-    for (int s = 0; s < ns; ++s) {
-        a += (unsigned)x[s] * kMixA[s & 7];
-        b += (unsigned)x[s] * kMixB[s & 7];
-    }
-    return mix_finish(a, b);
-}
-
+// (the tagged table and its hash: kfsp_hash_dev.h)
 __global__ __launch_bounds__(kBlock) void k_ht_build64(int n, int ns, int lds, const int32_t *__restrict__ state, unsigned long long *tab,
                                                        unsigned mask, unsigned *bitmap, unsigned bmask)
 {
@@ -330,10 +298,9 @@ __global__ __launch_bounds__(kBlock) void k_ssa_walk_any(SsaDev A, unsigned long
 template <int NS>
 __device__ __forceinline__ unsigned long long hash_regs64(const int32_t (&x)[NS], int ns)
 {
-    static_assert(NS <= 8, "kMixA / kMixB hold eight constants");
-    constexpr unsigned ca[8] = {0x9E3779B1u, 0x85EBCA77u, 0xC2B2AE3Du, 0x27D4EB2Fu, 0x165667B1u, 0xD3A2646Du, 0xFD7046C5u, 0xB55A4F09u};
-    constexpr unsigned cb[8] = {0x7FEB352Du, 0x846CA68Bu, 0xE6546B65u, 0x9E485565u, 0xAF836E39u, 0xC5A308D3u, 0x2C1B3C6Du, 0x297A2D39u};
-    unsigned a = 0x68E31DA4u, b = 0xB5297A4Du;
+    static_assert(NS <= 8, "eight constants per sum");
+    constexpr unsigned ca[8] = KFSP_MIX_A, cb[8] = KFSP_MIX_B;                 // (hash_state64 on registers)
+    unsigned a = kMixSeedA, b = kMixSeedB;
 #pragma unroll
     for (int s = 0; s < NS; ++s)
         if (s < ns) {
@@ -701,6 +668,12 @@ struct Arena {
         }                                                                                  \
     } while (0)
 
+void launch_table_build64(int n, int ns, int lds, const int32_t *state, unsigned long long *tab, unsigned mask, unsigned *bitmap, unsigned bmask,
+                          hipStream_t st)
+{
+    if (n > 0) hipLaunchKernelGGL(k_ht_build64, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, n, ns, lds, state, tab, mask, bitmap, bmask);
+}
+
 void launch_table_build(int n, int ns, int lds, const int32_t *state, int32_t *tab, unsigned mask, hipStream_t st)
 {
     if (n > 0) hipLaunchKernelGGL(k_ht_build, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, n, ns, lds, state, tab, mask);
@@ -739,9 +712,7 @@ int ssa_streams_core(kfsp_ctx *ctx, double tstep, int64_t seedmix, int32_t ns, i
     // (table and filter are neighbours in the arena: one memset)
     SSA_TRY(hipMemsetAsync(d_tab64, 0, fast ? (size_t)((char *)(d_bitmap + bwords) - (char *)d_tab64) : (size_t)slots * 4, st));
     if (fast) {
-        if (n > 0)
-            hipLaunchKernelGGL(k_ht_build64, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, n, ns, lds, d_state, d_tab64, slots - 1,
-                               filter ? d_bitmap : (unsigned *)nullptr, bwords - 1);
+        launch_table_build64(n, ns, lds, d_state, d_tab64, slots - 1, filter ? d_bitmap : (unsigned *)nullptr, bwords - 1, st);
     } else {
         launch_table_build(n, ns, lds, d_state, d_tab, slots - 1, st);
     }
