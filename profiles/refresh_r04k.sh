@@ -15,5 +15,6 @@ KFSP_SSA_STREAMS=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-f
 cp $(find /tmp/prof_k -name "k_kernel_stats.csv" | head -1) $O/k_resident_goutsias_kernel_stats.csv
 head -12 $O/k_resident_goutsias_kernel_stats.csv | cut -c1-140
 cd $R
+timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/k_smoke.log 2>&1; tail -1 $O/k_smoke.log
 timeout -k 10 300 python bench.py > $O/k_bench.json 2> $O/k_bench.err
 echo "bench rc=$?"; cut -c1-600 $O/k_bench.json
