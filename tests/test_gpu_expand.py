@@ -302,6 +302,45 @@ def test_resident_expansion_under_a_row_partition(golden_dir, P, order):
     assert np.array_equal(a["y"], b["y"])                  # every row is summed in FMATVEC's order whoever owns it
 
 
+def test_walk_register_path_with_a_tabulated_reaction(golden_dir):
+    """The walk's register path (ssa_regs) reads a reaction that is NOT a product chain from its one-species table, and meets
+    the listed states through the tagged table behind its bit-map filter (ssa_filter): a Goutsias-like program whose
+    dimerisation c X (X - 1) / 2 is tabulated - the other reactions are chains - must give the records the interpreter and
+    the unfiltered table give, from every seed, for a short and a long horizon (paths that stay inside / leave the FSP)."""
+    from krylovfspssa_amd import KfspContext
+    MUL, SUB, DIV, IMM = 5, 4, 6, 1
+    with KfspContext(0) as a, KfspContext(0) as b:
+        nu, state, adj = _grown(a, "goutsias_k16", golden_dir, 3)
+        nr, ns = nu.shape
+        params, progs = _mass_action(nu)
+        dimer = [k for k in range(nr) if (nu[k] == -2).any()]
+        assert dimer, "the model has a dimerisation"
+        tab_len = 4096
+        ts = np.full(nr, -1, dtype=np.int32)
+        tab = np.zeros((nr, tab_len))
+        for k in dimer:
+            s = int(np.where(nu[k] == -2)[0][0])
+            c = 100 + ns + 1 + k                                     # parameter k
+            progs[k] = ([c, 100 + s + 1, MUL, 100 + s + 1, IMM, SUB, MUL, IMM, DIV], [1.0, 2.0])
+            v = np.arange(tab_len, dtype=np.float64)
+            tab[k] = ((params[k] * v) * (v - 1.0)) / 2.0             # the program's operations in its order
+            ts[k] = s
+        for x in (a, b):
+            x.set_propensity_program(ns, params, progs, tables=(ts, tab))
+        b.set_option("ssa_regs", 0)
+        b.set_option("ssa_filter", 0)
+        off, diag = a.propensities(state)
+        off_b, diag_b = b.propensities(state)
+        assert np.array_equal(off, off_b) and np.array_equal(diag, diag_b)
+        for scale, seed in ((0.5, 11), (8.0, 12), (40.0, 13)):
+            t = scale / float(np.mean(diag[diag > 0]))
+            ra = a.ssa_streams(t, seed, nu, state, adj, off, diag, max_count=tab_len - 1, capacity_new=1 << 20)
+            rb = b.ssa_streams(t, seed, nu, state, adj, off, diag, max_count=tab_len - 1, capacity_new=1 << 20)
+            assert len(ra[0]) > 0
+            for u, v in zip(ra, rb):
+                assert np.array_equal(u, v), (scale, len(ra[0]), len(rb[0]))
+
+
 def test_refusals(golden_dir):
     from krylovfspssa_amd import KfspContext, KfspError
     with KfspContext(0) as c:
